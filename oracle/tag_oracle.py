@@ -1,0 +1,583 @@
+"""CPU restatement (oracle) of the text-to-audio-grounding hot path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product package.
+
+Plain PyTorch eager on the CPU, written functionally over a flat ``state`` dict
+whose keys and shapes are the reference's ``state_dict`` names, so the same
+weights can be loaded into the imported reference (tests/golden/make_golden.py)
+and into the HIP path.  Every function cites the reference lines it restates
+(paths relative to /root/reference).
+
+Pinning status
+--------------
+* Rows F3, A1-A5, T1-T2, M0-M3, R1, L1, O1, P1 of SURVEY.md section 8: PINNED by the
+  golden vectors under tests/golden/, produced by importing the reference itself
+  in the build container (tests/golden/make_golden.py).
+* Rows F1/F2 (MelSpectrogram / AmplitudeToDB): the arithmetic lives in
+  torchaudio, a third-party dependency that is NOT vendored in the reference,
+  not listed in its requirements.txt and not installed here: PARITY UNPINNED.
+  ``melscale_fbanks``/``mel_spectrogram``/``amplitude_to_db`` below follow
+  torchaudio's published algorithm (torchaudio.functional.melscale_fbanks,
+  transforms.Spectrogram -> torch.stft, transforms.AmplitudeToDB) anchored on
+  the reference's call sites models/audio_encoder.py:29-37,113-124,68-69,183-184.
+  The filterbank is cross-checked against transformers.audio_utils in
+  tests/test_oracle_golden.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# Frontend (rows F1, F2) -- torchaudio semantics
+# --------------------------------------------------------------------------
+
+
+def _hz_to_mel(freq: float, mel_scale: str) -> float:
+    if mel_scale == "htk":
+        return 2595.0 * math.log10(1.0 + freq / 700.0)
+    f_sp = 200.0 / 3
+    mels = freq / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    if freq >= min_log_hz:
+        mels = min_log_mel + math.log(freq / min_log_hz) / logstep
+    return mels
+
+
+def _mel_to_hz(mels: torch.Tensor, mel_scale: str) -> torch.Tensor:
+    if mel_scale == "htk":
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    log_t = mels >= min_log_mel
+    freqs[log_t] = min_log_hz * torch.exp(logstep * (mels[log_t] - min_log_mel))
+    return freqs
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int,
+                    sample_rate: int, norm: Optional[str], mel_scale: str) -> torch.Tensor:
+    """(n_freqs, n_mels) triangular filterbank, torchaudio algorithm."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = _hz_to_mel(f_min, mel_scale)
+    m_max = _hz_to_mel(f_max, mel_scale)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = _mel_to_hz(m_pts, mel_scale)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.max(torch.zeros(1), torch.min(down, up))
+    if norm == "slaney":
+        enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+        fb = fb * enorm.unsqueeze(0)
+    return fb
+
+
+#: frontend parameter sets (models/audio_encoder.py:107-123 and :29-35)
+FRONTEND = {
+    "cnn8rnn": dict(sample_rate=32000, n_fft=1024, win_length=1024, hop_length=320,
+                    f_min=50.0, f_max=14000.0, n_mels=64, norm="slaney", mel_scale="slaney"),
+    "crnn": dict(sample_rate=32000, n_fft=2048, win_length=1280, hop_length=640,
+                 f_min=0.0, f_max=16000.0, n_mels=64, norm=None, mel_scale="htk"),
+}
+
+
+def frontend_tables(kind: str):
+    """hann window (win_length,) periodic and fb (n_fft//2+1, n_mels) for a parameter set."""
+    p = FRONTEND[kind]
+    window = torch.hann_window(p["win_length"])
+    fb = melscale_fbanks(p["n_fft"] // 2 + 1, p["f_min"], p["f_max"], p["n_mels"],
+                         p["sample_rate"], p["norm"], p["mel_scale"])
+    return window, fb
+
+
+def mel_spectrogram(waveform: torch.Tensor, kind: str, window=None, fb=None) -> torch.Tensor:
+    """power mel spectrogram (B, n_mels, F); torchaudio MelSpectrogram(power=2, center=True)."""
+    p = FRONTEND[kind]
+    if window is None or fb is None:
+        window, fb = frontend_tables(kind)
+    window = window.to(waveform.dtype)
+    fb = fb.to(waveform.dtype)
+    spec = torch.stft(waveform, p["n_fft"], p["hop_length"], p["win_length"], window=window,
+                      center=True, pad_mode="reflect", normalized=False, onesided=True,
+                      return_complex=True)
+    power = spec.abs().pow(2.0)                       # (B, bins, F)
+    return torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
+
+
+def amplitude_to_db(x: torch.Tensor) -> torch.Tensor:
+    """AmplitudeToDB(stype='power', top_db=None): 10 log10(clamp(x,1e-10)) - 10 log10(max(1e-10,1))."""
+    x_db = 10.0 * torch.log10(torch.clamp(x, min=1e-10))
+    x_db = x_db - 10.0 * math.log10(max(1e-10, 1.0))
+    return x_db
+
+
+def logmel(waveform: torch.Tensor, kind: str) -> torch.Tensor:
+    """(B, n_mels, F) in dB -- rows F1+F2."""
+    return amplitude_to_db(mel_spectrogram(waveform, kind))
+
+
+# --------------------------------------------------------------------------
+# State construction (reference init distributions; NOT the reference RNG order)
+# --------------------------------------------------------------------------
+
+CNN8_CHANNELS = [(1, 64), (64, 128), (128, 256), (256, 512)]
+
+
+def _xavier_uniform(shape, gen):
+    # nn.init.xavier_uniform_ (models/panns.py:5-11)
+    if len(shape) == 4:
+        rf = shape[2] * shape[3]
+        fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    else:
+        fan_out, fan_in = shape
+    a = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, generator=gen) * 2 - 1) * a
+
+
+def _uniform(shape, bound, gen):
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def init_state(seed: int = 0, vocab_size: int = 5221, text_dim: int = 512, shared_dim: int = 512,
+               add_proj: bool = False, logit_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Random state for BiEncoder(Cnn8Rnn, EmbeddingAgg(mean), match) with reference key names.
+
+    ``logit_gain`` scales the embedding table so that frame logits span several
+    units (a random-init model gives frame_sim in [0.5001, 0.5042]).
+    """
+    g = torch.Generator().manual_seed(seed)
+    st: Dict[str, torch.Tensor] = {}
+    ae = "audio_encoder."
+
+    def bn(prefix, c, randomize):
+        st[prefix + "weight"] = torch.ones(c) if not randomize else 0.5 + torch.rand(c, generator=g)
+        st[prefix + "bias"] = torch.zeros(c) if not randomize else 0.2 * torch.randn(c, generator=g)
+        st[prefix + "running_mean"] = torch.zeros(c)
+        st[prefix + "running_var"] = torch.ones(c)
+        st[prefix + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    randomize = logit_gain != 1.0
+    bn(ae + "bn0.", 64, randomize)
+    for i, (cin, cout) in enumerate(CNN8_CHANNELS, start=1):
+        st[f"{ae}conv_block{i}.conv1.weight"] = _xavier_uniform((cout, cin, 3, 3), g)
+        st[f"{ae}conv_block{i}.conv2.weight"] = _xavier_uniform((cout, cout, 3, 3), g)
+        bn(f"{ae}conv_block{i}.bn1.", cout, randomize)
+        bn(f"{ae}conv_block{i}.bn2.", cout, randomize)
+    st[ae + "fc1.weight"] = _xavier_uniform((512, 512), g)
+    st[ae + "fc1.bias"] = torch.zeros(512) if not randomize else 0.1 * torch.randn(512, generator=g)
+    k = 1.0 / math.sqrt(256)
+    for sfx in ("", "_reverse"):
+        st[f"{ae}rnn.weight_ih_l0{sfx}"] = _uniform((768, 512), k, g)
+        st[f"{ae}rnn.weight_hh_l0{sfx}"] = _uniform((768, 256), k, g)
+        st[f"{ae}rnn.bias_ih_l0{sfx}"] = _uniform((768,), k, g)
+        st[f"{ae}rnn.bias_hh_l0{sfx}"] = _uniform((768,), k, g)
+    # nn.Embedding + kaiming_uniform_ (models/utils.py:19-20): bound = sqrt(6 / fan_in), fan_in = D
+    st["text_encoder.embedding.core.weight"] = _uniform((vocab_size, text_dim),
+                                                        math.sqrt(6.0 / text_dim), g) * logit_gain
+    if text_dim != 512 or add_proj:
+        for name, din in (("audio_proj", 512), ("text_proj", text_dim)):
+            b = 1.0 / math.sqrt(din)
+            st[name + ".weight"] = _uniform((shared_dim, din), b, g)
+            st[name + ".bias"] = _uniform((shared_dim,), b, g)
+    return st
+
+
+def state_to(st, dtype=None, requires_grad=False):
+    out = {}
+    for k, v in st.items():
+        if v.is_floating_point():
+            v = v.detach().clone().to(dtype or v.dtype)
+            if requires_grad and "running_" not in k:
+                v.requires_grad_(True)
+        else:
+            v = v.clone()
+        out[k] = v
+    return out
+
+
+# --------------------------------------------------------------------------
+# Cnn8Rnn (rows F3, A1-A5)
+# --------------------------------------------------------------------------
+
+
+def _bn(x, st, prefix, training, momentum=0.1, eps=1e-5):
+    # nn.BatchNorm2d semantics; running stats are updated in place when training
+    return F.batch_norm(x, st[prefix + "running_mean"], st[prefix + "running_var"],
+                        st[prefix + "weight"], st[prefix + "bias"], training, momentum, eps)
+
+
+def _dropout(x, p, training, masks, name):
+    """Dropout with an injectable keep-mask so another implementation's RNG can be replayed."""
+    if not training or p == 0.0:
+        return x
+    if masks is not None and name in masks:
+        return x * masks[name].to(x.dtype) / (1.0 - p)
+    return F.dropout(x, p=p, training=True)
+
+
+def conv_block(x, st, prefix, pool_size, training, taps=None):
+    """ConvBlock.forward with pool_type='avg+max' (models/panns.py:46-62)."""
+    y1 = F.conv2d(x, st[prefix + "conv1.weight"], None, 1, 1)
+    a1 = F.relu(_bn(y1, st, prefix + "bn1.", training))
+    y2 = F.conv2d(a1, st[prefix + "conv2.weight"], None, 1, 1)
+    a2 = F.relu(_bn(y2, st, prefix + "bn2.", training))
+    out = F.avg_pool2d(a2, kernel_size=pool_size) + F.max_pool2d(a2, kernel_size=pool_size)
+    if taps is not None:
+        taps[prefix + "conv1"] = y1
+        taps[prefix + "conv2"] = y2
+        taps[prefix + "pool"] = out
+    return out
+
+
+def output_length(waveform_len, hop_length: int, downsample_ratio: int = 4) -> torch.Tensor:
+    """models/audio_encoder.py:219-227 (and :77-84): floor((floor(len / hop) + 1) / 4), int64."""
+    length = torch.div(torch.as_tensor(waveform_len), hop_length, rounding_mode="floor") + 1
+    return torch.div(length, downsample_ratio, rounding_mode="floor")
+
+
+def cnn8rnn_forward(st, waveform, waveform_len, training=False, p_drop=(0.2, 0.5),
+                    masks=None, taps=None, prefix="audio_encoder."):
+    """Cnn8Rnn.forward with specaug=False and no mixup (models/audio_encoder.py:178-232)."""
+    x = logmel(waveform, "cnn8rnn")                   # (B, 64, F)
+    if taps is not None:
+        taps["logmel"] = x
+    x = x.transpose(1, 2).unsqueeze(1)                # (B, 1, F, 64)
+    x = x.transpose(1, 3)
+    x = _bn(x, st, prefix + "bn0.", training)
+    x = x.transpose(1, 3)
+    if taps is not None:
+        taps["bn0"] = x
+    pools = [(2, 2), (2, 2), (1, 2), (1, 2)]
+    for i, ps in enumerate(pools, start=1):
+        x = conv_block(x, st, f"{prefix}conv_block{i}.", ps, training, taps)
+        x = _dropout(x, p_drop[0], training, masks, f"drop{i}")
+    x = torch.mean(x, dim=3)                          # (B, 512, T')
+    x = x.transpose(1, 2)
+    x = _dropout(x, p_drop[1], training, masks, "drop5")
+    x = F.relu(F.linear(x, st[prefix + "fc1.weight"], st[prefix + "fc1.bias"]))
+    if taps is not None:
+        taps["fc1"] = x
+    x = gru_bidir(x, st, prefix + "rnn.")
+    length = output_length(waveform_len, FRONTEND["cnn8rnn"]["hop_length"])
+    return {"embedding": x, "length": length}
+
+
+def gru_bidir(x, st, prefix):
+    """nn.GRU(512, 256, bidirectional=True, batch_first=True), h0 = 0, all T' steps (row A4)."""
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    flat = [st[prefix + n] for n in names] + [st[prefix + n + "_reverse"] for n in names]
+    hidden = flat[1].shape[1]
+    h0 = x.new_zeros(2, x.shape[0], hidden)
+    out, _ = torch.gru(x, h0, flat, True, 1, 0.0, False, True, True)
+    return out
+
+
+def gru_bidir_manual(x, st, prefix):
+    """Explicit gate arithmetic (PyTorch order r, z, n); used to cross-check ``gru_bidir``."""
+    B, T, _ = x.shape
+    outs = []
+    for sfx, order in (("", range(T)), ("_reverse", range(T - 1, -1, -1))):
+        w_ih, w_hh = st[f"{prefix}weight_ih_l0{sfx}"], st[f"{prefix}weight_hh_l0{sfx}"]
+        b_ih, b_hh = st[f"{prefix}bias_ih_l0{sfx}"], st[f"{prefix}bias_hh_l0{sfx}"]
+        H = w_hh.shape[1]
+        h = x.new_zeros(B, H)
+        ys = [None] * T
+        for t in order:
+            gi = F.linear(x[:, t], w_ih, b_ih)
+            gh = F.linear(h, w_hh, b_hh)
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            ys[t] = h
+        outs.append(torch.stack(ys, 1))
+    return torch.cat(outs, -1)
+
+
+# --------------------------------------------------------------------------
+# CrnnEncoder (row A1') -- what the strong eg_config literally instantiates
+# --------------------------------------------------------------------------
+
+
+def init_crnn_state(seed=0, embed_dim=256, prefix="audio_encoder."):
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    chans = {0: (1, 32), 2: (32, 128), 3: (128, 128), 5: (128, 128), 6: (128, 128)}
+    for idx, (cin, cout) in chans.items():
+        p = f"{prefix}cnn.{idx}."
+        st[p + "0.weight"] = torch.ones(cin)
+        st[p + "0.bias"] = torch.zeros(cin)
+        st[p + "0.running_mean"] = torch.zeros(cin)
+        st[p + "0.running_var"] = torch.ones(cin)
+        st[p + "0.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        std = math.sqrt(2.0 / (cin * 9))              # kaiming_normal_ (models/utils.py:6-7)
+        st[p + "1.weight"] = torch.randn((cout, cin, 3, 3), generator=g) * std
+    H = embed_dim // 2
+    k = 1.0 / math.sqrt(H)
+    for sfx in ("", "_reverse"):
+        st[f"{prefix}gru.weight_ih_l0{sfx}"] = _uniform((3 * H, 128), k, g)
+        st[f"{prefix}gru.weight_hh_l0{sfx}"] = _uniform((3 * H, H), k, g)
+        st[f"{prefix}gru.bias_ih_l0{sfx}"] = _uniform((3 * H,), k, g)
+        st[f"{prefix}gru.bias_hh_l0{sfx}"] = _uniform((3 * H,), k, g)
+    return st
+
+
+def _lppool4(x, k):
+    # nn.LPPool2d(4, k): (sum_window x^4)^(1/4), stride = kernel, floor
+    return F.lp_pool2d(x, 4.0, k)
+
+
+def crnn_forward(st, waveform, waveform_len, training=False, p_drop=0.3, masks=None, taps=None,
+                 prefix="audio_encoder."):
+    """CrnnEncoder.forward (models/audio_encoder.py:16-22,39-49,66-86)."""
+    x = logmel(waveform, "crnn").transpose(1, 2).unsqueeze(1)   # (B,1,F,64)
+    if taps is not None:
+        taps["logmel"] = x
+
+    def block(x, idx):
+        p = f"{prefix}cnn.{idx}."
+        x = _bn(x, st, p + "0.", training)
+        x = F.conv2d(x, st[p + "1.weight"], None, 1, 1)
+        return F.leaky_relu(x, 0.1)
+
+    x = _lppool4(block(x, 0), (2, 4))
+    x = _lppool4(block(block(x, 2), 3), (2, 4))
+    x = _lppool4(block(block(x, 5), 6), (1, 4))
+    x = _dropout(x, p_drop, training, masks, "drop")
+    x = x.transpose(1, 2).contiguous().flatten(-2)
+    if taps is not None:
+        taps["cnn"] = x
+    x = gru_bidir(x, st, prefix + "gru.")
+    length = output_length(waveform_len, FRONTEND["crnn"]["hop_length"])
+    return {"embedding": x, "length": length}
+
+
+# --------------------------------------------------------------------------
+# Text encoder (rows T1, T2), heads (M0-M3), loss (R1, L1)
+# --------------------------------------------------------------------------
+
+
+def length_mask(lens, max_length=None) -> torch.Tensor:
+    """models/utils.py:22-30: arange(L) < len."""
+    lens = torch.as_tensor(lens)
+    if max_length is None:
+        max_length = int(lens.max().item())
+    return torch.arange(max_length).unsqueeze(0) < lens.view(-1, 1)
+
+
+def embedding_agg_mean(st, text, text_len, prefix="text_encoder."):
+    """EmbeddingAgg(aggregation='mean') (models/text_encoder.py:79-88; models/utils.py:33-58)."""
+    table = st[prefix + "embedding.core.weight"]
+    embs = F.embedding(text.long(), table)            # (B, L, D)
+    lens = torch.as_tensor(text_len)
+    mask = length_mask(lens, embs.size(1)).unsqueeze(-1).to(embs.dtype)
+    seq = (embs * mask).sum(1) / lens.view(-1, 1).to(embs.dtype)
+    return {"token_emb": embs, "seq_emb": seq}
+
+
+def match_exp_neg_l2(audio, text, l2norm=True):
+    """match.ExpNegL2 (models/match.py:16-33), text_level='seq'."""
+    if l2norm:
+        audio = F.normalize(audio, dim=-1)
+        text = F.normalize(text, dim=-1)
+    diff = audio - text.unsqueeze(1)
+    return torch.exp(-torch.norm(diff, dim=-1))
+
+
+def match_dot_product(audio, text, l2norm=False, scale=True, return_logit=False):
+    """match.DotProduct (models/match.py:43-60), text_level='seq'."""
+    if l2norm:
+        audio = F.normalize(audio, dim=-1)
+        text = F.normalize(text, dim=-1)
+    score = (audio * text.unsqueeze(1)).sum(-1)
+    if scale:
+        score = score / math.sqrt(audio.size(-1))
+    if return_logit:
+        return score
+    return torch.sigmoid(score).clamp(1e-7, 1.0)
+
+
+def align_dot_product(audio, text, l2norm=False, scaled=False):
+    """align.DotProduct (models/align.py:14-31): (B,T,D),(B,N,D) -> (B,B,T,N)."""
+    if l2norm:
+        audio = F.normalize(audio, dim=-1)
+        text = F.normalize(text, dim=-1)
+    B, T, D = audio.shape
+    N = text.shape[1]
+    score = audio.reshape(-1, D) @ text.reshape(-1, D).t()
+    if scaled:
+        score = score / math.sqrt(D)
+    score = torch.sigmoid(score).clamp(1e-7, 1.0)
+    return score.reshape(B, T, B, N).transpose(1, 2)
+
+
+def biencoder_forward(st, batch, match="dot", audio="cnn8rnn", training=False, p_drop=None,
+                      masks=None, taps=None):
+    """BiEncoder.forward (models/audio_text_model.py:58-98), cross_encoder=None, upsample=False."""
+    if audio == "cnn8rnn":
+        kw = {} if p_drop is None else {"p_drop": p_drop}
+        ao = cnn8rnn_forward(st, batch["waveform"], batch["waveform_len"], training, masks=masks,
+                             taps=taps, **kw)
+    else:
+        kw = {} if p_drop is None else {"p_drop": p_drop}
+        ao = crnn_forward(st, batch["waveform"], batch["waveform_len"], training, masks=masks,
+                          taps=taps, **kw)
+    audio_emb = ao["embedding"]
+    te = embedding_agg_mean(st, batch["text"], batch["text_len"])
+    seq = te["seq_emb"]
+    if "audio_proj.weight" in st:
+        audio_emb = F.linear(audio_emb, st["audio_proj.weight"], st["audio_proj.bias"])
+        seq = F.linear(seq, st["text_proj.weight"], st["text_proj.bias"])
+    if taps is not None:
+        taps["audio_emb"] = audio_emb
+        taps["seq_emb"] = seq
+    if match == "dot":
+        if taps is not None:
+            taps["logit"] = match_dot_product(audio_emb, seq, return_logit=True)
+        sim = match_dot_product(audio_emb, seq)
+    elif match == "expnegl2":
+        sim = match_exp_neg_l2(audio_emb, seq)
+    else:
+        raise ValueError(match)
+    return {"frame_sim": sim, "length": ao["length"]}
+
+
+def runner_truncate(output, label):
+    """Runner.forward label alignment (python_scripts/training/run_strong.py:107-118)."""
+    frame_sim = output["frame_sim"]
+    tt = min(frame_sim.size(1), label.size(1))
+    return {"frame_sim": frame_sim[..., :tt], "label": label[..., :tt],
+            "length": torch.clamp(output["length"], 1, tt)}
+
+
+def frame_bce_loss(frame_sim, label, length):
+    """FrameBceLoss.forward (losses.py:12-24)."""
+    loss = F.binary_cross_entropy(frame_sim, label, reduction="none")
+    mask = length_mask(length).to(frame_sim.dtype)
+    if mask.shape[1] < loss.shape[1]:     # generate_length_mask uses max(length) columns
+        mask = F.pad(mask, (0, loss.shape[1] - mask.shape[1]))
+    return (loss * mask).sum() / mask.sum()
+
+
+def train_step_loss(st, batch, match="dot", audio="cnn8rnn", training=True, p_drop=None,
+                    masks=None, taps=None):
+    """zero_grad -> forward -> FrameBceLoss, the timed unit of BASELINE.md section 3."""
+    out = biencoder_forward(st, batch, match, audio, training, p_drop, masks, taps)
+    out = runner_truncate(out, batch["label"])
+    return frame_bce_loss(out["frame_sim"], out["label"], out["length"]), out
+
+
+# --------------------------------------------------------------------------
+# Synthetic batch (BASELINE.md section 3 / SURVEY section 8d)
+# --------------------------------------------------------------------------
+
+
+def synthetic_batch(batch_size: int, n_samples: int = 320000, seed: int = 1234, ragged: bool = False,
+                    hop: int = 320, vocab_size: int = 5221):
+    g = torch.Generator().manual_seed(seed)
+    waveform = 0.1 * torch.randn(batch_size, n_samples, generator=g)
+    if ragged:
+        lens = torch.randint(n_samples // 2, n_samples + 1, (batch_size,), generator=g)
+        lens[0] = n_samples
+        for i in range(batch_size):
+            waveform[i, lens[i]:] = 0.0
+    else:
+        lens = torch.full((batch_size,), n_samples, dtype=torch.long)
+    text = torch.randint(2, vocab_size, (batch_size, 4), generator=g)
+    text_len = 1 + torch.arange(batch_size) % 4
+    for i in range(batch_size):
+        text[i, text_len[i]:] = 0                     # pad id 0 (utils/build_vocab.py:42-43)
+    t_out = (n_samples // hop + 1) // 4
+    label = (torch.rand(batch_size, t_out, generator=g) < 0.5).float()
+    return {"waveform": waveform, "waveform_len": lens.numpy(), "text": text,
+            "text_len": text_len.numpy(), "label": label}
+
+
+# --------------------------------------------------------------------------
+# Post-processing (row P1) -- integer work, numpy
+# --------------------------------------------------------------------------
+
+
+def binarize(x: np.ndarray, threshold) -> np.ndarray:
+    """eval_util.binarize (utils/eval_util.py:47-52 -> sklearn.preprocessing.binarize):
+    strict ``x > threshold`` evaluated in float64 (the thresholds are np.float64 scalars,
+    run_strong.py:203-205, which promote the float32 scores), result 0/1 in x's dtype."""
+    x = np.asarray(x)
+    return (x.astype(np.float64) > np.float64(threshold)).astype(x.dtype)
+
+
+def median_filter_1d(b: np.ndarray, window_size: int) -> np.ndarray:
+    """scipy.ndimage.median_filter along time with mode='reflect' (utils/eval_util.py:55-63).
+
+    Window of ``size`` samples covering [i - size//2, i - size//2 + size - 1], boundary
+    'reflect' = (d c b a | a b c d | d c b a); element of rank size//2 of the sorted window.
+    """
+    b = np.asarray(b)
+    if window_size <= 1:
+        return b.copy()
+    T = b.shape[-1]
+    left = window_size // 2
+    idx = np.arange(-left, T + window_size - left - 1)
+    period = 2 * T
+    idx = np.mod(idx, period)
+    idx = np.where(idx >= T, period - 1 - idx, idx)
+    padded = b[..., idx]
+    win = np.lib.stride_tricks.sliding_window_view(padded, window_size, axis=-1)
+    return np.sort(win, axis=-1)[..., window_size // 2].astype(b.dtype)
+
+
+def find_contiguous_regions(a: np.ndarray) -> np.ndarray:
+    """utils/eval_util.py:18-44 -> (K, 2) int64 rows [onset, offset)."""
+    a = np.asarray(a).astype(bool)
+    out = []
+    start = None
+    for i, v in enumerate(a):
+        if v and start is None:
+            start = i
+        elif not v and start is not None:
+            out.append((start, i))
+            start = None
+    if start is not None:
+        out.append((start, a.size))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2)
+
+
+def connect_clusters(x: np.ndarray, n: int) -> np.ndarray:
+    """utils/eval_util.py:74-116: merge regions whose gap (next onset - cur offset) <= n."""
+    x = np.asarray(x)
+    reg = find_contiguous_regions(x)
+    out = np.zeros_like(x, dtype=int)
+    if len(reg) == 0:
+        return out
+    start, end = reg[0]
+    merged = []
+    for cur, nxt in zip(reg[:-1], reg[1:]):
+        end = nxt[1]
+        if nxt[0] - cur[1] > n:
+            merged.append((start, cur[1]))
+            start = nxt[0]
+    merged.append((start, end))
+    for s, e in merged:
+        out[s:e] = 1
+    return out
+
+
+def segments(frame_sim_row: np.ndarray, threshold, window_size: int, n_connect: int) -> np.ndarray:
+    """The per-(clip, threshold) chain of run_strong.py:234-252."""
+    b = median_filter_1d(binarize(frame_sim_row, threshold), window_size)
+    return find_contiguous_regions(connect_clusters(b, n_connect))
+
+
+def eval_thresholds(n_thresholds: int = 50) -> np.ndarray:
+    """run_strong.py:203-205."""
+    return np.arange(1 / (n_thresholds * 2), 1, 1 / n_thresholds)

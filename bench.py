@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/s of the hot path (log-mel -> Cnn8Rnn -> w2v-mean text encoder -> frame
+similarity -> FrameBceLoss), forward + backward + gradient all-reduce + clip + Adam, on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512, mean) + match.DotProduct, fp32,
+batch 64 per GPU, 10 s @ 32 kHz synthetic clips, dropout on, train-mode BatchNorm (weak scaling: per-GPU batch
+fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_CLIP = 101.7e9          # 3 x 33.90 GFLOP forward
+PEAK_FP32_MFMA = 157.3           # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+
+
+def synthetic_batch(B, n_samples, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    wave = 0.1 * torch.randn(B, n_samples, generator=g)
+    text = torch.randint(2, 5221, (B, 4), generator=g)
+    text_len = 1 + torch.arange(B) % 4
+    for i in range(B):
+        text[i, text_len[i]:] = 0
+    label = (torch.rand(B, (n_samples // 320 + 1) // 4, generator=g) < 0.5).float()
+    return {"waveform": wave.to(device), "waveform_len": torch.full((B,), n_samples).numpy(), "text": text.to(device),
+            "text_len": text_len.to(device), "label": label.to(device)}
+
+
+def cpu_baseline(batch=8, iters=2):
+    """The oracle (plain PyTorch eager CPU restatement) timed on the host cores: fwd+bwd, dropout on."""
+    from oracle import tag_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    st = O.state_to(O.init_state(seed=0), torch.float32, requires_grad=True)
+    b = O.synthetic_batch(batch, 320000, seed=1234)
+    times = []
+    for i in range(iters + 1):
+        for v in st.values():
+            if v.is_floating_point() and v.grad is not None:
+                v.grad = None
+        t0 = time.perf_counter()
+        loss, _ = O.train_step_loss(st, b, "dot", "cnn8rnn", True)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fwd+bwd, B={batch} x 10 s clips, median of {iters} after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
+    from texttoaudiogrounding_amd.runner import StrongRunner, init_distributed
+
+    rank, world, local = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                       match.DotProduct(), 512)
+    runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(device))
+    batch = synthetic_batch(args.batch, 320000, 1234 + rank, device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.train_step(dict(batch))
+    sync()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner.train_step(dict(batch))
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    clips = world * args.batch * args.steps
+    value = clips / dt
+
+    # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad), HIP events on the launch stream
+    fam = {}
+    for key, evs in prof.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        fl = sum(f for _, _, f in evs)
+        d = fam.setdefault(key[0], {"ms": 0.0, "flop": 0.0, "launches": 0})
+        d["ms"] += ms; d["flop"] += fl; d["launches"] += len(evs)
+    dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
+    roof = None
+    if dom:
+        ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA, 4), "traffic": None,
+                "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
+                "share_of_step": round(fam[dom]["ms"] * 1e-3 / dt, 3),
+                "families": {k: {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                 "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in fam.items()}}
+    if rank == 0:
+        out = {"metric": "clips/sec (10 s@32 kHz, 1-phrase) fwd+bwd", "value": round(value, 2), "unit": "clips/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "
+                                      "fwd+bwd+clip+Adam, dropout on, train-mode BN", "batch_per_gpu": args.batch,
+                          "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}"},
+               "loss": round(float(loss.item()), 6),
+               "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 / PEAK_FP32_MFMA, 4),
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

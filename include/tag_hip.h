@@ -1,0 +1,231 @@
+/*
+ * tag_hip.h -- C ABI of libtag_hip.so: the MI355X (gfx950) hot path of text-to-audio grounding.
+ *
+ * The reference (wsntxxn/TextToAudioGrounding) is pure Python/PyTorch: it has no FFI of its own.
+ * The replaceable seam is the nn.Module contract of SURVEY.md section 8(b); every entry point below
+ * names the reference call site whose arithmetic it replaces (paths relative to the reference
+ * root).  The Python host side (texttoaudiogrounding_amd/) binds these with ctypes and mirrors the
+ * reference's module names and forward() signatures; INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
+ *   - all floating tensors are contiguous fp32 unless a stride is given; indices are int64;
+ *   - image tensors are channels-last: (B, H=time, W=freq, C);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are async;
+ *   - return value: 0 on success, otherwise a negative TAG_E* code or a positive hipError_t;
+ *     tag_last_error() returns a static, thread-local message for the last failure;
+ *   - no call allocates device memory: scratch is passed in by the caller (`ws`), with the size
+ *     given by the matching *_ws_bytes() query.
+ */
+#ifndef TAG_HIP_H
+#define TAG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAG_ABI_VERSION 1
+#define TAG_EINVAL (-1) /* bad argument (shape not supported, null pointer, ...) */
+#define TAG_ELAUNCH (-2)
+
+int tag_abi_version(void);
+const char* tag_last_error(void);
+/* number of CUs of the current device (used by the host to size split-K workspaces) */
+int tag_device_cu_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * F1 + F2: torchaudio MelSpectrogram(power=2, center=True, reflect) + AmplitudeToDB(power)
+ * models/audio_encoder.py:113-124,183-184 (Cnn8Rnn) and :29-37,68-69 (CrnnEncoder).
+ * wave (B,S) -> out (B, F=S/hop+1, n_mels) in dB, time-major (= the (B,1,F,n_mels) image the CNN reads).
+ * window: (win_length) hann; fb: (n_fft/2+1, n_mels).  n_fft in {1024, 2048}; n_mels <= 64.
+ * power_out (nullable): (B,F,n_mels) mel power before the dB step (parity is checked in the power domain).
+ * ------------------------------------------------------------------------------------------- */
+int tag_logmel_forward(const float* wave, int B, int S, int n_fft, int win_length, int hop,
+                       const float* window, const float* fb, int n_mels, float* out_db,
+                       float* power_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F3 / A1: BatchNorm2d statistics over a channels-last tensor x (rows, C)  (nn.BatchNorm2d, train)
+ * models/audio_encoder.py:133,188-190 (bn0 over the mel axis) and models/panns.py:35-36,49-50.
+ * Produces batch mean / invstd (biased var, eps) and the fused affine  scale = gamma*invstd,
+ * shift = beta - mean*scale; updates running_mean/var (momentum, unbiased var) when non-null.
+ * pre_op: 0 = stats of x; 1 = stats of leaky_relu(x, 0.1) (CrnnEncoder cdur_block chain).
+ * ------------------------------------------------------------------------------------------- */
+size_t tag_bn_stats_ws_bytes(long rows, int C);
+int tag_bn_stats(const float* x, long rows, int C, int pre_op, const float* gamma, const float* beta,
+                 float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                 float* invstd, float* scale, float* shift, void* ws, void* stream);
+/* eval mode: scale/shift from running statistics */
+int tag_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       void* stream);
+/* y = x*scale[c] + shift[c] over (rows, C) (bn0 apply) */
+int tag_affine_forward(const float* x, long rows, int C, const float* scale, const float* shift,
+                       float* y, void* stream);
+/* dgamma[c] = sum dy*xhat, dbeta[c] = sum dy  for a plain affine BN (bn0): xhat=(x-mean)*invstd */
+int tag_bn_param_grad(const float* x, const float* dy, long rows, int C, const float* mean,
+                      const float* invstd, float* dgamma, float* dbeta, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1: 3x3 convolution, stride 1, pad 1, no bias (models/panns.py:25-33,49-50), channels-last,
+ * implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   wpack: (9, Cin, Cout) produced by tag_pack_conv_weight.
+ *   prologue applied to x on load (padding stays zero):
+ *     0 none | 1 relu(x*in_scale[c]+in_shift[c]) | 2 leaky(x,.1)*in_scale+in_shift | 3 x*in_scale+in_shift
+ * Requires Cin % 32 == 0 (use tag_conv3x3_c1_* for Cin == 1).
+ * The same entry computes dgrad when given the flipped/transposed pack (wdgrad) and dy as x.
+ * ------------------------------------------------------------------------------------------- */
+int tag_pack_conv_weight(const float* w /*(Cout,Cin,3,3)*/, float* wfwd /*(9,Cin,Cout)*/,
+                         float* wdgrad /*(9,Cout,Cin), nullable*/, int Cin, int Cout, void* stream);
+int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
+                        const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                        void* stream);
+/* dw (Cout,Cin,3,3) = sum over pixels of prologue(x)[shifted] * dy ; ws from *_ws_bytes */
+size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift,
+                      const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                      void* stream);
+/* Cin == 1 (conv_block1.conv1): x (B,H,W) with optional per-column affine x*col_scale[w]+col_shift[w]
+ * (bn0 folded: the BatchNorm2d(64) over the mel axis), w (Cout,1,3,3) */
+int tag_conv3x3_c1_forward(const float* x, const float* col_scale, const float* col_shift,
+                           const float* w, float* y, int B, int H, int W, int Cout, void* stream);
+size_t tag_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout);
+int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, const float* col_shift,
+                         const float* dy, float* dw, int B, int H, int W, int Cout, void* ws,
+                         void* stream);
+int tag_conv3x3_c1_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int Cout,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1 + A2: relu(bn(y)) -> avg_pool + max_pool (kernel = stride = (ph,pw), floor) -> dropout
+ * models/panns.py:49-58 with pool_type 'avg+max'; F.dropout models/audio_encoder.py:203-210.
+ * y raw conv output (B,H,W,C); out (B,H/ph,W/pw,C).  Dropout keep-mask = counter-based hash of
+ * (seed, flat output index); p = 0 disables.  act: 1 relu(bn) | 2 leaky(.1) without bn (scale=NULL),
+ * pool: 0 avg+max | 1 LPPool(norm 4).
+ * ------------------------------------------------------------------------------------------- */
+int tag_bnact_pool_forward(const float* y, const float* scale, const float* shift, float* out, int B,
+                           int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
+                           uint64_t seed, void* stream);
+/* backward of the above + the BatchNorm backward, two passes:
+ *   reduce: dgamma/dbeta (needs ws), apply: dy = invstd*gamma*(dz - dbeta/N - xhat*dgamma/N)
+ * dout is the gradient wrt `out`.  */
+size_t tag_bn_backward_ws_bytes(long rows, int C);
+int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* gamma,
+                             const float* dout, float* dy, float* dgamma, float* dbeta, int B, int H,
+                             int W, int C, int ph, int pw, float drop_p, uint64_t seed, int bn_train,
+                             void* ws, void* stream);
+/* same without pooling: upstream gradient da (rows,C) wrt relu(bn(y)); dy may alias da */
+int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, const float* gamma, const float* da, float* dy,
+                        float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
+                        void* stream);
+/* materialise the dropout keep-mask (0/1 bytes) the kernels above use, for parity tests */
+int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream);
+
+/* A3: mean over W then dropout: x (rows, W, C) -> (rows, C)   models/audio_encoder.py:212-215 */
+int tag_mean_w_forward(const float* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out,
+                       void* stream);
+int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p, uint64_t seed,
+                        float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the MFMA, row-major:  C = act(op(A) op(B) + bias) [+ C if accumulate]
+ *   op(A): transA ? A^T : A, A stored (M,K) ld=lda or (K,M) when transA; same for B (K,N)/(N,K).
+ * Serves nn.Linear fc1 / audio_proj / text_proj (models/audio_encoder.py:140,216;
+ * models/audio_text_model.py:45-46,78-87), the GRU input projections and all their backward GEMMs.
+ * act: 0 none, 1 relu.  bias (N) nullable.
+ * ------------------------------------------------------------------------------------------- */
+int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C,
+             int ldc, int M, int N, int K, const float* bias, int act, int accumulate, void* stream);
+/* out[n] = sum_m x[m, n] (bias gradients); x (M,N) ld; ws >= tag_colsum_ws_bytes */
+size_t tag_colsum_ws_bytes(long M, int N);
+int tag_colsum(const float* x, int ld, long M, int N, float* out, void* ws, void* stream);
+/* dx = dy * (y > 0) elementwise (relu_ backward), dx may alias dy */
+int tag_relu_backward(const float* y, const float* dy, float* dx, long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4: bidirectional GRU recurrence, PyTorch gate order (r,z,n), h0 = 0, ALL T steps
+ * nn.GRU(512,256,bidirectional=True,batch_first=True) models/audio_encoder.py:141,217.
+ *   gi   (B,T,2,3H): x W_ih^T + b_ih for both directions (a tag_gemm)
+ *   w_hh (2,3H,H), b_hh (2,3H)
+ *   y    (B,T,2H)   hidden states, forward direction in [:H], reverse in [H:]
+ *   gates(B,T,2,4H) saved r,z,n and (W_hn h + b_hn) for the backward pass (nullable in inference)
+ * backward: dy (B,T,2H) -> dgi (B,T,2,3H), dgh (B,T,2,3H); hprev (B,T,2,H) is also written
+ * (h_{t-1} per direction) so that dW_hh = dgh^T hprev is a plain GEMM for the caller.
+ * scratch: (2,B,H) floats for the running dh.
+ * ------------------------------------------------------------------------------------------- */
+int tag_gru_forward(const float* gi, const float* w_hh, const float* b_hh, float* y, float* gates,
+                    float* ws /* 2*3*H*H floats */, int B, int T, int H, void* stream);
+int tag_gru_backward(const float* dy, const float* y, const float* gates, const float* w_hh,
+                     float* dgi, float* dgh, float* hprev, float* scratch, int B, int T, int H,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * T1 + T2: nn.Embedding gather + mean over valid tokens
+ * models/text_encoder.py:39-43,79-88; models/utils.py:33-58.
+ * text (B,L) int64, text_len (B) int64, table (V,D); token_emb (B,L,D) nullable; seq_emb (B,D).
+ * backward accumulates into dtable (V,D), which the caller zero-fills.
+ * ------------------------------------------------------------------------------------------- */
+int tag_embed_mean_forward(const int64_t* text, const int64_t* text_len, const float* table,
+                           float* token_emb, float* seq_emb, int B, int L, int D, int V, void* stream);
+int tag_embed_mean_backward(const float* dseq, const int64_t* text, const int64_t* text_len,
+                            float* dtable, int B, int L, int D, int V, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * M1 / M2: frame x phrase heads, text_level 'seq'   models/match.py:16-33 (ExpNegL2), :43-60 (DotProduct)
+ * kind 0: sigmoid(a.t [/sqrt(D)]).clamp(1e-7,1)   kind 1: exp(-||a - t||)   (l2norm: normalise both first)
+ * audio (B,T,D), text (B,D) -> sim (B,T).  backward -> daudio (B,T,D), dtext (B,D).
+ * ------------------------------------------------------------------------------------------- */
+int tag_match_forward(const float* audio, const float* text, float* sim, int kind, int l2norm,
+                      int scale, int B, int T, int D, void* stream);
+int tag_match_backward(const float* audio, const float* text, const float* sim, const float* dsim,
+                       float* daudio, float* dtext, int kind, int l2norm, int scale, int B, int T,
+                       int D, void* stream);
+
+/* M3: align.DotProduct models/align.py:14-31: audio (B,T,D), text (B,N,D) -> (B,B,T,N) */
+int tag_align_dot_forward(const float* audio, const float* text, float* out, int l2norm, int scaled,
+                          int B, int T, int N, int D, float* ws /* (B*T + B*N)*D floats when l2norm */,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R1 + L1: FrameBceLoss losses.py:12-24 after the label alignment of run_strong.py:107-118.
+ * sim (B, >=Tt) row stride ld_sim, label (B, >=Tt) row stride ld_label, length (B) int64 (unclamped:
+ * clamped to [1,Tt] inside).  loss: 1 float.  backward: dsim (B,ld_sim) zero outside the mask.
+ * ------------------------------------------------------------------------------------------- */
+int tag_frame_bce_forward(const float* sim, int ld_sim, const float* label, int ld_label,
+                          const int64_t* length, int B, int Tt, float* loss, void* stream);
+int tag_frame_bce_backward(const float* sim, int ld_sim, const float* label, int ld_label,
+                           const int64_t* length, int B, int Tt, const float* dloss, float* dsim,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * P1: post-processing utils/eval_util.py:18-116 driven as in run_strong.py:203-252:
+ * binarize (strict >, float64 compare) -> median filter (window, scipy 'reflect') -> connect
+ * clusters (gap <= n_connect) -> contiguous regions.  One (clip, threshold) pair per thread.
+ * sim (B,T) ld; thresholds (NT) double; regions (B,NT,max_regions,2) int64 rows [onset, offset);
+ * counts (B,NT) int32.
+ * ------------------------------------------------------------------------------------------- */
+int tag_segments(const float* sim, int ld, int B, int T, const double* thresholds, int NT, int window,
+                 int n_connect, int64_t* regions, int32_t* counts, int max_regions, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * O1: clip_grad_norm_ + Adam on a flat fp32 buffer (run_strong.py:143-145; torch.optim.Adam).
+ * tag_sumsq: out[0] (double) = sum g^2 (zero-filled by the call).  tag_adam_step reads the squared
+ * norm from device memory: coef = min(1, max_norm / (sqrt(gnorm_sq) + 1e-6)); max_norm <= 0 disables.
+ * grad_scale multiplies g first (1/world_size for DP averaging).
+ * ------------------------------------------------------------------------------------------- */
+size_t tag_sumsq_ws_bytes(long n);
+int tag_sumsq(const float* g, long n, double* out, void* ws, void* stream);
+int tag_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                  float beta2, float eps, int step, const double* gnorm_sq, float max_norm,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAG_HIP_H */

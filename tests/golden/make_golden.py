@@ -154,7 +154,7 @@ def case_whole_path(name, audio, match, text_dim, training, dropout_seed=None, s
     batch = make_batch(hop)
     if audio == "cnn8rnn":
         st = O.init_state(seed=7, text_dim=text_dim, shared_dim=256 if text_dim != 512 else 512,
-                          logit_gain=6.0)
+                          logit_gain=120.0)
     else:
         st = O.init_crnn_state(seed=7)
         g = torch.Generator().manual_seed(8)

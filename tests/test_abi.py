@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/tag_hip.h declares;
+the host-side mirror keeps the reference's names, constructor arguments and state-dict keys; and the
+product package never touches the oracle."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "tag_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tag_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from texttoaudiogrounding_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    handle = lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/tag_hip.h but not exported"
+    assert sorted(lib.declared_symbols()) == syms, "lib.py signature table and the header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (tag_[a-z0-9_]+)", out))
+    assert set(syms) <= exported
+    assert handle.tag_abi_version() == 1
+
+
+def test_code_object_is_gfx950_only():
+    from texttoaudiogrounding_amd import lib
+    blob = open(lib.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_missing_gpu_fails_loudly():
+    """No silent CPU fallback: a CPU tensor must raise, not compute."""
+    from texttoaudiogrounding_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.logmel(torch.zeros(1, 4000), 1024, 1024, 320, torch.zeros(1024), torch.zeros(513, 64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "texttoaudiogrounding_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_reference_shaped_interface():
+    from texttoaudiogrounding_amd.models import align, audio_encoder, audio_text_model, match, text_encoder
+    from texttoaudiogrounding_amd import losses
+    from oracle import tag_oracle as O
+    ae = audio_encoder.Cnn8Rnn(sample_rate=32000, freeze_cnn=False, freeze_bn=False, pretrained=None)
+    assert (ae.embed_dim, ae.downsample_ratio, ae.time_resolution, ae.hop_length) == (512, 4, 0.04, 320)
+    assert audio_encoder.Cnn8_Rnn is audio_encoder.Cnn8Rnn
+    te = text_encoder.EmbeddingAgg(vocab_size=5221, embed_dim=256, pretrained_embedding=None, freeze_embedding=False,
+                                   aggregation="mean")
+    model = audio_text_model.BiEncoder(ae, te, match.ExpNegL2(l2norm=True, text_level="seq"), shared_dim=256,
+                                       cross_encoder=None, add_proj=False, upsample=False,
+                                       freeze_audio_encoder=False, freeze_text_encoder=False, pretrained=None)
+    keys = set(model.state_dict())
+    want = set(O.init_state(text_dim=256, shared_dim=256))
+    assert want <= keys
+    assert keys - want == {"audio_encoder.melspec_extractor.spectrogram.window",
+                           "audio_encoder.melspec_extractor.mel_scale.fb"}     # torchaudio's persistent buffers
+    assert sum(p.numel() for p in model.parameters()) == 7_665_344
+    m2 = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                    match.DotProduct(l2norm=False, scale=True, text_level="seq"), 512)
+    assert not hasattr(m2, "audio_proj") and sum(p.numel() for p in m2.parameters()) == 8_804_800
+    assert isinstance(losses.FrameBceLoss(), torch.nn.Module) and align.DotProduct(l2norm=False, scaled=False)
+    # length arithmetic (row A5) is host-side integer work
+    length = torch.div(torch.div(torch.as_tensor([320000, 160000, 1]), 320, rounding_mode="floor") + 1, 4,
+                       rounding_mode="floor")
+    assert length.tolist() == [250, 125, 0]
+    # frozen-CNN / frozen-BN switches
+    fz = audio_encoder.Cnn8Rnn(32000, freeze_cnn=True, freeze_bn=True).train()
+    assert not fz.fc1.weight.requires_grad and fz.rnn.weight_hh_l0.requires_grad and not fz.bn0.training
+
+
+def test_yaml_style_construction_with_aliases():
+    import texttoaudiogrounding_amd as pkg
+    from texttoaudiogrounding_amd.runner import build_model
+    pkg.install_aliases(force=True)
+    cfg = {"audio_encoder": {"type": "models.audio_encoder.Cnn8Rnn", "args": {"sample_rate": 32000}},
+           "text_encoder": {"type": "models.text_encoder.EmbeddingAgg",
+                            "args": {"embed_dim": 512, "vocab_size": 5221, "aggregation": "mean"}},
+           "match_fn": {"type": "models.match.DotProduct", "args": {"text_level": "seq"}},
+           "type": "models.audio_text_model.BiEncoder",
+           "args": {"shared_dim": 512, "add_proj": False, "upsample": False}}
+    model = build_model(cfg)
+    assert type(model).__name__ == "BiEncoder" and type(model).__module__.startswith("texttoaudiogrounding_amd")
+    import sys
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "losses"]:
+        del sys.modules[k]

@@ -1,0 +1,401 @@
+"""Per-kernel parity: every C-ABI entry point of libtag_hip.so against the oracle / a plain torch
+fp32-or-fp64 CPU restatement of the same op, on seeded inputs small enough for the CPU to finish in
+seconds.  Tolerances are stated per test; integer outputs must be bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):   # (B,C,H,W) -> (B,H,W,C) contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from texttoaudiogrounding_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------- frontend
+@pytest.mark.parametrize("kind", ["cnn8rnn", "crnn"])
+def test_logmel_vs_oracle(ops, dev, kind):
+    g = torch.Generator().manual_seed(1)
+    wave = 0.1 * torch.randn(3, 20000, generator=g)
+    wave[1, 15000:] = 0.0                                   # zero-padded tail -> -100 dB floor
+    wave[2] = 0.5 * torch.sin(2 * math.pi * 1000.0 * torch.arange(20000) / 32000.0)
+    p = O.FRONTEND[kind]
+    window, fb = O.frontend_tables(kind)
+    db, power = ops.logmel(wave.to(dev), p["n_fft"], p["win_length"], p["hop_length"], window.to(dev), fb.to(dev),
+                           want_power=True)
+    ref_power = O.mel_spectrogram(wave.double(), kind).transpose(1, 2)        # fp64 oracle, (B,F,mel)
+    ref32 = O.mel_spectrogram(wave, kind).transpose(1, 2)
+    scale = ref_power.abs().amax(dim=(1, 2), keepdim=True)
+    err = ((power.cpu().double() - ref_power).abs() / scale).max().item()
+    err32 = ((ref32.double() - ref_power).abs() / scale).max().item()
+    print(f"logmel[{kind}] power err vs fp64 oracle {err:.2e} (fp32 oracle itself {err32:.2e})")
+    assert err < 5e-6                                       # power-domain tolerance, relative to clip max
+    ref_db = O.amplitude_to_db(ref_power)
+    big = ref_power > 1e-4 * scale                          # away from the rounding-sensitive floor
+    assert (db.cpu().double() - ref_db)[big].abs().max().item() < 1e-3       # dB
+    assert torch.all(db[1, -5:].cpu() == -100.0)            # silent frames hit the clamp exactly
+
+
+def test_logmel_known_answers(ops, dev, golden_dir):
+    gold = np.load(f"{golden_dir}/frontend.npz")
+    n = torch.arange(32000, dtype=torch.float32)
+    x = (0.5 * torch.sin(2 * math.pi * 1000.0 * n / 32000.0)).unsqueeze(0)
+    for kind in ("cnn8rnn", "crnn"):
+        p = O.FRONTEND[kind]
+        window, fb = O.frontend_tables(kind)
+        db = ops.logmel(x.to(dev), p["n_fft"], p["win_length"], p["hop_length"], window.to(dev), fb.to(dev))
+        ref = torch.from_numpy(gold[f"sine_{kind}"]).transpose(1, 2)          # (1,F,64)
+        strong = ref > -40.0
+        assert (db.cpu() - ref)[strong].abs().max().item() < 2e-3
+    # SURVEY appendix A known answers (Cnn8Rnn set): frame 50 peak bin 17 = 23.6652 dB
+    p = O.FRONTEND["cnn8rnn"]
+    window, fb = O.frontend_tables("cnn8rnn")
+    db = ops.logmel(x.to(dev), p["n_fft"], p["win_length"], p["hop_length"], window.to(dev), fb.to(dev)).cpu()
+    assert int(db[0, 50].argmax()) == 17 and abs(db[0, 50, 17].item() - 23.6652) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("C,rows", [(64, 3003), (128, 1000), (512, 777)])
+def test_bn_stats(ops, dev, C, rows):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(rows, C, generator=g) * 3 - 20.0 * (C == 64)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_d, rv_d = rm.clone().to(dev), rv.clone().to(dev)
+    st = ops.bn_stats(x.to(dev), gamma.to(dev), beta.to(dev), rm_d, rv_d, True)
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    assert relerr(st.mean, mean) < 1e-6
+    assert relerr(st.invstd, 1 / torch.sqrt(var + 1e-5)) < 1e-6
+    assert relerr(st.scale, gamma.double() / torch.sqrt(var + 1e-5)) < 1e-6
+    assert relerr(rm_d, 0.9 * rm.double() + 0.1 * mean) < 1e-6
+    assert relerr(rv_d, 0.9 * rv.double() + 0.1 * xd.var(0, unbiased=True)) < 1e-6
+    st_e = ops.bn_stats(x.to(dev), gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), False)
+    assert relerr(st_e.scale, gamma / torch.sqrt(rv + 1e-5)) < 1e-6
+    assert relerr(st_e.shift, beta - rm * gamma / torch.sqrt(rv + 1e-5)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- convolutions
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", [(2, 9, 8, 32, 64, 0), (1, 17, 16, 64, 128, 1), (2, 5, 4, 128, 256, 1),
+                                                (1, 7, 8, 64, 64, 3), (1, 6, 8, 32, 32, 2), (3, 11, 8, 256, 512, 0)])
+def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    s, t = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+
+    def pro_fn(v):
+        sc, sh = s.view(1, -1, 1, 1).double(), t.view(1, -1, 1, 1).double()
+        if pro == 1:
+            return F.relu(v * sc + sh)
+        if pro == 2:
+            return F.leaky_relu(v, 0.1) * sc + sh
+        if pro == 3:
+            return v * sc + sh
+        return v
+
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    a = pro_fn(xd)
+    a.retain_grad()
+    y_ref = F.conv2d(a, wd, None, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+
+    wf, wdg = ops.pack_conv_weight(w.to(dev))
+    sd, td = (s.to(dev), t.to(dev)) if pro else (None, None)
+    y = ops.conv3x3(nhwc(x).to(dev), wf, Cout, pro, sd, td)
+    assert relerr(nchw(y), y_ref) < 2e-6
+    da = ops.conv3x3(nhwc(dy).to(dev), wdg, Cin)                                 # dgrad wrt prologue output
+    assert relerr(nchw(da), a.grad) < 2e-6
+    dw = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev), pro, sd, td)
+    assert relerr(dw, wd.grad) < 2e-6
+
+
+def test_conv3x3_c1(ops, dev):
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Cout = 2, 21, 64, 64
+    x = torch.randn(B, H, W, generator=g) * 10 - 30
+    cs, ct = torch.rand(W, generator=g) * 0.1 + 0.05, torch.randn(W, generator=g)
+    w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
+    xin = (x.double() * cs.double() + ct.double()).unsqueeze(1).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xin, wd, None, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    y = ops.conv3x3_c1(x.to(dev), w.to(dev), cs.to(dev), ct.to(dev))
+    assert relerr(nchw(y), y_ref) < 2e-6
+    dw = ops.conv3x3_c1_wgrad(x.to(dev), nhwc(dy).to(dev), cs.to(dev), ct.to(dev))
+    assert relerr(dw, wd.grad) < 2e-6
+    dx = ops.conv3x3_c1_dgrad(nhwc(dy).to(dev), w.to(dev))
+    assert relerr(dx, xin.grad[:, 0]) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------- bn+relu+pool
+@pytest.mark.parametrize("H,W,C,ph,pw,train,p", [(9, 8, 64, 2, 2, True, 0.0), (7, 8, 128, 1, 2, True, 0.2),
+                                                 (5, 6, 256, 2, 2, False, 0.0), (4, 4, 512, 1, 2, True, 0.0)])
+def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
+    B = 2
+    g = torch.Generator().manual_seed(H * 100 + C)
+    y = torch.randn(B, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    yh = nhwc(y).to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gamma.to(dev), beta.to(dev), rm.clone().to(dev), rv.clone().to(dev), train)
+    seed = 12345
+    out = ops.bnact_pool(yh, st, ph, pw, 1, 0, p, seed)
+    Ho, Wo = H // ph, W // pw
+    mask = ops.dropout_mask(seed, (B, Ho, Wo, C), p, dev).cpu().permute(0, 3, 1, 2) if p > 0 else None
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, rm.double().clone(), rv.double().clone(), gd, bd, train, 0.1, 1e-5))
+    ref = F.avg_pool2d(a, (ph, pw)) + F.max_pool2d(a, (ph, pw))
+    if mask is not None:
+        ref = ref * mask.double() / (1 - p)
+    assert relerr(nchw(out), ref) < 2e-6
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout.double())
+    dy, dg, db = ops.bnrelu_pool_backward(yh, st, gamma.to(dev), nhwc(dout).to(dev), ph, pw, p, seed)
+    assert relerr(nchw(dy), yd.grad) < 5e-6
+    assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
+
+
+def test_bnrelu_backward(ops, dev):
+    B, C, H, W = 2, 128, 5, 6
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(B, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    yh = nhwc(y).to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gamma.to(dev), beta.to(dev), None, None, True)
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5))
+    da = torch.randn(a.shape, generator=g)
+    a.backward(da.double())
+    dy, dg, db = ops.bnrelu_backward(yh, st, gamma.to(dev), nhwc(da).to(dev))
+    assert relerr(nchw(dy), yd.grad) < 5e-6
+    assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
+
+
+def test_bn_param_grad_and_mean_w(ops, dev):
+    g = torch.Generator().manual_seed(4)
+    rows, C = 1001, 64
+    x = torch.randn(rows, C, generator=g) * 5 - 30
+    dy = torch.randn(rows, C, generator=g)
+    st = ops.bn_stats(x.to(dev), None, None, None, None, True)
+    dg, db = ops.bn_param_grad(x.to(dev), dy.to(dev), st)
+    xd = x.double()
+    xhat = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-5)
+    assert relerr(dg, (dy.double() * xhat).sum(0)) < 1e-5 and relerr(db, dy.double().sum(0)) < 1e-5
+    from texttoaudiogrounding_amd.lib import call, ptr
+    xm = torch.randn(37, 4, 512, generator=g)
+    out = torch.empty(37, 512, device=dev)
+    call("tag_mean_w_forward", ptr(xm.to(dev)), 37, 4, 512, 0.0, 0, ptr(out))
+    assert relerr(out, xm.double().mean(1)) < 1e-6
+    dx = torch.empty(37, 4, 512, device=dev)
+    call("tag_mean_w_backward", ptr(out), 37, 4, 512, 0.0, 0, ptr(dx))
+    assert relerr(dx, (out.cpu().double() / 4).unsqueeze(1).expand(37, 4, 512)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,ta,tb", [(100, 512, 512, False, True), (70, 33, 129, False, False),
+                                         (65, 64, 96, True, False), (130, 7, 260, True, True),
+                                         (1536, 512, 300, True, False)])
+def test_gemm(ops, dev, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double())
+    out = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb)
+    assert relerr(out, ref) < 2e-6
+    out2 = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb, bias=bias.to(dev), act=1)
+    assert relerr(out2, F.relu(ref + bias.double())) < 2e-6
+    acc = out.clone()
+    ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb, out=acc, accumulate=True)
+    assert relerr(acc, 2 * ref) < 2e-6
+    cs = ops.colsum(out2, M, N)
+    assert relerr(cs, out2.cpu().double().sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (18, 6, 512, 256)])
+def test_gru_forward_backward(ops, dev, B, T, I, H):
+    from texttoaudiogrounding_amd.lib import call, ptr
+    g = torch.Generator().manual_seed(B)
+    k = 1 / math.sqrt(H)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    shapes = [(3 * H, I), (3 * H, H), (3 * H,), (3 * H,)]
+    st = {}
+    for sfx in ("", "_reverse"):
+        for n, s in zip(names, shapes):
+            st["rnn." + n + sfx] = ((torch.rand(s, generator=g) * 2 - 1) * k * 2).double().requires_grad_(True)
+    x = torch.randn(B, T, I, generator=g)
+    xd = x.double().requires_grad_(True)
+    y_ref = O.gru_bidir(xd, st, "rnn.")
+    y_man = O.gru_bidir_manual(xd, st, "rnn.")
+    assert (y_ref - y_man).abs().max().item() < 1e-12        # the oracle's two GRU statements agree
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+
+    f = lambda k_: st[k_].detach().float().to(dev)
+    w_ih = torch.cat([f("rnn.weight_ih_l0"), f("rnn.weight_ih_l0_reverse")], 0)
+    b_ih = torch.cat([f("rnn.bias_ih_l0"), f("rnn.bias_ih_l0_reverse")], 0)
+    w_hh = torch.stack([f("rnn.weight_hh_l0"), f("rnn.weight_hh_l0_reverse")], 0).contiguous()
+    b_hh = torch.stack([f("rnn.bias_hh_l0"), f("rnn.bias_hh_l0_reverse")], 0).contiguous()
+    M = B * T
+    xdv = x.to(dev).view(M, I)
+    gi = ops.gemm(xdv, w_ih, M, 6 * H, I, transB=True, bias=b_ih)
+    y = torch.empty(B, T, 2 * H, device=dev)
+    gates = torch.empty(B, T, 2, 4 * H, device=dev)
+    ws = torch.empty(6 * H * H, device=dev)
+    call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(ws), B, T, H)
+    assert relerr(y, y_ref) < 5e-6
+    dgi = torch.empty(B, T, 2, 3 * H, device=dev)
+    dgh = torch.empty(B, T, 2, 3 * H, device=dev)
+    hprev = torch.empty(B, T, 2, H, device=dev)
+    scratch = torch.empty(2, B, H, device=dev)
+    call("tag_gru_backward", ptr(dy.to(dev)), ptr(y), ptr(gates), ptr(w_hh), ptr(dgi), ptr(dgh), ptr(hprev),
+         ptr(scratch), B, T, H)
+    dx = ops.gemm(dgi, w_ih, M, I, 6 * H)
+    assert relerr(dx.view(B, T, I), xd.grad) < 2e-5
+    dw_ih = ops.gemm(dgi, xdv, 6 * H, I, M, transA=True, lda=6 * H)
+    assert relerr(dw_ih[:3 * H], st["rnn.weight_ih_l0"].grad) < 2e-5
+    assert relerr(dw_ih[3 * H:], st["rnn.weight_ih_l0_reverse"].grad) < 2e-5
+    for d, sfx in enumerate(("", "_reverse")):
+        a = dgh.view(M, 6 * H)[:, d * 3 * H:]
+        hb = hprev.view(M, 2 * H)[:, d * H:]
+        dw_hh = ops.gemm(a, hb, 3 * H, H, M, transA=True, lda=6 * H, ldb=2 * H)
+        assert relerr(dw_hh, st["rnn.weight_hh_l0" + sfx].grad) < 2e-5
+    assert relerr(ops.colsum(dgh, M, 6 * H)[:3 * H], st["rnn.bias_hh_l0"].grad) < 2e-5
+    assert relerr(ops.colsum(dgi, M, 6 * H)[3 * H:], st["rnn.bias_ih_l0_reverse"].grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- heads
+def test_embed_mean(ops, dev):
+    g = torch.Generator().manual_seed(9)
+    V, D, B, L = 50, 256, 5, 4
+    table = torch.randn(V, D, generator=g)
+    text = torch.randint(2, V, (B, L), generator=g)
+    lens = torch.tensor([4, 1, 2, 3, 4])
+    text[1, 1:] = 0
+    td = table.double().requires_grad_(True)
+    ref = O.embedding_agg_mean({"text_encoder.embedding.core.weight": td}, text, lens)
+    tab = table.to(dev).requires_grad_(True)
+    seq, tok = ops.EmbedMeanFunction.apply(tab, text.to(dev), lens.to(dev), True)
+    assert relerr(seq, ref["seq_emb"]) < 1e-6 and relerr(tok, ref["token_emb"]) == 0
+    dseq = torch.randn(B, D, generator=g)
+    ref["seq_emb"].backward(dseq.double())
+    seq.backward(dseq.to(dev))
+    assert relerr(tab.grad, td.grad) < 1e-6
+
+
+@pytest.mark.parametrize("kind,l2norm,scale", [(0, False, True), (0, True, False), (1, True, False), (1, False, False)])
+def test_match_heads(ops, dev, golden_dir, kind, l2norm, scale):
+    gold = np.load(f"{golden_dir}/heads.npz")
+    audio, text = torch.from_numpy(gold["audio"]), torch.from_numpy(gold["text"])
+    key = {(0, False, True): "dot", (0, True, False): "dot_l2", (1, True, False): "expnegl2",
+           (1, False, False): "expnegl2_raw"}[(kind, l2norm, scale)]
+    a = audio.to(dev).requires_grad_(True)
+    t = text.to(dev).requires_grad_(True)
+    sim = ops.MatchFunction.apply(a, t, kind, l2norm, scale)
+    assert (sim.cpu() - torch.from_numpy(gold["sim_" + key])).abs().max().item() < 1e-6    # golden (reference)
+    ad, td = audio.double().requires_grad_(True), text.double().requires_grad_(True)
+    ref = O.match_dot_product(ad, td, l2norm, scale) if kind == 0 else O.match_exp_neg_l2(ad, td, l2norm)
+    g = torch.Generator().manual_seed(2)
+    ds = torch.randn(ref.shape, generator=g)
+    ref.backward(ds.double())
+    sim.backward(ds.to(dev))
+    assert relerr(a.grad, ad.grad) < 2e-5 and relerr(t.grad, td.grad) < 2e-5
+
+
+def test_frame_bce(ops, dev, golden_dir):
+    gold = np.load(f"{golden_dir}/heads.npz")
+    sim = torch.from_numpy(gold["sim_dot"])
+    label, length = torch.from_numpy(gold["label"]), torch.from_numpy(gold["length"])
+    s = sim.to(dev).requires_grad_(True)
+    loss = ops.FrameBceFunction.apply(s, label.to(dev), length.to(dev), sim.shape[1])
+    assert abs(loss.item() - float(gold["loss_dot"])) < 1e-6                               # golden (reference)
+    sd = sim.double().requires_grad_(True)
+    ref = O.frame_bce_loss(sd, label.double(), length)
+    ref.backward()
+    loss.backward()
+    assert relerr(s.grad, sd.grad) < 1e-5
+    # saturated probabilities: log clamp at -100 and the 1e-12 guard of the backward
+    edge = torch.tensor([[1.0, 1e-7, 0.5, 1.0]]), torch.tensor([[0.0, 1.0, 1.0, 1.0]])
+    e = edge[0].to(dev).requires_grad_(True)
+    le = ops.FrameBceFunction.apply(e, edge[1].to(dev), torch.tensor([4]).to(dev), 4)
+    ed = edge[0].clone().requires_grad_(True)
+    lr = O.frame_bce_loss(ed, edge[1], torch.tensor([4]))
+    lr.backward()
+    le.backward()
+    assert abs(le.item() - lr.item()) < 1e-5 and relerr(e.grad, ed.grad) < 1e-5
+
+
+def test_align_dot(ops, dev, golden_dir):
+    gold = np.load(f"{golden_dir}/align.npz")
+    audio, text = torch.from_numpy(gold["audio"]).to(dev), torch.from_numpy(gold["text"]).to(dev)
+    for l2 in (0, 1):
+        for sc in (0, 1):
+            out = ops.align_dot(audio, text, bool(l2), bool(sc))
+            ref = torch.from_numpy(gold[f"l2{l2}_sc{sc}"])
+            assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-6
+
+
+def test_segments_bit_exact_vs_reference_golden(ops, dev, golden_dir):
+    """P1: integer segment indices, bit-exact against what the reference's own eval_util produced."""
+    gold = np.load(f"{golden_dir}/postproc.npz")
+    rows, lens, th, segs = gold["rows"], gold["row_len"], gold["thresholds"], gold["segments"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for T in sorted(set(lens.tolist())):
+        idx = [i for i, l in enumerate(lens) if l == T]
+        x = torch.from_numpy(np.stack([rows[off[i]:off[i + 1]] for i in idx])).to(dev)
+        for window in (1, 3, 4):
+            for n_connect in (7, 13):
+                regions, counts = ops.segments(x, th, window, n_connect)
+                regions, counts = regions.cpu().numpy(), counts.cpu().numpy()
+                for bi, ri in enumerate(idx):
+                    for ti in range(len(th)):
+                        sel = (segs[:, 0] == ri) & (segs[:, 1] == ti) & (segs[:, 2] == window) & (segs[:, 3] == n_connect)
+                        want = segs[sel][:, 4:6]
+                        got = regions[bi, ti, :counts[bi, ti]]
+                        assert np.array_equal(got, want), (ri, ti, window, n_connect)
+
+
+def test_adam_clip_vs_torch(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    n = 100003
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) * 0.01 * (i + 1) for i in range(3)]
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.double().clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = gr.to(dev)
+        gsq = ops.grad_sumsq(gd)
+        assert abs(gsq.item() - float((gr.double() ** 2).sum())) / float((gr.double() ** 2).sum()) < 1e-10
+        ops.adam_step(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, i + 1, gsq, 1.0, 1.0)
+    assert (p.cpu().double() - pr.detach()).abs().max().item() < 1e-6

@@ -1,0 +1,623 @@
+// F3 / A1 / A2: BatchNorm statistics, BN+ReLU+(avg+max | LP) pool + dropout, and their backward.
+// Reference: nn.BatchNorm2d + F.relu_ + F.avg_pool2d/F.max_pool2d (models/panns.py:46-62),
+// bn0 over the mel axis (models/audio_encoder.py:188-190), F.dropout (:203-210),
+// cdur_block / nn.LPPool2d (models/audio_encoder.py:16-22,39-49).
+//
+// All tensors channels-last (rows, C); every kernel is HBM-bound: one float4 per lane, channels
+// innermost so a wave reads 1 KiB contiguous.  Per-channel reductions accumulate in fp64 per
+// thread, are combined per block through LDS and written as per-block partials; a one-block
+// finalize kernel sums the partials in a fixed order (deterministic, no atomics).
+#include "tag_common.h"
+
+namespace {
+
+constexpr int RED_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ float leaky01(float v) { return v > 0.0f ? v : 0.1f * v; }
+
+// ------------------------------------------------------------------------------------------
+// generic two-quantity per-channel reduction over (rows, C), C % 4 == 0, (C/4) | 256
+// Functor: void operator()(long row, int c, float4& a, float4& b)   (c multiple of 4)
+// partials: [nblk][2][C] doubles
+// ------------------------------------------------------------------------------------------
+template <class Fn>
+__global__ __launch_bounds__(256) void reduce2_kernel(Fn fn, long rows, int C, double* __restrict__ partials) {
+    extern __shared__ double sred[];   // [256][8]
+    const int tpr = C >> 2;                 // threads per row
+    const int rpi = 256 / tpr;              // rows per iteration
+    const int c = (threadIdx.x % tpr) << 2;
+    const int rsub = threadIdx.x / tpr;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
+        float4 a, b;
+        fn(r, c, a, b);
+        s1[0] += a.x; s1[1] += a.y; s1[2] += a.z; s1[3] += a.w;
+        s2[0] += b.x; s2[1] += b.y; s2[2] += b.z; s2[3] += b.w;
+    }
+    double* mine = sred + threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mine[j] = s1[j]; mine[4 + j] = s2[j]; }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int q = 1; q < rpi; ++q) {
+            const double* o = sred + (threadIdx.x + q * tpr) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += o[j]; s2[j] += o[4 + j]; }
+        }
+        double* p = partials + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p[c + j] = s1[j]; p[C + c + j] = s2[j]; }
+    }
+}
+
+// scalar fallback for C % 4 != 0 or C < 4 (CrnnEncoder's 1-channel BatchNorm): thread t owns
+// channel t % C; requires C <= 256 and 256 % C == 0
+template <class Fn1>
+__global__ __launch_bounds__(256) void reduce2_scalar_kernel(Fn1 fn, long rows, int C,
+                                                            double* __restrict__ partials) {
+    __shared__ double sred[256][2];
+    const int c = threadIdx.x % C;
+    const int rpi = 256 / C;
+    const int rsub = threadIdx.x / C;
+    double s1 = 0, s2 = 0;
+    for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
+        float a, b;
+        fn(r, c, a, b);
+        s1 += a; s2 += b;
+    }
+    sred[threadIdx.x][0] = s1; sred[threadIdx.x][1] = s2;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int q = 1; q < rpi; ++q) { s1 += sred[threadIdx.x + q * C][0]; s2 += sred[threadIdx.x + q * C][1]; }
+        double* p = partials + (size_t)blockIdx.x * 2 * C;
+        p[c] = s1; p[C + c] = s2;
+    }
+}
+
+struct StatsFn {
+    const float* x; int C; int pre;
+    __device__ void operator()(long r, int c, float4& a, float4& b) const {
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+        if (pre == 1) { v.x = leaky01(v.x); v.y = leaky01(v.y); v.z = leaky01(v.z); v.w = leaky01(v.w); }
+        a = v;
+        b = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+    }
+};
+struct StatsFn1 {
+    const float* x; int C; int pre;
+    __device__ void operator()(long r, int c, float& a, float& b) const {
+        float v = x[(size_t)r * C + c];
+        if (pre == 1) v = leaky01(v);
+        a = v; b = v * v;
+    }
+};
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk, long rows, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, float momentum, float* running_mean, float* running_var,
+                                         float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += partials[(size_t)b * 2 * C + c];
+        s2 += partials[(size_t)b * 2 * C + C + c];
+    }
+    const double m = s1 / (double)rows;
+    double var = s2 / (double)rows - m * m;
+    if (var < 0) var = 0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (mean) mean[c] = (float)m;
+    if (invstd) invstd[c] = (float)is;
+    const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    const float sc = (float)(g * is);
+    if (scale) scale[c] = sc;
+    if (shift) shift[c] = (float)((double)bt - m * (double)g * is);
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) {
+        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// dgamma / dbeta finalize: partial slot 0 = sum dz, slot 1 = sum dz*xhat
+__global__ void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
+                                        float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += partials[(size_t)b * 2 * C + c];
+        s2 += partials[(size_t)b * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    scale[c] = g * is;
+    shift[c] = b - rm[c] * g * is;
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, long n4, int C,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 t = *reinterpret_cast<const float4*>(shift + c);
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
+    const float* x; const float* dy; const float* mean; const float* invstd; int C;
+    __device__ void operator()(long r, int c, float4& a, float4& b) const {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * C + c);
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        a = g;
+        b = make_float4(g.x * (v.x - m.x) * is.x, g.y * (v.y - m.y) * is.y, g.z * (v.z - m.z) * is.z,
+                        g.w * (v.w - m.w) * is.w);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// forward: act(bn(y)) -> pool -> dropout
+// ------------------------------------------------------------------------------------------
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             float* __restrict__ out, int B, int H, int W, int C,
+                                                             int act, int pool, float drop_p, uint64_t seed) {
+    const int Ho = H / PH, Wo = W / PW, C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * C4;
+    const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) << 2;
+        long q = i / C4;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
+        if (scale) {
+            s = *reinterpret_cast<const float4*>(scale + c);
+            t = *reinterpret_cast<const float4*>(shift + c);
+        }
+        float sum[4] = {0, 0, 0, 0}, mx[4];
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                const size_t off = (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c;
+                const float4 v = *reinterpret_cast<const float4*>(y + off);
+                float a[4] = {fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = (act == 1) ? fmaxf(a[j], 0.0f) : leaky01(a[j]);
+                    if (pool == 0) {
+                        sum[j] += a[j];
+                        mx[j] = (dh == 0 && dw == 0) ? a[j] : fmaxf(mx[j], a[j]);
+                    } else {
+                        const float a2 = a[j] * a[j];
+                        sum[j] += a2 * a2;
+                    }
+                }
+            }
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
+            if (drop_p > 0.0f) r[j] = tag_keep(seed, (uint64_t)i * 4 + j, drop_p) ? r[j] * keep_scale : 0.0f;
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of relu(bn(y)) -> avg+max pool -> dropout.  A thread owns one pooling slot (4 channels),
+// including the partial slots of the floor-dropped last row/column (dz = 0 there).
+// MODE 0: accumulate (sum dz, sum dz*xhat); MODE 1: write dy.
+// ------------------------------------------------------------------------------------------
+template <int PH, int PW>
+struct PoolBwdCtx {
+    const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
+    const float* dout; int B, H, W, C; float drop_p; uint64_t seed;
+    // dz for the slot (b, hs, ws, c..c+3); valid[dh][dw] tells which positions exist
+    __device__ void slot(int b, int hs, int ws, int c, float dz[PH][PW][4], float xh[PH][PW][4],
+                         bool ex[PH][PW]) const {
+        const int Ho = H / PH, Wo = W / PW;
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 t = *reinterpret_cast<const float4*>(shift + c);
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float sv[4] = {s.x, s.y, s.z, s.w}, tv[4] = {t.x, t.y, t.z, t.w};
+        const float mv[4] = {m.x, m.y, m.z, m.w}, iv[4] = {is.x, is.y, is.z, is.w};
+        const bool full = hs < Ho && ws < Wo;
+        float a[PH][PW][4];
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                const int h = hs * PH + dh, w = ws * PW + dw;
+                ex[dh][dw] = h < H && w < W;
+                float4 v = make_float4(0, 0, 0, 0);
+                if (ex[dh][dw]) v = *reinterpret_cast<const float4*>(y + (((size_t)b * H + h) * W + w) * C + c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[dh][dw][j] = fmaf(vv[j], sv[j], tv[j]);
+                    xh[dh][dw][j] = (vv[j] - mv[j]) * iv[j];
+                    dz[dh][dw][j] = 0.0f;
+                }
+            }
+        if (!full) return;
+        const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
+        const float4 g4 = *reinterpret_cast<const float4*>(dout + oi);
+        float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (drop_p > 0.0f) g[j] = tag_keep(seed, (uint64_t)oi + j, drop_p) ? g[j] * keep_scale : 0.0f;
+            // first maximum in scan order (h then w), as ATen's max_pool2d picks it
+            int am = 0; float best = fmaxf(a[0][0][j], 0.0f);
+#pragma unroll
+            for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < PW; ++dw) {
+                    const float r = fmaxf(a[dh][dw][j], 0.0f);
+                    if (r > best) { best = r; am = dh * PW + dw; }
+                }
+#pragma unroll
+            for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < PW; ++dw) {
+                    const float da = g[j] * ((1.0f / (PH * PW)) + ((am == dh * PW + dw) ? 1.0f : 0.0f));
+                    dz[dh][dw][j] = a[dh][dw][j] > 0.0f ? da : 0.0f;
+                }
+        }
+    }
+};
+
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW> ctx, double* __restrict__ partials) {
+    extern __shared__ double sred[];
+    const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    const int Ho = ctx.H / PH, Wo = ctx.W / PW;   // only full slots carry gradient
+    const long slots = (long)ctx.B * Ho * Wo;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
+        const int ws = (int)(r % Wo); long q = r / Wo;
+        const int hs = (int)(q % Ho); const int b = (int)(q / Ho);
+        float dz[PH][PW][4], xh[PH][PW][4]; bool ex[PH][PW];
+        ctx.slot(b, hs, ws, c, dz, xh, ex);
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += dz[dh][dw][j]; s2[j] += dz[dh][dw][j] * xh[dh][dw][j]; }
+    }
+    double* mine = sred + threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mine[j] = s1[j]; mine[4 + j] = s2[j]; }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int q = 1; q < rpi; ++q) {
+            const double* o = sred + (threadIdx.x + q * tpr) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += o[j]; s2[j] += o[4 + j]; }
+        }
+        double* p = partials + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p[c + j] = s1[j]; p[C + c + j] = s2[j]; }
+    }
+}
+
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW> ctx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ dgamma,
+                                                             const float* __restrict__ dbeta, int bn_train,
+                                                             float* __restrict__ dy) {
+    const int C = ctx.C, C4 = C >> 2;
+    const int Hs = (ctx.H + PH - 1) / PH, Ws = (ctx.W + PW - 1) / PW;
+    const long total = (long)ctx.B * Hs * Ws * C4;
+    const float invN = 1.0f / (float)((long)ctx.B * ctx.H * ctx.W);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) << 2;
+        long q = i / C4;
+        const int ws = (int)(q % Ws); q /= Ws;
+        const int hs = (int)(q % Hs); const int b = (int)(q / Hs);
+        float dz[PH][PW][4], xh[PH][PW][4]; bool ex[PH][PW];
+        ctx.slot(b, hs, ws, c, dz, xh, ex);
+        float k0[4], k1[4], k2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = gamma[c + j] * ctx.invstd[c + j];
+            k0[j] = gi;
+            k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
+            k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
+        }
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                if (!ex[dh][dw]) continue;
+                const int h = hs * PH + dh, w = ws * PW + dw;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
+                *reinterpret_cast<float4*>(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c) =
+                    make_float4(o[0], o[1], o[2], o[3]);
+            }
+    }
+}
+
+// plain relu(bn(y)) backward (no pooling)
+struct BnReluBwdFn {
+    const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
+    const float* da; int C;
+    __device__ void operator()(long r, int c, float4& a, float4& b) const {
+        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + c);
+        const float4 g = *reinterpret_cast<const float4*>(da + (size_t)r * C + c);
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 t = *reinterpret_cast<const float4*>(shift + c);
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        a.x = fmaf(v.x, s.x, t.x) > 0.0f ? g.x : 0.0f;
+        a.y = fmaf(v.y, s.y, t.y) > 0.0f ? g.y : 0.0f;
+        a.z = fmaf(v.z, s.z, t.z) > 0.0f ? g.z : 0.0f;
+        a.w = fmaf(v.w, s.w, t.w) > 0.0f ? g.w : 0.0f;
+        b = make_float4(a.x * (v.x - m.x) * is.x, a.y * (v.y - m.y) * is.y, a.z * (v.z - m.z) * is.z,
+                        a.w * (v.w - m.w) * is.w);
+    }
+};
+
+__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFn fn, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dgamma,
+                                                               const float* __restrict__ dbeta, int bn_train,
+                                                               long rows, float* __restrict__ dy) {
+    const int C = fn.C, C4 = C >> 2;
+    const long total = rows * C4;
+    const float invN = 1.0f / (float)rows;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) << 2;
+        const long r = i / C4;
+        float4 dz, dzx;
+        fn(r, c, dz, dzx);
+        const float4 v = *reinterpret_cast<const float4*>(fn.y + (size_t)r * C + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w}, dzv[4] = {dz.x, dz.y, dz.z, dz.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float is = fn.invstd[c + j];
+            const float xh = (vv[j] - fn.mean[c + j]) * is;
+            const float k1 = bn_train ? dbeta[c + j] * invN : 0.0f;
+            const float k2 = bn_train ? dgamma[c + j] * invN : 0.0f;
+            o[j] = gamma[c + j] * is * (dzv[j] - k1 - xh * k2);
+        }
+        *reinterpret_cast<float4*>(dy + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void dropout_mask_kernel(uint64_t seed, long n, float p, uint8_t* mask) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        mask[i] = tag_keep(seed, (uint64_t)i, p) ? 1 : 0;
+}
+
+// mean over W then dropout: x (rows, W, C) -> (rows, C)
+__global__ __launch_bounds__(256) void mean_w_fwd_kernel(const float* __restrict__ x, long rows, int W, int C,
+                                                         float drop_p, uint64_t seed, float* __restrict__ out) {
+    const long total = rows * C;
+    const float ks = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C; const int c = (int)(i % C);
+        float s = 0.0f;
+        for (int w = 0; w < W; ++w) s += x[((size_t)r * W + w) * C + c];
+        s = s / (float)W;
+        if (drop_p > 0.0f) s = tag_keep(seed, (uint64_t)i, drop_p) ? s * ks : 0.0f;
+        out[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void mean_w_bwd_kernel(const float* __restrict__ dout, long rows, int W, int C,
+                                                         float drop_p, uint64_t seed, float* __restrict__ dx) {
+    const long total = rows * C;
+    const float ks = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C; const int c = (int)(i % C);
+        float g = dout[i];
+        if (drop_p > 0.0f) g = tag_keep(seed, (uint64_t)i, drop_p) ? g * ks : 0.0f;
+        g = g / (float)W;
+        for (int w = 0; w < W; ++w) dx[((size_t)r * W + w) * C + c] = g;
+    }
+}
+
+int red_blocks(long rows, int C) {
+    const int rpi = 256 / (C >> 2 > 0 ? C >> 2 : 1);
+    long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);
+    if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+bool vec_ok(int C) { return C % 4 == 0 && C >= 4 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
+int ew_blocks(long n) {
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+extern "C" size_t tag_bn_stats_ws_bytes(long rows, int C) {
+    (void)rows;
+    return (size_t)RED_MAX_BLOCKS * 2 * (size_t)C * sizeof(double);
+}
+extern "C" size_t tag_bn_backward_ws_bytes(long rows, int C) { return tag_bn_stats_ws_bytes(rows, C); }
+
+extern "C" int tag_bn_stats(const float* x, long rows, int C, int pre_op, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                            float* invstd, float* scale, float* shift, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && ws && rows > 0 && C > 0);
+    double* partials = static_cast<double*>(ws);
+    int nblk;
+    if (vec_ok(C)) {
+        nblk = red_blocks(rows, C);
+        hipLaunchKernelGGL(reduce2_kernel<StatsFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
+                           as_stream(stream), StatsFn{x, C, pre_op}, rows, C, partials);
+    } else {
+        TAG_CHECK_ARG(C <= 256 && 256 % C == 0);
+        const int rpi = 256 / C;
+        long nb = (rows + (long)rpi * 32 - 1) / ((long)rpi * 32);
+        nblk = (int)(nb > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : (nb < 1 ? 1 : nb));
+        hipLaunchKernelGGL(reduce2_scalar_kernel<StatsFn1>, dim3(nblk), dim3(256), 0, as_stream(stream),
+                           StatsFn1{x, C, pre_op}, rows, C, partials);
+    }
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk,
+                       rows, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift,
+                                  void* stream) {
+    TAG_CHECK_ARG(running_mean && running_var && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_affine_forward(const float* x, long rows, int C, const float* scale, const float* shift, float* y,
+                                  void* stream) {
+    TAG_CHECK_ARG(x && y && scale && shift && C % 4 == 0);
+    const long n4 = rows * C / 4;
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_blocks(n4)), dim3(256), 0, as_stream(stream), x, n4, C, scale, shift, y);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_bn_param_grad(const float* x, const float* dy, long rows, int C, const float* mean,
+                                 const float* invstd, float* dgamma, float* dbeta, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && dy && mean && invstd && dgamma && dbeta && ws && vec_ok(C));
+    double* partials = static_cast<double*>(ws);
+    const int nblk = red_blocks(rows, C);
+    hipLaunchKernelGGL(reduce2_kernel<ParamGradFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
+                       as_stream(stream), ParamGradFn{x, dy, mean, invstd, C}, rows, C, partials);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, C,
+                       dgamma, dbeta);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DISPATCH_POOL(PH_, PW_, ...)                       \
+    if (ph == PH_ && pw == PW_) { constexpr int PH = PH_, PW = PW_; __VA_ARGS__; launched = true; }
+
+extern "C" int tag_bnact_pool_forward(const float* y, const float* scale, const float* shift, float* out, int B,
+                                      int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
+                                      uint64_t seed, void* stream) {
+    TAG_CHECK_ARG(y && out && C % 4 == 0 && (act == 1 || act == 2) && (pool == 0 || pool == 1));
+    TAG_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
+    const long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    bool launched = false;
+    const int nb = ew_blocks(total);
+    DISPATCH_POOL(2, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+    DISPATCH_POOL(1, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+    DISPATCH_POOL(2, 4, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+    DISPATCH_POOL(1, 4, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+    DISPATCH_POOL(1, 1, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+    TAG_CHECK_ARG(launched);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, const float* gamma, const float* dout, float* dy,
+                                        float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
+                                        float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+    TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && dout && dy && dgamma && dbeta && ws);
+    TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
+    double* partials = static_cast<double*>(ws);
+    const long slots = (long)B * (H / ph) * (W / pw);
+    const int nblk = red_blocks(slots, C);
+    const long total = (long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (C / 4);
+    const int nb = ew_blocks(total);
+    bool launched = false;
+#define POOL_BWD_BODY                                                                                              \
+    PoolBwdCtx<PH, PW> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                         \
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),          \
+                       as_stream(stream), ctx, partials);                                                          \
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, \
+                       C, dgamma, dbeta);                                                                          \
+    hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma,     \
+                       dgamma, dbeta, bn_train, dy);
+    DISPATCH_POOL(2, 2, POOL_BWD_BODY)
+    DISPATCH_POOL(1, 2, POOL_BWD_BODY)
+    DISPATCH_POOL(1, 1, POOL_BWD_BODY)
+#undef POOL_BWD_BODY
+    TAG_CHECK_ARG(launched);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const float* gamma, const float* da, float* dy,
+                                   float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
+                                   void* stream) {
+    TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && da && dy && dgamma && dbeta && ws && vec_ok(C));
+    double* partials = static_cast<double*>(ws);
+    const int nblk = red_blocks(rows, C);
+    BnReluBwdFn fn{y, scale, shift, mean, invstd, da, C};
+    hipLaunchKernelGGL(reduce2_kernel<BnReluBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
+                       as_stream(stream), fn, rows, C, partials);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, C,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, as_stream(stream), fn,
+                       gamma, dgamma, dbeta, bn_train, rows, dy);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream) {
+    TAG_CHECK_ARG(mask && n > 0);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), seed, n, p, mask);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_mean_w_forward(const float* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out,
+                                  void* stream) {
+    TAG_CHECK_ARG(x && out && rows > 0 && W > 0 && C > 0);
+    hipLaunchKernelGGL(mean_w_fwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), x, rows, W, C,
+                       drop_p, seed, out);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p, uint64_t seed, float* dx,
+                                   void* stream) {
+    TAG_CHECK_ARG(dout && dx && rows > 0 && W > 0 && C > 0);
+    hipLaunchKernelGGL(mean_w_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), dout, rows, W,
+                       C, drop_p, seed, dx);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,630 @@
+// A1: 3x3 / stride 1 / pad 1 / no-bias convolution (models/panns.py:25-33,49-50), channels-last,
+// forward + dgrad (one kernel, different weight pack) and wgrad, as implicit GEMMs on the exact-fp32
+// MFMA v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak on gfx950; bit-equal to an fmaf chain).
+//
+// forward / dgrad   M = B*H*W pixels, N = Cout, K = 9*Cin.  128 x {128,64} tile per 256-thread
+//   workgroup (4 waves, each 64x64 or 64x32 of 32x32 MFMA tiles), K walked tap-major in chunks of
+//   32 channels, operands staged through LDS k-major (As[k][m], Bs[k][n]) so that every MFMA
+//   operand read is a conflict-free 32-lane row; double-buffered, one barrier per K chunk, the
+//   global loads of chunk i+1 are in flight while chunk i is on the matrix pipe.  The producing
+//   layer's BatchNorm + ReLU is applied to the A operand in registers on its way to LDS, so the
+//   normalised activation never round-trips through HBM.
+// wgrad             M = Cin, N = Cout, K = pixels (x9 taps), split over the pixel axis; partials
+//   are reduced in a fixed order by a second kernel that also writes the reference's
+//   (Cout,Cin,3,3) layout.
+#include "tag_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDA = BM + 1;   // (4q+j)*LDA + p hits 32 distinct banks for the transposing A store
+
+__device__ __forceinline__ float4 apply_prologue(float4 v, int mode, float4 s, float4 t) {
+    if (mode == 1) {
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.0f); v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.0f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.0f); v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.0f);
+    } else if (mode == 2) {
+        v.x = fmaf(v.x > 0 ? v.x : 0.1f * v.x, s.x, t.x); v.y = fmaf(v.y > 0 ? v.y : 0.1f * v.y, s.y, t.y);
+        v.z = fmaf(v.z > 0 ? v.z : 0.1f * v.z, s.z, t.z); v.w = fmaf(v.w > 0 ? v.w : 0.1f * v.w, s.w, t.w);
+    } else if (mode == 3) {
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+    }
+    return v;
+}
+
+template <int BN_, int PRO>
+__global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ wp,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift,
+                                                             float* __restrict__ y, int B, int H, int W, int Cin,
+                                                             int Cout) {
+    constexpr int TN = BN_ / 64;            // 32-wide n tiles per wave (waves 2 x 2, wave tile 64 x BN_/2)
+    constexpr int B_LOADS = BN_ / 32;       // float4 per thread for the B chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                        // [2][BK][LDA]
+    float* Bs = smem + 2 * BK * LDA;         // [2][BK][BN_]   (2*BK*LDA*4 bytes is a multiple of 16)
+
+    const long M = (long)B * H * W;
+    const int n_tiles = (Cout + BN_ - 1) / BN_;
+    const int m_tiles = (int)((M + BM - 1) / BM);
+    const int L = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int n0 = (L % n_tiles) * BN_;
+    const long m0 = (long)(L / n_tiles) * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
+
+    // ---- A staging geometry: 4 pixels per thread, 4 channels (one float4) each ----
+    const int q = tid & 7;                   // channel quad within the 32-channel chunk
+    int ph[4], pw_[4];
+    long pm[4];
+    bool pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (tid >> 3) + 32 * i;
+        const long m = m0 + p;
+        pv[i] = m < M;
+        const long mm = pv[i] ? m : 0;
+        const int hw = (int)(mm % ((long)H * W));
+        ph[i] = hw / W;
+        pw_[i] = hw % W;
+        pm[i] = mm;
+    }
+    const int cchunks = Cin / BK;
+    const int kiters = 9 * cchunks;
+
+    float4 ra[4], rb[B_LOADS];
+    auto load_chunk = [&](int it) {
+        const int tap = it / cchunks, c0 = (it - tap * cchunks) * BK;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
+        if (PRO != 0) {
+            s = *reinterpret_cast<const float4*>(in_scale + c0 + q * 4);
+            t = *reinterpret_cast<const float4*>(in_shift + c0 + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hh = ph[i] + dy, ww = pw_[i] + dx;
+            const bool ok = pv[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(x + (pm[i] + (long)dy * W + dx) * Cin + c0 + q * 4);
+                v = apply_prologue(v, PRO, s, t);
+            }
+            ra[i] = v;
+        }
+        const float* wrow = wp + ((size_t)tap * Cin + c0) * Cout;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + 256 * i;
+            const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+            const int n = n0 + n4 * 4;
+            rb[i] = (n < Cout) ? *reinterpret_cast<const float4*>(wrow + (size_t)k * Cout + n)
+                               : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * BK * LDA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (tid >> 3) + 32 * i;
+            a[(q * 4 + 0) * LDA + p] = ra[i].x;
+            a[(q * 4 + 1) * LDA + p] = ra[i].y;
+            a[(q * 4 + 2) * LDA + p] = ra[i].z;
+            a[(q * 4 + 3) * LDA + p] = ra[i].w;
+        }
+        float* b = Bs + buf * BK * BN_;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + 256 * i;
+            const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+            *reinterpret_cast<float4*>(b + k * BN_ + n4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int kl = lane >> 5, ml = lane & 31;
+    for (int it = 0; it < kiters; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < kiters) load_chunk(it + 1);
+        const float* a = As + buf * BK * LDA + kl * LDA + wm0 + ml;
+        const float* b = Bs + buf * BK * BN_ + kl * BN_ + wn0 + ml;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[2], bf[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = a[kk * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = b[kk * BN_ + j * 32];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < kiters) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + ml;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m < M && n < Cout) y[m * Cout + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: partial[split][tap][ci][co] = sum_{m in split} prologue(x)[m + shift(tap)][ci] * dy[m][co]
+// ------------------------------------------------------------------------------------------
+template <int TC, int PRO>   // TC x TC output tile (64 or 128)
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ in_scale,
+                                                               const float* __restrict__ in_shift,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ partial, int B, int H, int W,
+                                                               int Cin, int Cout, int splits, long chunk) {
+    constexpr int TT = TC / 64;              // 32x32 tiles per wave per dim (waves 2 x 2)
+    constexpr int LOADS = TC / 32;           // float4 per thread per operand per chunk (32 pixels x TC)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                        // [2][BK][TC]  (pixel-major, ci contiguous)
+    float* Bs = smem + 2 * BK * TC;          // [2][BK][TC]
+
+    const long M = (long)B * H * W;
+    const int ci_tiles = (Cin + TC - 1) / TC, co_tiles = (Cout + TC - 1) / TC;
+    int L = xcd_remap(blockIdx.x, 9 * ci_tiles * co_tiles * splits);
+    const int tap = L % 9; L /= 9;
+    const int cot = L % co_tiles; L /= co_tiles;
+    const int cit = L % ci_tiles; L /= ci_tiles;
+    const int split = L;
+    const int ci0 = cit * TC, co0 = cot * TC;
+    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
+    const long kbeg = (long)split * chunk;
+    long kend = kbeg + chunk;
+    if (kend > M) kend = M;
+    const int kiters = kbeg < kend ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * (TC / 2), wn0 = (wid & 1) * (TC / 2);
+    const long HW = (long)H * W;
+
+    float4 ra[LOADS], rb[LOADS];
+    auto load_chunk = [&](int it) {
+        const long kb = kbeg + (long)it * BK;
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + 256 * i;
+            const int pix = idx / (TC / 4), c4 = (idx % (TC / 4)) * 4;
+            const long m = kb + pix;
+            float4 va = make_float4(0, 0, 0, 0), vb = make_float4(0, 0, 0, 0);
+            if (m < kend) {
+                const int hw = (int)(m % HW);
+                const int hh = hw / W + dyy, ww = hw % W + dxx;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + c4 < Cin) {
+                    va = *reinterpret_cast<const float4*>(x + (m + (long)dyy * W + dxx) * Cin + ci0 + c4);
+                    if (PRO != 0) {
+                        const float4 s = *reinterpret_cast<const float4*>(in_scale + ci0 + c4);
+                        const float4 t = *reinterpret_cast<const float4*>(in_shift + ci0 + c4);
+                        va = apply_prologue(va, PRO, s, t);
+                    }
+                }
+                if (co0 + c4 < Cout) vb = *reinterpret_cast<const float4*>(dy + m * Cout + co0 + c4);
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + 256 * i;
+            const int pix = idx / (TC / 4), c4 = (idx % (TC / 4)) * 4;
+            *reinterpret_cast<float4*>(As + (buf * BK + pix) * TC + c4) = ra[i];
+            *reinterpret_cast<float4*>(Bs + (buf * BK + pix) * TC + c4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int kl = lane >> 5, ml = lane & 31;
+    if (kiters > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < kiters; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < kiters) load_chunk(it + 1);
+        const float* a = As + (buf * BK + kl) * TC + wm0 + ml;
+        const float* b = Bs + (buf * BK + kl) * TC + wn0 + ml;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[TT], bf[TT];
+#pragma unroll
+            for (int i = 0; i < TT; ++i) af[i] = a[kk * TC + i * 32];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) bf[j] = b[kk * TC + j * 32];
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < kiters) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = partial + ((size_t)split * 9 + tap) * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int co = co0 + wn0 + j * 32 + ml;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[co][ci][tap] = sum_split partial[split][tap][ci][co]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cin,
+                                                           int Cout, float* __restrict__ dw) {
+    const long n = (long)9 * Cin * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        // i indexes partial layout [tap][ci][co] (coalesced reads)
+        float s = 0.0f;
+        for (int sp = 0; sp < splits; ++sp) s += partial[(size_t)sp * n + i];
+        const int co = (int)(i % Cout);
+        const long r = i / Cout;
+        const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+        dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                          float* __restrict__ wd, int Cin, int Cout) {
+    const long n = (long)9 * Cin * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        // i indexes wf layout [tap][ci][co]
+        const int co = (int)(i % Cout);
+        const long r = i / Cout;
+        const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+        const float v = w[((size_t)co * Cin + ci) * 9 + tap];
+        wf[i] = v;
+        if (wd) wd[((size_t)(8 - tap) * Cout + co) * Cin + ci] = v;   // flipped taps, (co,ci) swapped
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cin == 1 (conv_block1.conv1): a 9-tap stencil, HBM-bound on the (B,H,W,Cout) side.
+// The per-column affine folds bn0 (BatchNorm2d over the mel axis) into the load.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float c1_in(const float* x, const float* cs, const float* ct, int H, int W, long m,
+                                       int h, int w, int dy, int dx) {
+    const int hh = h + dy, ww = w + dx;
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) return 0.0f;
+    const float v = x[m + (long)dy * W + dx];
+    return cs ? fmaf(v, cs[ww], ct[ww]) : v;
+}
+
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                          const float* __restrict__ ct, const float* __restrict__ w,
+                                                          float* __restrict__ y, long M, int H, int W, int Cout) {
+    const int C4 = Cout >> 2;
+    const long total = M * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) << 2;
+        const long m = i / C4;
+        const int hw = (int)(m % ((long)H * W));
+        const int h = hw / W, ww = hw % W;
+        float o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = c1_in(x, cs, ct, H, W, m, h, ww, tap / 3 - 1, tap % 3 - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(v, w[(c + j) * 9 + tap], o[j]);
+        }
+        *reinterpret_cast<float4*>(y + m * Cout + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// partials [nblk][Cout*9] doubles
+__global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                            const float* __restrict__ ct,
+                                                            const float* __restrict__ dy, double* __restrict__ partials,
+                                                            long M, int H, int W, int Cout) {
+    extern __shared__ double sred[];         // [4 waves][64][36] (only lanes < tpr used)
+    const int tpr = Cout >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    float acc[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
+    double dacc[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dacc[j][t] = 0.0;
+    int cnt = 0;
+    for (long m = (long)blockIdx.x * rpi + rsub; m < M; m += (long)gridDim.x * rpi) {
+        const int hw = (int)(m % ((long)H * W));
+        const int h = hw / W, ww = hw % W;
+        const float4 g = *reinterpret_cast<const float4*>(dy + m * Cout + c);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = c1_in(x, cs, ct, H, W, m, h, ww, tap / 3 - 1, tap % 3 - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][tap] = fmaf(v, gv[j], acc[j][tap]);
+        }
+        if (++cnt == 64) {   // flush fp32 partial sums into fp64 every 64 pixels
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { dacc[j][t] += acc[j][t]; acc[j][t] = 0.0f; }
+            cnt = 0;
+        }
+    }
+    // threads sharing a channel quad sit tpr lanes apart: fold inside the wave, then across the 4 waves
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            double v = dacc[j][t] + (double)acc[j][t];
+            for (int o = 32; o >= tpr; o >>= 1) v += __shfl_xor(v, o, 64);
+            dacc[j][t] = v;
+        }
+    if (lane < tpr) {
+        double* mine = sred + (wid * 64 + lane) * 36;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) mine[j * 9 + t] = dacc[j][t];
+    }
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        double* p = partials + (size_t)blockIdx.x * Cout * 9;
+        for (int e = 0; e < 36; ++e) {
+            double s = 0;
+            for (int wv = 0; wv < 4; ++wv) s += sred[(wv * 64 + threadIdx.x) * 36 + e];
+            p[(c + e / 9) * 9 + e % 9] = s;
+        }
+    }
+}
+__global__ void conv_c1_wgrad_finalize_kernel(const double* __restrict__ partials, int nblk, int n,
+                                              float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * n + i];
+    dw[i] = (float)s;
+}
+
+// dx[m] = sum_tap sum_co dy[m - shift(tap)][co] * w[co][tap]; 16 lanes x float4 cover Cout = 64
+__global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, long M, int H, int W, int Cout) {
+    const int tpr = Cout >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    float wr[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[j][t] = w[(c + j) * 9 + t];
+    const long iters = (M + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    for (long itr = 0; itr < iters; ++itr) {
+        const long m = ((long)itr * gridDim.x + blockIdx.x) * rpi + rsub;
+        float s = 0.0f;
+        if (m < M) {
+            const int hw = (int)(m % ((long)H * W));
+            const int h = hw / W, ww = hw % W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // output pixel m' = m - shift(tap) used x[m] through tap
+                const int hh = h - (tap / 3 - 1), w2 = ww - (tap % 3 - 1);
+                if (hh >= 0 && hh < H && w2 >= 0 && w2 < W) {
+                    const float4 g =
+                        *reinterpret_cast<const float4*>(dy + (m - (long)(tap / 3 - 1) * W - (tap % 3 - 1)) * Cout + c);
+                    s = fmaf(g.x, wr[0][tap], s); s = fmaf(g.y, wr[1][tap], s);
+                    s = fmaf(g.z, wr[2][tap], s); s = fmaf(g.w, wr[3][tap], s);
+                }
+            }
+        }
+        // reduce across the tpr lanes that share the pixel (tpr is a power of two <= 64, lane-aligned)
+        for (int o = tpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (m < M && (threadIdx.x % tpr) == 0) dx[m] = s;
+    }
+}
+
+int wgrad_splits(long M, int Cin, int Cout, int TC) {
+    const int tiles = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC);
+    long s = (1024 + tiles - 1) / tiles;
+    const long maxs = (M + 32 * 16 - 1) / (32 * 16);   // at least 16 K-chunks per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+int wgrad_tile(int Cin, int Cout) { return (Cin >= 128 && Cout >= 128) ? 128 : 64; }
+
+}  // namespace
+
+extern "C" int tag_pack_conv_weight(const float* w, float* wfwd, float* wdgrad, int Cin, int Cout, void* stream) {
+    TAG_CHECK_ARG(w && wfwd && Cin > 0 && Cout > 0);
+    const long n = (long)9 * Cin * Cout;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0,
+                       as_stream(stream), w, wfwd, wdgrad, Cin, Cout);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BN_>
+static int launch_fwd(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, int B, int H,
+                      int W, int Cin, int Cout, hipStream_t st) {
+    const long M = (long)B * H * W;
+    const int grid = (int)((M + BM - 1) / BM) * ((Cout + BN_ - 1) / BN_);
+    const size_t lds = (size_t)(2 * BK * LDA + 2 * BK * BN_) * sizeof(float);
+#define LAUNCH_PRO(P)                                                                                            \
+    {                                                                                                            \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fwd_kernel<BN_, P>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, P>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, B, H, W, \
+                           Cin, Cout);                                                                           \
+    }
+    switch (pro) {
+        case 0: LAUNCH_PRO(0) break;
+        case 1: LAUNCH_PRO(1) break;
+        case 2: LAUNCH_PRO(2) break;
+        default: LAUNCH_PRO(3) break;
+    }
+#undef LAUNCH_PRO
+    return 0;
+}
+
+extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
+                                   const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                                   void* stream) {
+    TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0 && W > 0);
+    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0);
+    TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    if (Cout >= 128)
+        launch_fwd<128>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, as_stream(stream));
+    else
+        launch_fwd<64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    const long M = (long)B * H * W;
+    const int TC = wgrad_tile(Cin, Cout);
+    return (size_t)wgrad_splits(M, Cin, Cout, TC) * 9 * Cin * Cout * sizeof(float);
+}
+
+template <int TC>
+static void launch_wgrad(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial,
+                         int B, int H, int W, int Cin, int Cout, int splits, long chunk, hipStream_t st) {
+    const int grid = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC) * splits;
+    const size_t lds = (size_t)(4 * BK * TC) * sizeof(float);
+#define LAUNCH_PRO(P)                                                                                              \
+    {                                                                                                              \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<TC, P>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<TC, P>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, B, \
+                           H, W, Cin, Cout, splits, chunk);                                                        \
+    }
+    switch (pro) {
+        case 0: LAUNCH_PRO(0) break;
+        case 1: LAUNCH_PRO(1) break;
+        case 2: LAUNCH_PRO(2) break;
+        default: LAUNCH_PRO(3) break;
+    }
+#undef LAUNCH_PRO
+}
+
+extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift,
+                                 const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                 void* stream) {
+    TAG_CHECK_ARG(x && dy && dw && ws && B > 0 && H > 0 && W > 0);
+    TAG_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && prologue >= 0 && prologue <= 3);
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    const long M = (long)B * H * W;
+    const int TC = wgrad_tile(Cin, Cout);
+    const int splits = wgrad_splits(M, Cin, Cout, TC);
+    long chunk = (M + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    float* partial = static_cast<float*>(ws);
+    if (TC == 128)
+        launch_wgrad<128>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, splits, chunk,
+                          as_stream(stream));
+    else
+        launch_wgrad<64>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, splits, chunk,
+                         as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    const long n = (long)9 * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0,
+                       as_stream(stream), partial, splits, Cin, Cout, dw);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, const float* col_shift, const float* w,
+                                      float* y, int B, int H, int W, int Cout, void* stream) {
+    TAG_CHECK_ARG(x && w && y && Cout % 4 == 0 && (col_scale == nullptr) == (col_shift == nullptr));
+    const long M = (long)B * H * W;
+    long nb = (M * (Cout / 4) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, w,
+                       y, M, H, W, Cout);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout) {
+    (void)B; (void)H; (void)W;
+    return (size_t)1024 * Cout * 9 * sizeof(double);
+}
+
+extern "C" int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, const float* col_shift, const float* dy,
+                                    float* dw, int B, int H, int W, int Cout, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && dy && dw && ws && Cout % 4 == 0 && Cout / 4 <= 64 && 64 % (Cout / 4) == 0);
+    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
+    const long M = (long)B * H * W;
+    const int rpi = 256 / (Cout / 4);
+    long nb = (M + (long)rpi * 64 - 1) / ((long)rpi * 64);
+    const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+    double* partials = static_cast<double*>(ws);
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nblk), dim3(256), 4 * 64 * 36 * sizeof(double), as_stream(stream), x,
+                       col_scale, col_shift, dy, partials, M, H, W, Cout);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 64)), dim3(64), 0, as_stream(stream),
+                       partials, nblk, Cout * 9, dw);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_conv3x3_c1_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int Cout,
+                                    void* stream) {
+    TAG_CHECK_ARG(dy && w && dx && Cout % 4 == 0 && Cout / 4 <= 64 && 64 % (Cout / 4) == 0);
+    const long M = (long)B * H * W;
+    const int rpi = 256 / (Cout / 4);
+    long nb = (M + rpi - 1) / rpi;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), dy, w, dx, M, H, W, Cout);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

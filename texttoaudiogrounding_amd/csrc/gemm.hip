@@ -1,0 +1,262 @@
+// Dense fp32 GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), row-major, any transposition.
+// Serves nn.Linear fc1 (models/audio_encoder.py:140,216), audio_proj/text_proj
+// (models/audio_text_model.py:45-46,78-87), the GRU input projections (nn.GRU, :141,217), every
+// backward GEMM of those, and align.DotProduct (models/align.py:14-31) through the fused
+// sigmoid/clamp + (B,B,T,N) scatter epilogue.
+//
+// 64x64 tile, 4 waves x one 32x32 MFMA tile, K chunks of 32 staged k-major in LDS
+// (As[k][m], Bs[k][n]) and double-buffered; a k-contiguous operand is transposed on its way into
+// LDS with a stride of 65 floats (conflict-free), an mn-contiguous one is copied with float4.
+#include "tag_common.h"
+
+namespace {
+
+constexpr int GT = 64;   // tile edge
+constexpr int GK = 32;
+
+// element loader with tail handling: 4 consecutive elements starting at p, `n` of them valid
+__device__ __forceinline__ float4 load4(const float* p, int n, bool aligned) {
+    if (n >= 4 && aligned) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0, 0, 0, 0);
+    if (n > 0) v.x = p[0];
+    if (n > 1) v.y = p[1];
+    if (n > 2) v.z = p[2];
+    if (n > 3) v.w = p[3];
+    return v;
+}
+
+// KC = operand is k-contiguous in memory (element (r,k) at base[r*ld + k]); else mn-contiguous
+// (element (r,k) at base[k*ld + r]).  LDS image is always S[k][r].
+template <bool KC>
+struct Stage {
+    static constexpr int LD = KC ? GT + 1 : GT;
+    float4 reg[2];
+    __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (KC) {
+                const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                reg[i] = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
+            } else {
+                const int k = k0 + (idx >> 4), r = r0 + (idx & 15) * 4;
+                reg[i] = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* s) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (KC) {
+                const int r = idx >> 3, k = (idx & 7) * 4;
+                s[(k + 0) * LD + r] = reg[i].x;
+                s[(k + 1) * LD + r] = reg[i].y;
+                s[(k + 2) * LD + r] = reg[i].z;
+                s[(k + 3) * LD + r] = reg[i].w;
+            } else {
+                const int k = idx >> 4, r = (idx & 15) * 4;
+                *reinterpret_cast<float4*>(s + k * LD + r) = reg[i];
+            }
+        }
+    }
+};
+
+struct Epilogue {
+    const float* bias;
+    int act;          // 0 none, 1 relu, 2 sigmoid().clamp(1e-7, 1)
+    int accumulate;
+    float alpha;      // scales the product before bias/act
+    int scatter;      // 1: align layout: row = (b,t), col = (b2,n) -> out[b][b2][t][n]
+    int sc_T, sc_N, sc_B;
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                   int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                   Epilogue ep, bool a_al, bool b_al) {
+    constexpr int LDSA = Stage<AKC>::LD, LDSB = Stage<BKC>::LD;
+    __shared__ __attribute__((aligned(16))) float As[2][GK * LDSA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * LDSB];
+    const int n_tiles = (N + GT - 1) / GT, m_tiles = (M + GT - 1) / GT;
+    const int L = xcd_remap(blockIdx.x, n_tiles * m_tiles);
+    const int n0 = (L % n_tiles) * GT, m0 = (L / n_tiles) * GT;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
+    const int kl = lane >> 5, ml = lane & 31;
+
+    Stage<AKC> sa;
+    Stage<BKC> sb;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    const int kiters = (K + GK - 1) / GK;
+    sa.load(A, lda, m0, M, 0, K, a_al);
+    sb.load(B, ldb, n0, N, 0, K, b_al);
+    sa.store(As[0]);
+    sb.store(Bs[0]);
+    __syncthreads();
+    for (int it = 0; it < kiters; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < kiters) {
+            sa.load(A, lda, m0, M, (it + 1) * GK, K, a_al);
+            sb.load(B, ldb, n0, N, (it + 1) * GK, K, b_al);
+        }
+        const float* a = As[buf] + kl * LDSA + wm0 + ml;
+        const float* b = Bs[buf] + kl * LDSB + wn0 + ml;
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * LDSA], b[kk * LDSB], acc, 0, 0, 0);
+        if (it + 1 < kiters) {
+            sa.store(As[buf ^ 1]);
+            sb.store(Bs[buf ^ 1]);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn0 + ml;
+    if (n >= N) return;
+    const float bv = ep.bias ? ep.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (m >= M) continue;
+        float v = acc[r] * ep.alpha + bv;
+        size_t o;
+        if (ep.scatter) {
+            const int bb = m / ep.sc_T, t = m % ep.sc_T, b2 = n / ep.sc_N, nn = n % ep.sc_N;
+            o = (((size_t)bb * ep.sc_B + b2) * ep.sc_T + t) * ep.sc_N + nn;
+        } else {
+            o = (size_t)m * ldc + n;
+        }
+        if (ep.accumulate) v += C[o];
+        if (ep.act == 1) v = fmaxf(v, 0.0f);
+        else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+        C[o] = v;
+    }
+}
+
+int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M,
+                int N, int K, Epilogue ep, hipStream_t st) {
+    const int grid = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+    const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
+    const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
+    // A stored (M,K) -> k-contiguous; transA: stored (K,M) -> m-contiguous
+    // B stored (K,N) -> n-contiguous; transB: stored (N,K) -> k-contiguous
+    const bool akc = !transA, bkc = transB != 0;
+    if (akc && bkc)
+        hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
+    else if (akc && !bkc)
+        hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
+    else if (!akc && bkc)
+        hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
+    else
+        hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
+    return 0;
+}
+
+// column sums: partial over row blocks then finalize
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, long M, int N,
+                                                             double* __restrict__ partials) {
+    // block handles a 64-column stripe (blockIdx.y) and a strided set of rows
+    __shared__ double sred[4][64];
+    const int col = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;
+    double s = 0;
+    if (col < N)
+        for (long r = (long)blockIdx.x * 4 + rsub; r < M; r += (long)gridDim.x * 4) s += x[(size_t)r * ld + col];
+    sred[rsub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rsub == 0 && col < N)
+        partials[(size_t)blockIdx.x * N + col] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
+                                                 sred[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const double* __restrict__ partials, int nblk, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * N + c];
+    out[c] = (float)s;
+}
+int colsum_blocks(long M) {
+    long nb = (M + 63) / 64;
+    return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb));
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dx[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// row-wise L2 normalisation x / max(||x||, 1e-12)  (F.normalize) for align.DotProduct(l2norm=True)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                          int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int d = lane; d < D; d += 64) { const float v = x[row * D + d]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    for (int d = lane; d < D; d += 64) y[row * D + d] = x[row * D + d] * inv;
+}
+
+}  // namespace
+
+extern "C" int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                        int M, int N, int K, const float* bias, int act, int accumulate, void* stream) {
+    TAG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
+    TAG_CHECK_ARG(act == 0 || act == 1);
+    Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
+    launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_colsum_ws_bytes(long M, int N) { return (size_t)colsum_blocks(M) * N * sizeof(double); }
+
+extern "C" int tag_colsum(const float* x, int ld, long M, int N, float* out, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && out && ws && M > 0 && N > 0 && ld >= N);
+    const int nblk = colsum_blocks(M);
+    double* partials = static_cast<double*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(N, 64)), dim3(256), 0, as_stream(stream), x, ld, M, N,
+                       partials);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64), 0, as_stream(stream), partials, nblk, N, out);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_relu_backward(const float* y, const float* dy, float* dx, long n, void* stream) {
+    TAG_CHECK_ARG(y && dy && dx && n > 0);
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), y, dy, dx, n);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_align_dot_forward(const float* audio, const float* text, float* out, int l2norm, int scaled, int B,
+                                     int T, int N, int D, float* ws, void* stream) {
+    TAG_CHECK_ARG(audio && text && out && B > 0 && T > 0 && N > 0 && D > 0);
+    const float* a = audio;
+    const float* t = text;
+    if (l2norm) {
+        TAG_CHECK_ARG(ws != nullptr);
+        float* an = ws;
+        float* tn = ws + (size_t)B * T * D;
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, as_stream(stream), audio, an,
+                           (long)B * T, D);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv((long)B * N, 4)), dim3(256), 0, as_stream(stream), text, tn,
+                           (long)B * N, D);
+        TAG_LAUNCH_CHECK();
+        a = an;
+        t = tn;
+    }
+    Epilogue ep{nullptr, 2, 0, scaled ? 1.0f / sqrtf((float)D) : 1.0f, 1, T, N, B};
+    // score[(b,t)][(b2,n)] = audio (B*T, D) x text^T (stored (B*N, D): k-contiguous -> transB)
+    launch_gemm(a, D, 0, t, D, 1, out, 0, B * T, B * N, D, ep, as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

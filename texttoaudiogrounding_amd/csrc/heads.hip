@@ -1,0 +1,425 @@
+// T1/T2 text encoder, M1/M2 frame x phrase heads, R1/L1 frame BCE, P1 post-processing.
+// All HBM/latency-bound; one wave per embedding row, coalesced D-wide reads.
+//   nn.Embedding + mean_with_lens      models/text_encoder.py:39-43,79-88; models/utils.py:33-58
+//   match.ExpNegL2 / match.DotProduct  models/match.py:16-33, :43-60
+//   FrameBceLoss                       losses.py:12-24 (+ run_strong.py:107-118 label alignment)
+//   binarize/median/connect/regions    utils/eval_util.py:18-116, run_strong.py:203-252
+#include "tag_common.h"
+
+namespace {
+
+constexpr int MAXD_PER_LANE = 16;   // D <= 1024
+
+// ---------------------------------------------------------------- text encoder
+__global__ __launch_bounds__(256) void embed_mean_fwd_kernel(const int64_t* __restrict__ text,
+                                                             const int64_t* __restrict__ text_len,
+                                                             const float* __restrict__ table,
+                                                             float* __restrict__ token_emb, float* __restrict__ seq_emb,
+                                                             int L, int D, int V) {
+    const int b = blockIdx.x;
+    const int len = (int)text_len[b];
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float s = 0.0f;
+        for (int l = 0; l < L; ++l) {
+            int64_t tok = text[(size_t)b * L + l];
+            tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+            const float v = table[(size_t)tok * D + d];
+            if (token_emb) token_emb[((size_t)b * L + l) * D + d] = v;
+            if (l < len) s += v;
+        }
+        seq_emb[(size_t)b * D + d] = s / (float)len;
+    }
+}
+__global__ __launch_bounds__(256) void embed_mean_bwd_kernel(const float* __restrict__ dseq,
+                                                             const int64_t* __restrict__ text,
+                                                             const int64_t* __restrict__ text_len,
+                                                             float* __restrict__ dtable, int L, int D, int V) {
+    const int b = blockIdx.x;
+    const int len = (int)text_len[b];
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float g = dseq[(size_t)b * D + d] / (float)len;
+        for (int l = 0; l < L && l < len; ++l) {
+            int64_t tok = text[(size_t)b * L + l];
+            tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+            atomicAdd(dtable + (size_t)tok * D + d, g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- match heads
+struct Row {   // one D-vector spread over a wave
+    float v[MAXD_PER_LANE];
+};
+__device__ __forceinline__ void load_row(Row& r, const float* p, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) {
+        const int d = lane + 64 * i;
+        r.v[i] = d < D ? p[d] : 0.0f;
+    }
+}
+__device__ __forceinline__ float dot_rows(const Row& a, const Row& b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) s = fmaf(a.v[i], b.v[i], s);
+    return wave_sum(s);
+}
+
+// grid = B, block = 256: wave w handles t = w, w+4, ...
+__global__ __launch_bounds__(256) void match_fwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
+                                                        float* __restrict__ sim, int kind, int l2norm, int scale,
+                                                        int T, int D) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    Row tx;
+    load_row(tx, text + (size_t)b * D, D, lane);
+    float tinv = 1.0f;
+    if (l2norm) {
+        tinv = 1.0f / fmaxf(sqrtf(dot_rows(tx, tx)), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) tx.v[i] *= tinv;
+    }
+    const float rs = scale ? 1.0f / sqrtf((float)D) : 1.0f;
+    for (int t = wid; t < T; t += 4) {
+        Row a;
+        load_row(a, audio + ((size_t)b * T + t) * D, D, lane);
+        if (l2norm) {
+            const float ainv = 1.0f / fmaxf(sqrtf(dot_rows(a, a)), 1e-12f);
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) a.v[i] *= ainv;
+        }
+        float out;
+        if (kind == 0) {
+            const float s = dot_rows(a, tx) * rs;
+            out = fminf(fmaxf(1.0f / (1.0f + expf(-s)), 1e-7f), 1.0f);
+        } else {
+            float d2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) { const float df = a.v[i] - tx.v[i]; d2 = fmaf(df, df, d2); }
+            d2 = wave_sum(d2);
+            out = expf(-sqrtf(d2));
+        }
+        if (lane == 0) sim[(size_t)b * T + t] = out;
+    }
+}
+
+// backward: daudio rows directly; dtext accumulated per wave in registers, reduced through LDS
+__global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
+                                                        const float* __restrict__ dsim, float* __restrict__ daudio,
+                                                        float* __restrict__ dtext, int kind, int l2norm, int scale,
+                                                        int T, int D) {
+    __shared__ float red[4][64 * MAXD_PER_LANE];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    Row traw, tx;
+    load_row(traw, text + (size_t)b * D, D, lane);
+    tx = traw;
+    float tinv = 1.0f;
+    if (l2norm) {
+        tinv = 1.0f / fmaxf(sqrtf(dot_rows(traw, traw)), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) tx.v[i] *= tinv;
+    }
+    const float rs = scale ? 1.0f / sqrtf((float)D) : 1.0f;
+    Row dtn;   // gradient wrt the (normalised) text vector
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) dtn.v[i] = 0.0f;
+    for (int t = wid; t < T; t += 4) {
+        Row araw, a;
+        load_row(araw, audio + ((size_t)b * T + t) * D, D, lane);
+        a = araw;
+        float ainv = 1.0f;
+        if (l2norm) {
+            ainv = 1.0f / fmaxf(sqrtf(dot_rows(araw, araw)), 1e-12f);
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) a.v[i] *= ainv;
+        }
+        const float g = dsim[(size_t)b * T + t];
+        Row dan;   // gradient wrt the (normalised) audio row
+        if (kind == 0) {
+            const float s = dot_rows(a, tx) * rs;
+            const float p = 1.0f / (1.0f + expf(-s));
+            const float pass = (p >= 1e-7f && p <= 1.0f) ? 1.0f : 0.0f;   // clamp backward
+            const float ds = g * pass * p * (1.0f - p) * rs;
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) { dan.v[i] = ds * tx.v[i]; dtn.v[i] = fmaf(ds, a.v[i], dtn.v[i]); }
+        } else {
+            float d2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) { const float df = a.v[i] - tx.v[i]; d2 = fmaf(df, df, d2); }
+            d2 = wave_sum(d2);
+            const float r = sqrtf(d2);
+            const float out = expf(-r);
+            const float k = r > 0.0f ? -g * out / r : 0.0f;   // d/d(diff) = dr * diff / r, dr = -out * g
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) {
+                const float dd = k * (a.v[i] - tx.v[i]);
+                dan.v[i] = dd;
+                dtn.v[i] -= dd;
+            }
+        }
+        if (l2norm) {   // u = x/||x||: dx = (du - u (u.du)) / ||x||
+            const float ud = dot_rows(a, dan);
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) dan.v[i] = (dan.v[i] - a.v[i] * ud) * ainv;
+        }
+        float* o = daudio + ((size_t)b * T + t) * D;
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) o[d] = dan.v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) red[wid][lane + 64 * i] = dtn.v[i];
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i)
+            dtn.v[i] = red[0][lane + 64 * i] + red[1][lane + 64 * i] + red[2][lane + 64 * i] + red[3][lane + 64 * i];
+        if (l2norm) {
+            const float ud = dot_rows(tx, dtn);
+#pragma unroll
+            for (int i = 0; i < MAXD_PER_LANE; ++i) dtn.v[i] = (dtn.v[i] - tx.v[i] * ud) * tinv;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) dtext[(size_t)b * D + d] = dtn.v[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- frame BCE
+__device__ __forceinline__ int clamp_len(int64_t l, int Tt) { return (int)(l < 1 ? 1 : (l > Tt ? Tt : l)); }
+
+__global__ __launch_bounds__(256) void frame_bce_fwd_kernel(const float* __restrict__ sim, int ld_sim,
+                                                            const float* __restrict__ label, int ld_label,
+                                                            const int64_t* __restrict__ length, int B, int Tt,
+                                                            float* __restrict__ loss) {
+    __shared__ double sred[4];
+    __shared__ double dred[4];
+    double s = 0.0, den = 0.0;
+    for (int i = threadIdx.x; i < B * Tt; i += 256) {
+        const int b = i / Tt, t = i % Tt;
+        if (t < clamp_len(length[b], Tt)) {
+            const float p = sim[(size_t)b * ld_sim + t], y = label[(size_t)b * ld_label + t];
+            const float lp = fmaxf(logf(p), -100.0f), lq = fmaxf(logf(1.0f - p), -100.0f);
+            s += (double)((y - 1.0f) * lq - y * lp);
+        }
+    }
+    for (int b = threadIdx.x; b < B; b += 256) den += (double)clamp_len(length[b], Tt);
+    s = wave_sum_d(s);
+    den = wave_sum_d(den);
+    if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = s; dred[threadIdx.x >> 6] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        loss[0] = (float)((sred[0] + sred[1] + sred[2] + sred[3]) / (dred[0] + dred[1] + dred[2] + dred[3]));
+}
+__global__ __launch_bounds__(256) void frame_bce_bwd_kernel(const float* __restrict__ sim, int ld_sim,
+                                                            const float* __restrict__ label, int ld_label,
+                                                            const int64_t* __restrict__ length, int B, int Tt,
+                                                            const float* __restrict__ dloss, float* __restrict__ dsim) {
+    __shared__ double dred[4];
+    double den = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) den += (double)clamp_len(length[b], Tt);
+    den = wave_sum_d(den);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = den;
+    __syncthreads();
+    const float k = dloss[0] / (float)(dred[0] + dred[1] + dred[2] + dred[3]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * ld_sim; i += gridDim.x * 256) {
+        const int b = i / ld_sim, t = i % ld_sim;
+        float g = 0.0f;
+        if (t < Tt && t < clamp_len(length[b], Tt)) {
+            const float p = sim[(size_t)b * ld_sim + t], y = label[(size_t)b * ld_label + t];
+            g = k * (p - y) / fmaxf((1.0f - p) * p, 1e-12f);
+        }
+        dsim[(size_t)b * ld_sim + t] = g;
+    }
+}
+
+// ---------------------------------------------------------------- post-processing (integer work)
+__device__ __forceinline__ int refl(int j, int T) {
+    // scipy.ndimage 'reflect': (d c b a | a b c d | d c b a)
+    const int period = 2 * T;
+    j %= period;
+    if (j < 0) j += period;
+    return j >= T ? period - 1 - j : j;
+}
+__global__ __launch_bounds__(64) void segments_kernel(const float* __restrict__ sim, int ld, int B, int T,
+                                                      const double* __restrict__ thresholds, int NT, int window,
+                                                      int n_connect, int64_t* __restrict__ regions,
+                                                      int32_t* __restrict__ counts, int max_regions) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= B * NT) return;
+    const int b = id / NT, ti = id % NT;
+    const float* x = sim + (size_t)b * ld;
+    const double th = thresholds[ti];
+    int64_t* out = regions + (size_t)id * max_regions * 2;
+    const int left = window / 2, need = window - window / 2;   // median of a 0/1 window = [#ones >= size - size/2]
+    int n_out = 0;
+    bool in_reg = false;
+    int reg_start = 0;
+    bool have_pending = false;
+    int pend_start = 0, pend_end = 0;
+    for (int i = 0; i <= T; ++i) {
+        bool v = false;
+        if (i < T) {
+            if (window <= 1) {
+                v = (double)x[i] > th;
+            } else {
+                int ones = 0;
+                for (int j = i - left; j < i - left + window; ++j) ones += ((double)x[refl(j, T)] > th) ? 1 : 0;
+                v = ones >= need;
+            }
+        }
+        if (v && !in_reg) { in_reg = true; reg_start = i; }
+        else if (!v && in_reg) {
+            in_reg = false;
+            const int s = reg_start, e = i;
+            if (have_pending && s - pend_end <= n_connect) {
+                pend_end = e;
+            } else {
+                if (have_pending && n_out < max_regions) { out[2 * n_out] = pend_start; out[2 * n_out + 1] = pend_end; ++n_out; }
+                have_pending = true; pend_start = s; pend_end = e;
+            }
+        }
+    }
+    if (have_pending && n_out < max_regions) { out[2 * n_out] = pend_start; out[2 * n_out + 1] = pend_end; ++n_out; }
+    counts[id] = n_out;
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partials) {
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = g[i]; s += (double)v * v; }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partials, int nblk, double* out) {
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, const double* __restrict__ gnorm_sq,
+                                                   float max_norm, float grad_scale) {
+    float coef = grad_scale;
+    if (max_norm > 0.0f && gnorm_sq) {
+        const float norm = (float)sqrt(gnorm_sq[0]) * grad_scale;
+        const float c = max_norm / (norm + 1e-6f);
+        coef *= c < 1.0f ? c : 1.0f;
+    }
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+int sumsq_blocks(long n) {
+    long nb = (n + 256 * 16 - 1) / (256 * 16);
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+
+}  // namespace
+
+extern "C" int tag_embed_mean_forward(const int64_t* text, const int64_t* text_len, const float* table,
+                                      float* token_emb, float* seq_emb, int B, int L, int D, int V, void* stream) {
+    TAG_CHECK_ARG(text && text_len && table && seq_emb && B > 0 && L > 0 && D > 0 && V > 0);
+    hipLaunchKernelGGL(embed_mean_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), text, text_len, table,
+                       token_emb, seq_emb, L, D, V);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_embed_mean_backward(const float* dseq, const int64_t* text, const int64_t* text_len, float* dtable,
+                                       int B, int L, int D, int V, void* stream) {
+    TAG_CHECK_ARG(dseq && text && text_len && dtable && B > 0 && L > 0 && D > 0 && V > 0);
+    hipLaunchKernelGGL(embed_mean_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dseq, text, text_len, dtable,
+                       L, D, V);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_match_forward(const float* audio, const float* text, float* sim, int kind, int l2norm, int scale,
+                                 int B, int T, int D, void* stream) {
+    TAG_CHECK_ARG(audio && text && sim && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
+    TAG_CHECK_ARG(kind == 0 || kind == 1);
+    hipLaunchKernelGGL(match_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), audio, text, sim, kind, l2norm,
+                       scale, T, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_match_backward(const float* audio, const float* text, const float* sim, const float* dsim,
+                                  float* daudio, float* dtext, int kind, int l2norm, int scale, int B, int T, int D,
+                                  void* stream) {
+    (void)sim;
+    TAG_CHECK_ARG(audio && text && dsim && daudio && dtext && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
+    TAG_CHECK_ARG(kind == 0 || kind == 1);
+    hipLaunchKernelGGL(match_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), audio, text, dsim, daudio, dtext,
+                       kind, l2norm, scale, T, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_frame_bce_forward(const float* sim, int ld_sim, const float* label, int ld_label,
+                                     const int64_t* length, int B, int Tt, float* loss, void* stream) {
+    TAG_CHECK_ARG(sim && label && length && loss && B > 0 && Tt > 0 && ld_sim >= Tt && ld_label >= Tt);
+    hipLaunchKernelGGL(frame_bce_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), sim, ld_sim, label, ld_label,
+                       length, B, Tt, loss);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_frame_bce_backward(const float* sim, int ld_sim, const float* label, int ld_label,
+                                      const int64_t* length, int B, int Tt, const float* dloss, float* dsim,
+                                      void* stream) {
+    TAG_CHECK_ARG(sim && label && length && dloss && dsim && B > 0 && Tt > 0 && ld_sim >= Tt && ld_label >= Tt);
+    hipLaunchKernelGGL(frame_bce_bwd_kernel, dim3(cdiv((long)B * ld_sim, 256)), dim3(256), 0, as_stream(stream), sim,
+                       ld_sim, label, ld_label, length, B, Tt, dloss, dsim);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_segments(const float* sim, int ld, int B, int T, const double* thresholds, int NT, int window,
+                            int n_connect, int64_t* regions, int32_t* counts, int max_regions, void* stream) {
+    TAG_CHECK_ARG(sim && thresholds && regions && counts && B > 0 && T > 0 && NT > 0 && ld >= T);
+    TAG_CHECK_ARG(window >= 1 && n_connect >= 0 && max_regions >= (T + 1) / 2);
+    hipLaunchKernelGGL(segments_kernel, dim3(cdiv((long)B * NT, 64)), dim3(64), 0, as_stream(stream), sim, ld, B, T,
+                       thresholds, NT, window, n_connect, regions, counts, max_regions);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_sumsq_ws_bytes(long n) { return (size_t)sumsq_blocks(n) * sizeof(double); }
+extern "C" int tag_sumsq(const float* g, long n, double* out, void* ws, void* stream) {
+    TAG_CHECK_ARG(g && out && ws && n > 0);
+    const int nblk = sumsq_blocks(n);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), g, n,
+                       static_cast<double*>(ws));
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), static_cast<double*>(ws), nblk,
+                       out);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, int step, const double* gnorm_sq, float max_norm, float grad_scale,
+                             void* stream) {
+    TAG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
+                       eps, bc1, bc2_sqrt, gnorm_sq, max_norm, grad_scale);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,111 @@
+"""ctypes binding of libtag_hip.so (the C ABI declared in include/tag_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  ``import torch`` must precede the CDLL load so that the HIP runtime
+PyTorch ships (SONAME libamdhip64.so.7) is the one the library binds to -- streams and device
+pointers are then interchangeable with torch's.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtag_hip.so")
+
+P = c_void_p
+_SIGS = {
+    "tag_abi_version": (c_int, []),
+    "tag_last_error": (c_char_p, []),
+    "tag_device_cu_count": (c_int, []),
+    "tag_logmel_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    "tag_bn_stats_ws_bytes": (c_size_t, [c_long, c_int]),
+    "tag_bn_stats": (c_int, [P, c_long, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
+    "tag_bn_eval_affine": (c_int, [P, P, P, P, c_float, c_int, P, P, P]),
+    "tag_affine_forward": (c_int, [P, c_long, c_int, P, P, P, P]),
+    "tag_bn_param_grad": (c_int, [P, P, c_long, c_int, P, P, P, P, P, P]),
+    "tag_pack_conv_weight": (c_int, [P, P, P, c_int, c_int, P]),
+    "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_wgrad": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_c1_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_c1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_c1_wgrad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_c1_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_bnact_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_float, c_uint64, P]),
+    "tag_bn_backward_ws_bytes": (c_size_t, [c_long, c_int]),
+    "tag_bnrelu_pool_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_float, c_uint64, c_int, P, P]),
+    "tag_bnrelu_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
+    "tag_dropout_mask": (c_int, [c_uint64, c_long, c_float, P, P]),
+    "tag_mean_w_forward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
+    "tag_mean_w_backward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
+    "tag_gemm": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "tag_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
+    "tag_colsum": (c_int, [P, c_int, c_long, c_int, P, P, P]),
+    "tag_relu_backward": (c_int, [P, P, P, c_long, P]),
+    "tag_gru_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_gru_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_embed_mean_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_embed_mean_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_match_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_match_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_align_dot_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
+    "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
+    "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),
+    "tag_sumsq_ws_bytes": (c_size_t, [c_long]),
+    "tag_sumsq": (c_int, [P, c_long, P, P, P]),
+    "tag_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P, c_float, c_float, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtag_hip.so (once) and attach argtypes.  Raises RuntimeError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C texttoaudiogrounding_amd/csrc`). There is no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tag_abi_version() != 1:
+        raise RuntimeError("libtag_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on torch's current stream; raise on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.tag_last_error().decode()}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

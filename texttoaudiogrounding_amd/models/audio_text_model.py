@@ -1,0 +1,61 @@
+"""Model composition (mirror of BiEncoder, models/audio_text_model.py:16-98 in the reference)."""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class BiEncoder(nn.Module):
+    def __init__(self, audio_encoder: nn.Module, text_encoder: nn.Module, match_fn: nn.Module, shared_dim: int,
+                 cross_encoder: Optional[nn.Module] = None, add_proj: bool = False, upsample: bool = False,
+                 freeze_audio_encoder: bool = False, freeze_text_encoder: bool = False,
+                 pretrained: Optional[str] = None):
+        super().__init__()
+        if cross_encoder is not None:
+            raise NotImplementedError("cross_encoder (BASELINE config 4) is outside the round-1 hot path")
+        if upsample:
+            raise NotImplementedError("upsample=True is off in every strong eg_config and not on the HIP path")
+        self.audio_encoder = audio_encoder
+        self.text_encoder = text_encoder
+        self.match_fn = match_fn
+        self.cross_encoder = None
+        if audio_encoder.embed_dim != text_encoder.embed_dim or add_proj:
+            self.audio_proj = nn.Linear(audio_encoder.embed_dim, shared_dim)
+            self.text_proj = nn.Linear(text_encoder.embed_dim, shared_dim)
+        self.interpolate_ratio = self.audio_encoder.downsample_ratio
+        self.upsample = upsample
+        if pretrained is not None and type(self) is BiEncoder:
+            self.load_pretrained(pretrained)
+        if freeze_audio_encoder:
+            for p in self.audio_encoder.parameters():
+                p.requires_grad = False
+        if freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad = False
+
+    def load_pretrained(self, ckpt_path, output_fn=print):
+        state = torch.load(ckpt_path, map_location="cpu")
+        state = state.get("model", state)
+        own = self.state_dict()
+        matched = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
+        output_fn(f"BiEncoder: loading {len(matched)}/{len(own)} tensors from {ckpt_path}")
+        own.update(matched)
+        self.load_state_dict(own)
+
+    def forward(self, input_dict):
+        audio_output = self.audio_encoder(input_dict)
+        audio_emb = audio_output["embedding"]
+        text_emb = self.text_encoder(input_dict)
+        forward_dict = {"audio_emb": audio_emb, "text_emb": text_emb, "audio_len": audio_output["length"]}
+        if "text_len" in input_dict:
+            forward_dict["text_len"] = input_dict["text_len"]
+        if hasattr(self, "audio_proj"):
+            forward_dict["audio_emb"] = ops.LinearFunction.apply(forward_dict["audio_emb"], self.audio_proj.weight,
+                                                                 self.audio_proj.bias)
+            text_emb["seq_emb"] = ops.LinearFunction.apply(text_emb["seq_emb"], self.text_proj.weight,
+                                                           self.text_proj.bias)
+            # token_emb is not projected: no HIP head consumes it on this path (text_level='seq')
+        frame_sim = self.match_fn(forward_dict)
+        return {"frame_sim": frame_sim, "length": audio_output["length"]}

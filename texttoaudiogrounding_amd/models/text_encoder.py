@@ -1,0 +1,48 @@
+"""Word-embedding text encoder (mirror of models/text_encoder.py:14-43,61-88 in the reference)."""
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .utils import init_weights
+
+
+class EmbeddingLayer(nn.Module):
+    def __init__(self, vocab_size: int, embed_dim: int, pretrained_embedding: str = None,
+                 freeze_embedding: bool = False):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.core = nn.Embedding(vocab_size, embed_dim)
+        self.apply(init_weights)
+        if pretrained_embedding is not None:
+            self.load_pretrained_embedding(pretrained_embedding, freeze_embedding)
+
+    def load_pretrained_embedding(self, weight: str, freeze: bool = True):
+        w = np.load(weight)
+        if w.shape != tuple(self.core.weight.shape):
+            raise AssertionError(f"expect embedding with shape {tuple(self.core.weight.shape)} but {w.shape} is given")
+        self.core = nn.Embedding.from_pretrained(torch.as_tensor(w, dtype=torch.float), freeze)
+
+    def forward(self, input_dict: Dict):
+        raise RuntimeError("EmbeddingLayer is evaluated inside EmbeddingAgg's fused gather+mean kernel")
+
+
+class EmbeddingAgg(nn.Module):
+    def __init__(self, vocab_size, embed_dim, pretrained_embedding: str = None, freeze_embedding: bool = False,
+                 aggregation: str = "mean"):
+        super().__init__()
+        self.embedding = EmbeddingLayer(vocab_size, embed_dim, pretrained_embedding, freeze_embedding)
+        self.embed_dim = self.embedding.embed_dim
+        self.agg = aggregation
+        if aggregation != "mean":
+            raise Exception(f"{aggregation} not supported by the HIP path (hot path uses 'mean')")
+
+    def forward(self, input_dict):
+        table = self.embedding.core.weight
+        dev = table.device
+        text = input_dict["text"].long().to(dev).contiguous()
+        lens = torch.as_tensor(input_dict["text_len"]).long().to(dev).contiguous()
+        seq, tok = ops.EmbedMeanFunction.apply(table, text, lens, True)
+        return {"token_emb": tok, "seq_emb": seq}

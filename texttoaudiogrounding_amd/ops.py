@@ -1,0 +1,510 @@
+"""torch.autograd bindings over the C ABI of libtag_hip.so.
+
+PyTorch is plumbing here: device memory (torch.empty), the current HIP stream and autograd
+bookkeeping.  All arithmetic of the hot path runs in the hand-written gfx950 kernels; there is
+no eager fallback -- a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import lib
+from .lib import call, ptr, query
+
+F32 = torch.float32
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}; "
+                           "the HIP path has no CPU fallback")
+    if t.dtype != F32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _empty(*shape, like: torch.Tensor, dtype=F32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _ws(nbytes: int, like: torch.Tensor):
+    return torch.empty((max(int(nbytes), 16) + 7) // 8, device=like.device, dtype=torch.float64)
+
+
+#: when set to a dict by bench.py, MFMA kernel launches are bracketed by HIP events recorded on the
+#: launch stream: key -> list of (start_event, end_event, algorithmic_flops)
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, key, flops):
+        self.key, self.flops = key, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1, self.flops))
+
+
+def new_seed() -> int:
+    """Dropout seed drawn from torch's global CPU generator (so torch.manual_seed controls it)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+# ------------------------------------------------------------------------------------------------
+# thin functional wrappers (no autograd) -- also what the per-kernel parity tests call
+# ------------------------------------------------------------------------------------------------
+
+def logmel(wave, n_fft, win_length, hop, window, fb, want_power=False):
+    wave = _chk(wave, "waveform")
+    B, S = wave.shape
+    Fr = S // hop + 1
+    n_mels = fb.shape[1]
+    out = _empty(B, Fr, n_mels, like=wave)
+    power = _empty(B, Fr, n_mels, like=wave) if want_power else None
+    call("tag_logmel_forward", ptr(wave), B, S, n_fft, win_length, hop, ptr(window), ptr(fb), n_mels, ptr(out),
+         ptr(power))
+    return (out, power) if want_power else out
+
+
+class BNStat:
+    """Per-channel statistics / fused affine of one BatchNorm application."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "train")
+
+
+def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, pre_op=0) -> BNStat:
+    """x2d: (rows, C) view of a channels-last tensor."""
+    rows, C = x2d.shape
+    st = BNStat()
+    st.train = bool(training)
+    st.scale = _empty(C, like=x2d)
+    st.shift = _empty(C, like=x2d)
+    if training:
+        st.mean = _empty(C, like=x2d)
+        st.invstd = _empty(C, like=x2d)
+        ws = _ws(query("tag_bn_stats_ws_bytes", rows, C), x2d)
+        call("tag_bn_stats", ptr(x2d), rows, C, pre_op, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+             ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
+    else:
+        call("tag_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, C, ptr(st.scale),
+             ptr(st.shift))
+        st.mean = running_mean
+        st.invstd = _empty(C, like=x2d)
+        dummy = _empty(C, like=x2d)
+        call("tag_bn_eval_affine", None, None, ptr(running_mean), ptr(running_var), eps, C, ptr(st.invstd), ptr(dummy))
+    return st
+
+
+def pack_conv_weight(w, want_dgrad=True):
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = _empty(9, Cin, Cout, like=w)
+    wd = _empty(9, Cout, Cin, like=w) if want_dgrad else None
+    call("tag_pack_conv_weight", ptr(w), ptr(wf), ptr(wd), Cin, Cout)
+    return wf, wd
+
+
+def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
+    B, H, W, Cin = x.shape
+    y = _empty(B, H, W, Cout, like=x)
+    with _timed(("conv3x3_fwd_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+        call("tag_conv3x3_forward", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout)
+    return y
+
+
+def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None):
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    dw = _empty(Cout, Cin, 3, 3, like=x)
+    ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+    with _timed(("conv3x3_wgrad_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+        call("tag_conv3x3_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
+             ptr(ws))
+    return dw
+
+
+def conv3x3_c1(x, w, col_scale=None, col_shift=None):
+    B, H, W = x.shape
+    Cout = w.shape[0]
+    y = _empty(B, H, W, Cout, like=x)
+    call("tag_conv3x3_c1_forward", ptr(x), ptr(col_scale), ptr(col_shift), ptr(w), ptr(y), B, H, W, Cout)
+    return y
+
+
+def conv3x3_c1_wgrad(x, dy, col_scale=None, col_shift=None):
+    B, H, W = x.shape
+    Cout = dy.shape[3]
+    dw = _empty(Cout, 1, 3, 3, like=x)
+    ws = _ws(query("tag_conv3x3_c1_wgrad_ws_bytes", B, H, W, Cout), x)
+    call("tag_conv3x3_c1_wgrad", ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(dw), B, H, W, Cout, ptr(ws))
+    return dw
+
+
+def conv3x3_c1_dgrad(dy, w):
+    B, H, W, Cout = dy.shape
+    dx = _empty(B, H, W, like=dy)
+    call("tag_conv3x3_c1_dgrad", ptr(dy), ptr(w), ptr(dx), B, H, W, Cout)
+    return dx
+
+
+def bnact_pool(y, st: Optional[BNStat], ph, pw, act=1, pool=0, drop_p=0.0, seed=0):
+    B, H, W, C = y.shape
+    out = _empty(B, H // ph, W // pw, C, like=y)
+    call("tag_bnact_pool_forward", ptr(y), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(out), B,
+         H, W, C, ph, pw, act, pool, float(drop_p), seed)
+    return out
+
+
+def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0):
+    B, H, W, C = y.shape
+    dy = _empty(B, H, W, C, like=y)
+    dg, db = _empty(C, like=y), _empty(C, like=y)
+    ws = _ws(query("tag_bn_backward_ws_bytes", B * H * W, C), y)
+    call("tag_bnrelu_pool_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+         ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, float(drop_p), seed, int(st.train), ptr(ws))
+    return dy, dg, db
+
+
+def bnrelu_backward(y, st: BNStat, gamma, da, inplace=True):
+    C = y.shape[-1]
+    rows = y.numel() // C
+    dy = da if inplace else torch.empty_like(da)
+    dg, db = _empty(C, like=y), _empty(C, like=y)
+    ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), y)
+    call("tag_bnrelu_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+         ptr(da), ptr(dy), ptr(dg), ptr(db), rows, C, int(st.train), ptr(ws))
+    return dy, dg, db
+
+
+def bn_param_grad(x2d, dy2d, st: BNStat):
+    rows, C = x2d.shape
+    dg, db = _empty(C, like=x2d), _empty(C, like=x2d)
+    ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), x2d)
+    call("tag_bn_param_grad", ptr(x2d), ptr(dy2d), rows, C, ptr(st.mean), ptr(st.invstd), ptr(dg), ptr(db), ptr(ws))
+    return dg, db
+
+
+def dropout_mask(seed, shape, p, device):
+    n = int(math.prod(shape))
+    m = torch.empty(n, device=device, dtype=torch.uint8)
+    call("tag_dropout_mask", seed, n, float(p), ptr(m))
+    return m.view(*shape)
+
+
+def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
+         accumulate=False):
+    """Row-major C(M,N) = act(op(A) op(B) + bias) [+ C].  A/B may be strided views (lda/ldb)."""
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    if out is None:
+        out = _empty(M, N, like=A)
+    ldc = ldc if ldc is not None else N
+    call("tag_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(out), ldc, M, N, K, ptr(bias), act,
+         int(accumulate))
+    return out
+
+
+def colsum(x, M, N, ld=None):
+    out = _empty(N, like=x)
+    ws = _ws(query("tag_colsum_ws_bytes", M, N), x)
+    call("tag_colsum", ptr(x), ld if ld is not None else N, M, N, ptr(out), ptr(ws))
+    return out
+
+
+def relu_backward(y, dy):
+    call("tag_relu_backward", ptr(y), ptr(dy), ptr(dy), y.numel())
+    return dy
+
+
+def segments(frame_sim, thresholds, window_size, n_connect):
+    """P1 on the device.  Returns (regions (B,NT,maxK,2) int64, counts (B,NT) int32)."""
+    frame_sim = _chk(frame_sim, "frame_sim")
+    B, T = frame_sim.shape
+    th = torch.as_tensor(thresholds, dtype=torch.float64).to(frame_sim.device)
+    NT = th.numel()
+    maxk = (T + 1) // 2
+    regions = torch.zeros(B, NT, maxk, 2, device=frame_sim.device, dtype=torch.int64)
+    counts = torch.zeros(B, NT, device=frame_sim.device, dtype=torch.int32)
+    call("tag_segments", ptr(frame_sim), T, B, T, ptr(th), NT, int(window_size), int(n_connect), ptr(regions),
+         ptr(counts), maxk)
+    return regions, counts
+
+
+def align_dot(audio, text, l2norm=False, scaled=False):
+    audio, text = _chk(audio, "audio"), _chk(text, "text")
+    B, T, D = audio.shape
+    N = text.shape[1]
+    out = _empty(B, B, T, N, like=audio)
+    ws = _empty((B * T + B * N) * D, like=audio) if l2norm else None
+    call("tag_align_dot_forward", ptr(audio), ptr(text), ptr(out), int(l2norm), int(scaled), B, T, N, D, ptr(ws))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Cnn8Rnn: the whole audio encoder as one autograd node (rows F1-F3, A1-A4 forward + backward)
+# ------------------------------------------------------------------------------------------------
+
+CNN8_POOLS = [(2, 2), (2, 2), (1, 2), (1, 2)]
+
+
+class Cnn8RnnFunction(torch.autograd.Function):
+    """params order: bn0.w, bn0.b, 4 x (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b), fc1.w, fc1.b,
+    rnn (w_ih, w_hh, b_ih, b_hh) x (fwd, reverse)."""
+
+    @staticmethod
+    def forward(ctx, waveform, mod, *params):
+        wave = _chk(waveform, "waveform")
+        training = mod.training
+        bn_train = training and not mod.freeze_bn
+        p = [_chk(t.detach(), "parameter") for t in params]
+        bn0_w, bn0_b = p[0], p[1]
+        blocks = [p[2 + 6 * i: 8 + 6 * i] for i in range(4)]
+        fc_w, fc_b = p[26], p[27]
+        rnn = p[28:36]
+        drop = mod.dropout_p if training else (0.0, 0.0)
+        seeds = [new_seed() for _ in range(5)] if training and (drop[0] > 0 or drop[1] > 0) else [0] * 5
+        saved = {}
+
+        lm = logmel(wave, mod.n_fft, mod.win_length, mod.hop_length, mod.window, mod.mel_fb)   # (B,F,64)
+        B, Fr, NM = lm.shape
+        st0 = bn_stats(lm.view(B * Fr, NM), bn0_w, bn0_b, mod.bn0.running_mean, mod.bn0.running_var, bn_train,
+                       mod.bn0.eps, mod.bn0.momentum)
+        x = None
+        acts = []
+        for i, (c1w, g1, b1, c2w, g2, b2) in enumerate(blocks):
+            blk = getattr(mod, f"conv_block{i + 1}")
+            if i == 0:
+                y1 = conv3x3_c1(lm, c1w, st0.scale, st0.shift)
+                wf1 = wd1 = None
+            else:
+                wf1, wd1 = pack_conv_weight(c1w)
+                y1 = conv3x3(x, wf1, c1w.shape[0])
+            Bx, H, W, C = y1.shape
+            s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
+                          blk.bn1.momentum)
+            wf2, wd2 = pack_conv_weight(c2w)
+            y2 = conv3x3(y1, wf2, C, prologue=1, scale=s1.scale, shift=s1.shift)
+            s2 = bn_stats(y2.view(-1, C), g2, b2, blk.bn2.running_mean, blk.bn2.running_var, bn_train, blk.bn2.eps,
+                          blk.bn2.momentum)
+            ph, pw = CNN8_POOLS[i]
+            xo = bnact_pool(y2, s2, ph, pw, act=1, pool=0, drop_p=drop[0], seed=seeds[i])
+            acts.append((x, y1, s1, y2, s2, wd1, wd2))
+            x = xo
+        Bx, Tp, Wp, C = x.shape
+        xm = _empty(Bx * Tp, C, like=x)
+        call("tag_mean_w_forward", ptr(x), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(xm))
+        M = Bx * Tp
+        fc = gemm(xm, fc_w, M, fc_w.shape[0], C, transB=True, bias=fc_b, act=1)
+        Hh = rnn[1].shape[1]
+        w_ih = torch.cat([rnn[0], rnn[4]], 0)            # (2*3H, 512)
+        b_ih = torch.cat([rnn[2], rnn[6]], 0)
+        w_hh = torch.stack([rnn[1], rnn[5]], 0).contiguous()   # (2,3H,H)
+        b_hh = torch.stack([rnn[3], rnn[7]], 0).contiguous()
+        gi = gemm(fc, w_ih, M, 6 * Hh, fc.shape[1], transB=True, bias=b_ih)
+        y = _empty(Bx, Tp, 2 * Hh, like=x)
+        need_grad = any(ctx.needs_input_grad[2:])
+        gates = _empty(Bx, Tp, 2, 4 * Hh, like=x) if need_grad else None
+        wsr = _empty(6 * Hh * Hh, like=x)
+        call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(wsr), Bx, Tp, Hh)
+        if need_grad:
+            ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gates=gates, y=y, w_ih=w_ih,
+                             w_hh=w_hh, p=p, drop=drop, seeds=seeds, Hh=Hh)
+        mod._last_dropout = dict(p=drop, seeds=seeds)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv = ctx.saved
+        ctx.saved = None
+        p, Hh, y, gates = sv["p"], sv["Hh"], sv["y"], sv["gates"]
+        drop, seeds = sv["drop"], sv["seeds"]
+        dy = _chk(dy, "grad_output")
+        B, T, _ = y.shape
+        M = B * T
+        grads: List[Optional[torch.Tensor]] = [None] * len(p)
+        # ---- GRU ----
+        dgi = _empty(B, T, 2, 3 * Hh, like=y)
+        dgh = _empty(B, T, 2, 3 * Hh, like=y)
+        hprev = _empty(B, T, 2, Hh, like=y)
+        scratch = _empty(2, B, Hh, like=y)
+        call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
+             ptr(scratch), B, T, Hh)
+        fc = sv["fc"]
+        dw_ih = gemm(dgi, fc, 6 * Hh, fc.shape[1], M, transA=True, lda=6 * Hh)          # (6H, 512)
+        db_ih = colsum(dgi, M, 6 * Hh)
+        db_hh = colsum(dgh, M, 6 * Hh)
+        for d in range(2):
+            a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
+            hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
+            dw_hh = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh)
+            grads[28 + 4 * d + 0] = dw_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
+            grads[28 + 4 * d + 1] = dw_hh
+            grads[28 + 4 * d + 2] = db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
+            grads[28 + 4 * d + 3] = db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
+        dfc = gemm(dgi, sv["w_ih"], M, fc.shape[1], 6 * Hh)                              # (M, 512)
+        del dgi, dgh, hprev
+        dfc = relu_backward(fc, dfc)
+        xm = sv["xm"]
+        fc_w = p[26]
+        grads[26] = gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0])
+        grads[27] = colsum(dfc, M, fc_w.shape[0])
+        dxm = gemm(dfc, fc_w, M, fc_w.shape[1], fc_w.shape[0])
+        x_last = sv["x_last"]
+        Bx, Tp, Wp, C = x_last.shape
+        dx = torch.empty_like(x_last)
+        call("tag_mean_w_backward", ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
+        # ---- conv blocks, last to first ----
+        lm, st0 = sv["lm"], sv["st0"]
+        for i in range(3, -1, -1):
+            x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
+            c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]
+            ph, pw = CNN8_POOLS[i]
+            C = y2.shape[3]
+            dy2, grads[2 + 6 * i + 4], grads[2 + 6 * i + 5] = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0],
+                                                                                   seeds[i])
+            del dx
+            grads[2 + 6 * i + 3] = conv3x3_wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift)
+            da1 = conv3x3(dy2, wd2, C)
+            del dy2
+            dy1, grads[2 + 6 * i + 1], grads[2 + 6 * i + 2] = bnrelu_backward(y1, s1, g1, da1)
+            if i > 0:
+                grads[2 + 6 * i] = conv3x3_wgrad(x_in, dy1)
+                dx = conv3x3(dy1, wd1, x_in.shape[3])
+            else:
+                grads[2] = conv3x3_c1_wgrad(lm, dy1, st0.scale, st0.shift)
+                dbn0 = conv3x3_c1_dgrad(dy1, c1w)                                   # (B,F,64) grad wrt bn0 output
+                Bq, Fr, NM = lm.shape
+                grads[0], grads[1] = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0)
+            del dy1, da1
+            sv["acts"][i] = None
+        return (None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# small heads
+# ------------------------------------------------------------------------------------------------
+
+class LinearFunction(torch.autograd.Function):
+    """nn.Linear on the MFMA GEMM (audio_proj / text_proj, models/audio_text_model.py:45-46,78-87)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _chk(x, "x").view(-1, x.shape[-1])
+        w_, b_ = _chk(w.detach(), "weight"), (_chk(b.detach(), "bias") if b is not None else None)
+        M, K = x2.shape
+        N = w_.shape[0]
+        y = gemm(x2, w_, M, N, K, transB=True, bias=b_)
+        ctx.save_for_backward(x2, w_)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = _chk(dy, "grad").view(M, N)
+        dx = gemm(dy2, w, M, K, N).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = gemm(dy2, x2, N, K, M, transA=True, lda=N)
+        db = colsum(dy2, M, N) if ctx.has_bias else None
+        return dx, dw, db
+
+
+class EmbedMeanFunction(torch.autograd.Function):
+    """nn.Embedding gather + mean over valid tokens (rows T1/T2)."""
+
+    @staticmethod
+    def forward(ctx, table, text, text_len, want_tokens):
+        tab = _chk(table.detach(), "embedding table")
+        B, L = text.shape
+        V, D = tab.shape
+        seq = _empty(B, D, like=tab)
+        tok = _empty(B, L, D, like=tab) if want_tokens else None
+        call("tag_embed_mean_forward", ptr(text), ptr(text_len), ptr(tab), ptr(tok), ptr(seq), B, L, D, V)
+        ctx.save_for_backward(text, text_len)
+        ctx.shape = (B, L, D, V)
+        if want_tokens:
+            ctx.mark_non_differentiable(tok)
+            return seq, tok
+        return seq, None
+
+    @staticmethod
+    def backward(ctx, dseq, _dtok):
+        text, text_len = ctx.saved_tensors
+        B, L, D, V = ctx.shape
+        dtab = torch.zeros(V, D, device=dseq.device, dtype=F32)
+        call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
+        return dtab, None, None, None
+
+
+class MatchFunction(torch.autograd.Function):
+    """match.DotProduct (kind 0) / match.ExpNegL2 (kind 1), text_level='seq'."""
+
+    @staticmethod
+    def forward(ctx, audio, text, kind, l2norm, scale):
+        a, t = _chk(audio, "audio_emb"), _chk(text, "text_emb")
+        B, T, D = a.shape
+        sim = _empty(B, T, like=a)
+        call("tag_match_forward", ptr(a), ptr(t), ptr(sim), kind, int(l2norm), int(scale), B, T, D)
+        ctx.save_for_backward(a, t, sim)
+        ctx.cfg = (kind, int(l2norm), int(scale))
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t, sim = ctx.saved_tensors
+        kind, l2norm, scale = ctx.cfg
+        B, T, D = a.shape
+        da, dt = torch.empty_like(a), torch.empty_like(t)
+        call("tag_match_backward", ptr(a), ptr(t), ptr(sim), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), kind, l2norm,
+             scale, B, T, D)
+        return da, dt, None, None, None
+
+
+class FrameBceFunction(torch.autograd.Function):
+    """FrameBceLoss (losses.py:12-24) on (frame_sim[:, :Tt], label[:, :Tt], clamp(length, 1, Tt))."""
+
+    @staticmethod
+    def forward(ctx, sim, label, length, Tt):
+        s, lab = _chk(sim, "frame_sim"), _chk(label, "label")
+        B = s.shape[0]
+        loss = _empty(1, like=s)
+        call("tag_frame_bce_forward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), B, Tt, ptr(loss))
+        ctx.save_for_backward(s, lab, length)
+        ctx.Tt = Tt
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        s, lab, length = ctx.saved_tensors
+        B = s.shape[0]
+        ds = torch.empty_like(s)
+        dl = _chk(dloss.reshape(1), "grad")
+        call("tag_frame_bce_backward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), B, ctx.Tt, ptr(dl),
+             ptr(ds))
+        return ds, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser step on flat buffers (O1)
+# ------------------------------------------------------------------------------------------------
+
+def grad_sumsq(flat_grad):
+    out = torch.empty(1, device=flat_grad.device, dtype=torch.float64)
+    ws = _ws(query("tag_sumsq_ws_bytes", flat_grad.numel()), flat_grad)
+    call("tag_sumsq", ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws))
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    call("tag_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, ptr(gnorm_sq),
+         float(max_norm), float(grad_scale))

@@ -86,8 +86,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model on {device}, batch {args.batch}/GPU; warm-up {args.warmup} step(s)")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         runner.train_step(dict(batch))
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {time.perf_counter() - tw:.3f} s")
     sync()
     ops.PROFILE = {}
     t0 = time.perf_counter()
@@ -95,6 +103,7 @@ def main():
         loss = runner.train_step(dict(batch))
     sync()
     dt = time.perf_counter() - t0
+    log(f"timed {args.steps} steps in {dt:.3f} s")
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -132,6 +141,7 @@ def main():
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 / PEAK_FP32_MFMA, 4),
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle (bounded sample)")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -125,11 +125,12 @@ def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     wf, wdg = ops.pack_conv_weight(w.to(dev))
     sd, td = (s.to(dev), t.to(dev)) if pro else (None, None)
     y = ops.conv3x3(nhwc(x).to(dev), wf, Cout, pro, sd, td)
-    assert relerr(nchw(y), y_ref) < 2e-6
+    tol = 5e-6     # fp32 MFMA = sequential fmaf chain over K = 9*Cin <= 4608 terms (vs an fp64 reference)
+    assert relerr(nchw(y), y_ref) < tol
     da = ops.conv3x3(nhwc(dy).to(dev), wdg, Cin)                                 # dgrad wrt prologue output
-    assert relerr(nchw(da), a.grad) < 2e-6
+    assert relerr(nchw(da), a.grad) < tol
     dw = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev), pro, sd, td)
-    assert relerr(dw, wd.grad) < 2e-6
+    assert relerr(dw, wd.grad) < tol
 
 
 def test_conv3x3_c1(ops, dev):

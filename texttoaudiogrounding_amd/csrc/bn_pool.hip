@@ -92,17 +92,35 @@ struct StatsFn1 {
     }
 };
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk, long rows, int C,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float eps, float momentum, float* running_mean, float* running_var,
-                                         float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partials[(size_t)b * 2 * C + c];
-        s2 += partials[(size_t)b * 2 * C + C + c];
-    }
+// sum the per-block partials: 256 threads = 16 channels x 16 interleaved parts, folded through LDS in a
+// fixed order (deterministic)
+__device__ __forceinline__ void fold_partials(const double* __restrict__ partials, int nblk, int C, int c, int part,
+                                              double& s1, double& s2) {
+    __shared__ double sh[2][16][17];
+    double a = 0, b = 0;
+    if (c < C)
+        for (int blk = part; blk < nblk; blk += 16) {
+            a += partials[(size_t)blk * 2 * C + c];
+            b += partials[(size_t)blk * 2 * C + C + c];
+        }
+    sh[0][part][threadIdx.x & 15] = a;
+    sh[1][part][threadIdx.x & 15] = b;
+    __syncthreads();
+    s1 = 0; s2 = 0;
+    if (part == 0)
+        for (int q = 0; q < 16; ++q) { s1 += sh[0][q][threadIdx.x & 15]; s2 += sh[1][q][threadIdx.x & 15]; }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                               long rows, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               float momentum, float* running_mean,
+                                                               float* running_var, float* mean, float* invstd,
+                                                               float* scale, float* shift) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    double s1, s2;
+    fold_partials(partials, nblk, C, c, part, s1, s2);
+    if (part != 0 || c >= C) return;
     const double m = s1 / (double)rows;
     double var = s2 / (double)rows - m * m;
     if (var < 0) var = 0;
@@ -121,15 +139,12 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, in
 }
 
 // dgamma / dbeta finalize: partial slot 0 = sum dz, slot 1 = sum dz*xhat
-__global__ void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
-                                        float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partials[(size_t)b * 2 * C + c];
-        s2 += partials[(size_t)b * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(256) void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
+                                                              float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    double s1, s2;
+    fold_partials(partials, nblk, C, c, part, s1, s2);
+    if (part != 0 || c >= C) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
 }
@@ -484,7 +499,7 @@ extern "C" int tag_bn_stats(const float* x, long rows, int C, int pre_op, const 
                            StatsFn1{x, C, pre_op}, rows, C, partials);
     }
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk,
                        rows, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -517,7 +532,7 @@ extern "C" int tag_bn_param_grad(const float* x, const float* dy, long rows, int
     hipLaunchKernelGGL(reduce2_kernel<ParamGradFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
                        as_stream(stream), ParamGradFn{x, dy, mean, invstd, C}, rows, C, partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, C,
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -566,7 +581,7 @@ extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, cons
     PoolBwdCtx<PH, PW> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                         \
     hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),          \
                        as_stream(stream), ctx, partials);                                                          \
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, \
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, \
                        C, dgamma, dbeta);                                                                          \
     hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma,     \
                        dgamma, dbeta, bn_train, dy);
@@ -590,7 +605,7 @@ extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const flo
     hipLaunchKernelGGL(reduce2_kernel<BnReluBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
                        as_stream(stream), fn, rows, C, partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), partials, nblk, C,
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, as_stream(stream), fn,
                        gamma, dgamma, dbeta, bn_train, rows, dy);

@@ -28,10 +28,13 @@ __global__ __launch_bounds__(256) void gru_transpose_whh_kernel(const float* __r
     }
 }
 
-// grid (H/16, ceil(B/16), 2)
+// grid (H/16, ceil(B/16), 2).  HT > 0: compile-time hidden size -> the whole K slice of a wave is loaded up
+// front (all loads in flight at once) before the MFMA chain; HT == 0: runtime loop.
+template <int HT>
 __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restrict__ gi, const float* __restrict__ wt,
                                                            const float* __restrict__ b_hh, float* __restrict__ y,
-                                                           float* __restrict__ gates, int B, int T, int H, int step) {
+                                                           float* __restrict__ gates, int B, int T, int Hrt, int step) {
+    const int H = HT > 0 ? HT : Hrt;
     __shared__ float red[4][3][256];
     const int dir = blockIdx.z;
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
@@ -47,12 +50,29 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
         const int brow = b0 + li;
         const float* hp = y + (((size_t)(brow < B ? brow : 0) * T + tp) * 2 + dir) * H;
         const float* wbase = wt + (size_t)dir * 3 * H * H + j0 + li;
-        for (int k = wid * kq + lk; k < (wid + 1) * kq; k += 4) {
-            const float a = brow < B ? hp[k] : 0.0f;
+        if constexpr (HT > 0) {
+            constexpr int NI = HT / 16;
+            float av[NI], wv[3][NI];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const float bw = wbase[((size_t)g * H + k) * H];
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[g], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) {
+                const int k = wid * kq + lk + 4 * i;
+                av[i] = brow < B ? hp[k] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wv[g][i] = wbase[((size_t)g * H + k) * H];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wv[g][i], acc[g], 0, 0, 0);
+        } else {
+            for (int k = wid * kq + lk; k < (wid + 1) * kq; k += 4) {
+                const float a = brow < B ? hp[k] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float bw = wbase[((size_t)g * H + k) * H];
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[g], 0, 0, 0);
+                }
             }
         }
     }
@@ -84,11 +104,13 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
 }
 
 // backward step: see header.  dhbuf (2, B, H) holds dh of the step processed just before.
+template <int HT>
 __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ gates,
                                                            const float* __restrict__ w_hh, float* __restrict__ dgi,
                                                            float* __restrict__ dgh, float* __restrict__ hprev_out,
-                                                           float* __restrict__ dhbuf, int B, int T, int H, int step) {
+                                                           float* __restrict__ dhbuf, int B, int T, int Hrt, int step) {
+    const int H = HT > 0 ? HT : Hrt;
     __shared__ float red[4][256];
     const int dir = blockIdx.z;
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
@@ -104,11 +126,27 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
         const int brow = b0 + li;
         const float* ap = dgh + (((size_t)(brow < B ? brow : 0) * T + tn) * 2 + dir) * K;
         const float* wbase = w_hh + (size_t)dir * K * H + j0 + li;
-        for (int k = wid * kq + lk; k < (wid + 1) * kq; k += 8) {
-            const float a0 = brow < B ? ap[k] : 0.0f;
-            const float a1 = brow < B ? ap[k + 4] : 0.0f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wbase[(size_t)k * H], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wbase[(size_t)(k + 4) * H], acc1, 0, 0, 0);
+        if constexpr (HT > 0) {
+            constexpr int NI = 3 * HT / 16;
+            float av[NI], wv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int k = wid * kq + lk + 4 * i;
+                av[i] = brow < B ? ap[k] : 0.0f;
+                wv[i] = wbase[(size_t)k * H];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wv[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], wv[i + 1], acc1, 0, 0, 0);
+            }
+        } else {
+            for (int k = wid * kq + lk; k < (wid + 1) * kq; k += 8) {
+                const float a0 = brow < B ? ap[k] : 0.0f;
+                const float a1 = brow < B ? ap[k + 4] : 0.0f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wbase[(size_t)k * H], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wbase[(size_t)(k + 4) * H], acc1, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -153,8 +191,14 @@ extern "C" int tag_gru_forward(const float* gi, const float* w_hh, const float* 
     hipLaunchKernelGGL(gru_transpose_whh_kernel, dim3(cdiv((long)6 * H * H, 256)), dim3(256), 0, st, w_hh, ws, H);
     TAG_LAUNCH_CHECK();
     const dim3 grid(H / 16, (B + 15) / 16, 2);
-    for (int s = 0; s < T; ++s)
-        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+    for (int s = 0; s < T; ++s) {
+        if (H == 256)
+            hipLaunchKernelGGL(gru_fwd_step_kernel<256>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+        else if (H == 128)
+            hipLaunchKernelGGL(gru_fwd_step_kernel<128>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+        else
+            hipLaunchKernelGGL(gru_fwd_step_kernel<0>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+    }
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -165,9 +209,17 @@ extern "C" int tag_gru_backward(const float* dy, const float* y, const float* ga
     TAG_CHECK_ARG(H % 16 == 0 && (3 * H) % 32 == 0);
     hipStream_t st = as_stream(stream);
     const dim3 grid(H / 16, (B + 15) / 16, 2);
-    for (int s = 0; s < T; ++s)
-        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev, scratch,
-                           B, T, H, s);
+    for (int s = 0; s < T; ++s) {
+        if (H == 256)
+            hipLaunchKernelGGL(gru_bwd_step_kernel<256>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
+                               scratch, B, T, H, s);
+        else if (H == 128)
+            hipLaunchKernelGGL(gru_bwd_step_kernel<128>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
+                               scratch, B, T, H, s);
+        else
+            hipLaunchKernelGGL(gru_bwd_step_kernel<0>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
+                               scratch, B, T, H, s);
+    }
     TAG_LAUNCH_CHECK();
     return 0;
 }

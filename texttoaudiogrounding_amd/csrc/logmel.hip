@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             if (valid) {
                 const size_t o = (size_t)frame * n_mels + lane;
                 if (power_out) power_out[o] = acc;
-                out_db[o] = 10.0f * log10f(fmaxf(acc, 1e-10f));
+                // clamp(x, 1e-10) then 10 log10: the floor is exactly -100 dB (as on the CPU path)
+                out_db[o] = acc <= 1e-10f ? -100.0f : 10.0f * log10f(acc);
             }
         }
         __syncthreads();

@@ -37,10 +37,22 @@ def synthetic_batch(B, n_samples, seed, device):
             "text_len": text_len.to(device), "label": label.to(device)}
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(batch=8, iters=2):
     """The oracle (plain PyTorch eager CPU restatement) timed on the host cores: fwd+bwd, dropout on."""
     from oracle import tag_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     st = O.state_to(O.init_state(seed=0), torch.float32, requires_grad=True)
     b = O.synthetic_batch(batch, 320000, seed=1234)
     times = []

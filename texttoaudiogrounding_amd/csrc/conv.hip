@@ -20,7 +20,9 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDA = BM + 1;   // (4q+j)*LDA + p hits 32 distinct banks for the transposing A store
 
-__device__ __forceinline__ float4 apply_prologue(float4 v, int mode, float4 s, float4 t) {
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__device__ __forceinline__ f32x4 apply_prologue(f32x4 v, int mode, f32x4 s, f32x4 t) {
     if (mode == 1) {
         v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.0f); v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.0f);
         v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.0f); v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.0f);
@@ -75,34 +77,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     const int cchunks = Cin / BK;
     const int kiters = 9 * cchunks;
 
-    float4 ra[4], rb[B_LOADS];
+    // Loads are branch-free: an out-of-image tap reads the (valid) centre pixel instead and is zeroed when
+    // the chunk is written to LDS; the producer's BN+ReLU prologue is applied there too, so the global loads
+    // stay in flight across the whole MFMA phase of the previous chunk.
+    f32x4 ra[4], rb[B_LOADS], rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned okmask = 0;
     auto load_chunk = [&](int it) {
         const int tap = it / cchunks, c0 = (it - tap * cchunks) * BK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
         if (PRO != 0) {
-            s = *reinterpret_cast<const float4*>(in_scale + c0 + q * 4);
-            t = *reinterpret_cast<const float4*>(in_shift + c0 + q * 4);
+            rs = ldg4(in_scale + c0 + q * 4);
+            rt = ldg4(in_shift + c0 + q * 4);
         }
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int hh = ph[i] + dy, ww = pw_[i] + dx;
-            const bool ok = pv[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(x + (pm[i] + (long)dy * W + dx) * Cin + c0 + q * 4);
-                v = apply_prologue(v, PRO, s, t);
-            }
-            ra[i] = v;
+            const unsigned ok = (unsigned)pv[i] & (unsigned)((unsigned)hh < (unsigned)H) & (unsigned)((unsigned)ww < (unsigned)W);
+            okmask |= ok << i;
+            const long off = (long)(dy * W + dx) * (long)ok;
+            ra[i] = ldg4(x + (pm[i] + off) * Cin + c0 + q * 4);
         }
         const float* wrow = wp + ((size_t)tap * Cin + c0) * Cout;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-            const int n = n0 + n4 * 4;
-            rb[i] = (n < Cout) ? *reinterpret_cast<const float4*>(wrow + (size_t)k * Cout + n)
-                               : make_float4(0, 0, 0, 0);
+            int n = n0 + n4 * 4;
+            n = n < Cout ? n : 0;                          // (columns >= Cout are never stored)
+            rb[i] = ldg4(wrow + (size_t)k * Cout + n);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -110,17 +113,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = (tid >> 3) + 32 * i;
-            a[(q * 4 + 0) * LDA + p] = ra[i].x;
-            a[(q * 4 + 1) * LDA + p] = ra[i].y;
-            a[(q * 4 + 2) * LDA + p] = ra[i].z;
-            a[(q * 4 + 3) * LDA + p] = ra[i].w;
+            f32x4 v = apply_prologue(ra[i], PRO, rs, rt);
+            if (!((okmask >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            a[(q * 4 + 0) * LDA + p] = v.x;
+            a[(q * 4 + 1) * LDA + p] = v.y;
+            a[(q * 4 + 2) * LDA + p] = v.z;
+            a[(q * 4 + 3) * LDA + p] = v.w;
         }
         float* b = Bs + buf * BK * BN_;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-            *reinterpret_cast<float4*>(b + k * BN_ + n4 * 4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = rb[i];
         }
     };
 
@@ -139,21 +144,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     for (int it = 0; it < kiters; ++it) {
         const int buf = it & 1;
         if (it + 1 < kiters) load_chunk(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const float* a = As + buf * BK * LDA + kl * LDA + wm0 + ml;
         const float* b = Bs + buf * BK * BN_ + kl * BN_ + wn0 + ml;
+        // MFMA operand fragments are read one k-step ahead of their use
+        float af[2][2], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[2], bf[TN];
+        for (int i = 0; i < 2; ++i) af[0][i] = a[i * 32];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = a[kk * LDA + i * 32];
+        for (int j = 0; j < TN; ++j) bf[0][j] = b[j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = b[kk * BN_ + j * 32];
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[nxt][i] = a[(2 * ks + 2) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[(2 * ks + 2) * BN_ + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            // pin the software pipeline: the reads of step ks+1 issue ahead of the MFMAs of step ks
+            if (ks + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
         }
+        // nothing that consumes the in-flight global loads may be hoisted into the MFMA phase
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < kiters) store_chunk(buf ^ 1);
         __syncthreads();
     }
@@ -204,32 +224,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * (TC / 2), wn0 = (wid & 1) * (TC / 2);
-    const long HW = (long)H * W;
 
-    float4 ra[LOADS], rb[LOADS];
+    // branch-free loads (clamped addresses); zero-fill and the BN+ReLU prologue happen at the LDS store
+    f32x4 ra[LOADS], rb[LOADS], rs[LOADS], rt[LOADS];
+    unsigned amask = 0, bmask = 0;
+    const int iHW = H * W;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int c4 = ((tid + 256 * i) % (TC / 4)) * 4;
+        if (PRO != 0) {
+            const int cc = ci0 + c4 < Cin ? ci0 + c4 : 0;
+            rs[i] = ldg4(in_scale + cc);
+            rt[i] = ldg4(in_shift + cc);
+        } else {
+            rs[i] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+            rt[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
     auto load_chunk = [&](int it) {
         const long kb = kbeg + (long)it * BK;
+        amask = bmask = 0;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int pix = idx / (TC / 4), c4 = (idx % (TC / 4)) * 4;
-            const long m = kb + pix;
-            float4 va = make_float4(0, 0, 0, 0), vb = make_float4(0, 0, 0, 0);
-            if (m < kend) {
-                const int hw = (int)(m % HW);
-                const int hh = hw / W + dyy, ww = hw % W + dxx;
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W && ci0 + c4 < Cin) {
-                    va = *reinterpret_cast<const float4*>(x + (m + (long)dyy * W + dxx) * Cin + ci0 + c4);
-                    if (PRO != 0) {
-                        const float4 s = *reinterpret_cast<const float4*>(in_scale + ci0 + c4);
-                        const float4 t = *reinterpret_cast<const float4*>(in_shift + ci0 + c4);
-                        va = apply_prologue(va, PRO, s, t);
-                    }
-                }
-                if (co0 + c4 < Cout) vb = *reinterpret_cast<const float4*>(dy + m * Cout + co0 + c4);
-            }
-            ra[i] = va;
-            rb[i] = vb;
+            long m = kb + pix;
+            const bool in_range = m < kend;
+            m = in_range ? m : kend - 1;
+            const unsigned hw = (unsigned)(m % iHW);
+            const int hh = (int)(hw / (unsigned)W) + dyy, ww = (int)(hw % (unsigned)W) + dxx;
+            const unsigned aok = (unsigned)in_range & (unsigned)((unsigned)hh < (unsigned)H) & (unsigned)((unsigned)ww < (unsigned)W);
+            amask |= aok << i;
+            bmask |= (unsigned)in_range << i;
+            const long moff = (long)(dyy * W + dxx) * (long)aok;
+            const int ca = ci0 + c4 < Cin ? ci0 + c4 : 0, cb = co0 + c4 < Cout ? co0 + c4 : 0;
+            ra[i] = ldg4(x + (m + moff) * Cin + ca);
+            rb[i] = ldg4(dy + m * Cout + cb);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -237,8 +267,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int pix = idx / (TC / 4), c4 = (idx % (TC / 4)) * 4;
-            *reinterpret_cast<float4*>(As + (buf * BK + pix) * TC + c4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + (buf * BK + pix) * TC + c4) = rb[i];
+            f32x4 va = apply_prologue(ra[i], PRO, rs[i], rt[i]);
+            if (!((amask >> i) & 1u)) va = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 vb = rb[i];
+            if (!((bmask >> i) & 1u)) vb = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(As + (buf * BK + pix) * TC + c4) = va;
+            *reinterpret_cast<f32x4*>(Bs + (buf * BK + pix) * TC + c4) = vb;
         }
     };
 
@@ -259,21 +293,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     for (int it = 0; it < kiters; ++it) {
         const int buf = it & 1;
         if (it + 1 < kiters) load_chunk(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const float* a = As + (buf * BK + kl) * TC + wm0 + ml;
         const float* b = Bs + (buf * BK + kl) * TC + wn0 + ml;
+        float af[2][TT], bf[2][TT];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TT], bf[TT];
+        for (int i = 0; i < TT; ++i) af[0][i] = a[i * 32];
 #pragma unroll
-            for (int i = 0; i < TT; ++i) af[i] = a[kk * TC + i * 32];
+        for (int j = 0; j < TT; ++j) bf[0][j] = b[j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-            for (int j = 0; j < TT; ++j) bf[j] = b[kk * TC + j * 32];
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i) af[nxt][i] = a[(2 * ks + 2) * TC + i * 32];
+#pragma unroll
+                for (int j = 0; j < TT; ++j) bf[nxt][j] = b[(2 * ks + 2) * TC + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TT; ++i)
 #pragma unroll
                 for (int j = 0; j < TT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < kiters) store_chunk(buf ^ 1);
         __syncthreads();
     }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
             long m = kb + pix;
             const bool in_range = m < kend;
             m = in_range ? m : kend - 1;
-            const unsigned hw = (unsigned)(m % iHW);
+            const unsigned hw = (unsigned)m % (unsigned)iHW;     // M < 2^31 (checked by the launcher)
             const int hh = (int)(hw / (unsigned)W) + dyy, ww = (int)(hw % (unsigned)W) + dxx;
             const unsigned aok = (unsigned)in_range & (unsigned)((unsigned)hh < (unsigned)H) & (unsigned)((unsigned)ww < (unsigned)W);
             amask |= aok << i;
@@ -399,6 +399,121 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
     }
 }
 
+// 4 consecutive pixels along W x 4 output channels per thread: the 3 x 6 input patch (bn0 affine applied once per
+// value) is reused by 144 FMAs, weights live in registers.  Requires W % 4 == 0.
+__device__ __forceinline__ void c1_patch(const float* x, const float* cs, const float* ct, int H, int W, long mrow,
+                                         int h, int w0, float xin[3][6]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int hh = h + r - 1;
+        const bool hok = (unsigned)hh < (unsigned)H;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int ww = w0 + c - 1;
+            const bool ok = hok & ((unsigned)ww < (unsigned)W);
+            const int wc = ok ? ww : w0;
+            const long off = ok ? (long)(r - 1) * W + (c - 1) : 0;
+            const float v = x[mrow + off];
+            const float a = cs ? fmaf(v, cs[wc], ct[wc]) : v;
+            xin[r][c] = ok ? a : 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                           const float* __restrict__ ct, const float* __restrict__ w,
+                                                           float* __restrict__ y, long M, int H, int W, int Cout) {
+    const int C4 = Cout >> 2, gpi = 256 / C4;   // requires 256 % C4 == 0: a thread keeps its channel quad
+    const long groups = M >> 2;                 // W % 4 == 0 -> M % 4 == 0 and a group never straddles a row
+    const int c = (threadIdx.x % C4) << 2;
+    float wr[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[j][t] = w[(c + j) * 9 + t];
+    for (long gi = (long)blockIdx.x * gpi + threadIdx.x / C4; gi < groups; gi += (long)gridDim.x * gpi) {
+        const long m = gi << 2;
+        const int hw = (int)(m % ((long)H * W));
+        const int h = hw / W, w0 = hw % W;
+        float xin[3][6];
+        c1_patch(x, cs, ct, H, W, m, h, w0, xin);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(xin[tap / 3][px + tap % 3], wr[j][tap], o[j]);
+            *reinterpret_cast<float4*>(y + (m + px) * Cout + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_c1_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                             const float* __restrict__ ct,
+                                                             const float* __restrict__ dy, double* __restrict__ partials,
+                                                             long M, int H, int W, int Cout) {
+    extern __shared__ double sred[];         // [4 waves][64][36] (only lanes < tpr used)
+    const int tpr = Cout >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    float acc[4][9];
+    double dacc[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { acc[j][t] = 0.0f; dacc[j][t] = 0.0; }
+    int cnt = 0;
+    const long groups = M >> 2;
+    for (long gidx = (long)blockIdx.x * rpi + rsub; gidx < groups; gidx += (long)gridDim.x * rpi) {
+        const long m = gidx << 2;
+        const int hw = (int)(m % ((long)H * W));
+        const int h = hw / W, w0 = hw % W;
+        float xin[3][6];
+        c1_patch(x, cs, ct, H, W, m, h, w0, xin);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const float4 g = *reinterpret_cast<const float4*>(dy + (m + px) * Cout + c);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][tap] = fmaf(xin[tap / 3][px + tap % 3], gv[j], acc[j][tap]);
+        }
+        if (++cnt == 16) {   // flush fp32 partial sums (64 pixels) into fp64
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { dacc[j][t] += acc[j][t]; acc[j][t] = 0.0f; }
+            cnt = 0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            double v = dacc[j][t] + (double)acc[j][t];
+            for (int o = 32; o >= tpr; o >>= 1) v += __shfl_xor(v, o, 64);
+            dacc[j][t] = v;
+        }
+    if (lane < tpr) {
+        double* mine = sred + (wid * 64 + lane) * 36;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) mine[j * 9 + t] = dacc[j][t];
+    }
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        double* p = partials + (size_t)blockIdx.x * Cout * 9;
+        for (int e = 0; e < 36; ++e) {
+            double s = 0;
+            for (int wv = 0; wv < 4; ++wv) s += sred[(wv * 64 + threadIdx.x) * 36 + e];
+            p[(c + e / 9) * 9 + e % 9] = s;
+        }
+    }
+}
+
 // partials [nblk][Cout*9] doubles
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                             const float* __restrict__ ct,
@@ -464,13 +579,21 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
         }
     }
 }
-__global__ void conv_c1_wgrad_finalize_kernel(const double* __restrict__ partials, int nblk, int n,
-                                              float* __restrict__ dw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void conv_c1_wgrad_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                                    int n, float* __restrict__ dw) {
+    // 16 outputs x 16 interleaved parts per block, folded through LDS in a fixed order
+    __shared__ double sh[16][17];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * n + i];
-    dw[i] = (float)s;
+    if (i < n)
+        for (int b = part; b < nblk; b += 16) s += partials[(size_t)b * n + i];
+    sh[part][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (part == 0 && i < n) {
+        double t = 0;
+        for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x & 15];
+        dw[i] = (float)t;
+    }
 }
 
 // dx[m] = sum_tap sum_co dy[m - shift(tap)][co] * w[co][tap]; 16 lanes x float4 cover Cout = 64
@@ -509,8 +632,9 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
 }
 
 int wgrad_splits(long M, int Cin, int Cout, int TC) {
+    // two full residency rounds of 512 workgroup slots (2 per CU): floor, so the last round is not a stub
     const int tiles = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC);
-    long s = (1024 + tiles - 1) / tiles;
+    long s = 1024 / tiles;
     const long maxs = (M + 32 * 16 - 1) / (32 * 16);   // at least 16 K-chunks per split
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -609,6 +733,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     TAG_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
+    TAG_CHECK_ARG(M < (1L << 31));
     const int TC = wgrad_tile(Cin, Cout);
     const int splits = wgrad_splits(M, Cin, Cout, TC);
     long chunk = (M + splits - 1) / splits;
@@ -634,8 +759,15 @@ extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, co
     const long M = (long)B * H * W;
     long nb = (M * (Cout / 4) + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, w,
-                       y, M, H, W, Cout);
+    if (W % 4 == 0 && 256 % (Cout / 4) == 0) {
+        nb = ((M / 4) * (Cout / 4) + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(conv_c1_fwd4_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale,
+                           col_shift, w, y, M, H, W, Cout);
+    } else {
+        hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale,
+                           col_shift, w, y, M, H, W, Cout);
+    }
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -654,10 +786,14 @@ extern "C" int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, cons
     long nb = (M + (long)rpi * 64 - 1) / ((long)rpi * 64);
     const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
     double* partials = static_cast<double*>(ws);
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nblk), dim3(256), 4 * 64 * 36 * sizeof(double), as_stream(stream), x,
-                       col_scale, col_shift, dy, partials, M, H, W, Cout);
+    if (W % 4 == 0)
+        hipLaunchKernelGGL(conv_c1_wgrad4_kernel, dim3(nblk), dim3(256), 4 * 64 * 36 * sizeof(double),
+                           as_stream(stream), x, col_scale, col_shift, dy, partials, M, H, W, Cout);
+    else
+        hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nblk), dim3(256), 4 * 64 * 36 * sizeof(double),
+                           as_stream(stream), x, col_scale, col_shift, dy, partials, M, H, W, Cout);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 64)), dim3(64), 0, as_stream(stream),
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
                        partials, nblk, Cout * 9, dw);
     TAG_LAUNCH_CHECK();
     return 0;

@@ -4,14 +4,13 @@
 // backward GEMM of those, and align.DotProduct (models/align.py:14-31) through the fused
 // sigmoid/clamp + (B,B,T,N) scatter epilogue.
 //
-// 64x64 tile, 4 waves x one 32x32 MFMA tile, K chunks of 32 staged k-major in LDS
+// 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 staged k-major in LDS
 // (As[k][m], Bs[k][n]) and double-buffered; a k-contiguous operand is transposed on its way into
 // LDS with a stride of 65 floats (conflict-free), an mn-contiguous one is copied with float4.
 #include "tag_common.h"
 
 namespace {
 
-constexpr int GT = 64;   // tile edge
 constexpr int GK = 32;
 
 // element loader with tail handling: 4 consecutive elements starting at p, `n` of them valid
@@ -26,27 +25,30 @@ __device__ __forceinline__ float4 load4(const float* p, int n, bool aligned) {
 }
 
 // KC = operand is k-contiguous in memory (element (r,k) at base[r*ld + k]); else mn-contiguous
-// (element (r,k) at base[k*ld + r]).  LDS image is always S[k][r].
-template <bool KC>
+// (element (r,k) at base[k*ld + r]).  LDS image is always S[k][r].  T = tile edge (64 or 128).
+template <bool KC, int T>
 struct Stage {
-    static constexpr int LD = KC ? GT + 1 : GT;
-    float4 reg[2];
+    static constexpr int LD = KC ? T + 1 : T;
+    static constexpr int NL = T / 32;       // float4 per thread per chunk
+    f32x4 reg[NL];
     __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NL; ++i) {
             const int idx = threadIdx.x + 256 * i;
+            float4 v;
             if (KC) {
                 const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-                reg[i] = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
+                v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
             } else {
-                const int k = k0 + (idx >> 4), r = r0 + (idx & 15) * 4;
-                reg[i] = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
+                const int k = k0 + idx / (T / 4), r = r0 + (idx % (T / 4)) * 4;
+                v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
             }
+            reg[i] = (f32x4){v.x, v.y, v.z, v.w};
         }
     }
     __device__ __forceinline__ void store(float* s) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NL; ++i) {
             const int idx = threadIdx.x + 256 * i;
             if (KC) {
                 const int r = idx >> 3, k = (idx & 7) * 4;
@@ -55,8 +57,8 @@ struct Stage {
                 s[(k + 2) * LD + r] = reg[i].z;
                 s[(k + 3) * LD + r] = reg[i].w;
             } else {
-                const int k = idx >> 4, r = (idx & 15) * 4;
-                *reinterpret_cast<float4*>(s + k * LD + r) = reg[i];
+                const int k = idx / (T / 4), r = (idx % (T / 4)) * 4;
+                *reinterpret_cast<f32x4*>(s + k * LD + r) = reg[i];
             }
         }
     }
@@ -71,31 +73,38 @@ struct Epilogue {
     int sc_T, sc_N, sc_B;
 };
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int T>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                    Epilogue ep, bool a_al, bool b_al) {
-    constexpr int LDSA = Stage<AKC>::LD, LDSB = Stage<BKC>::LD;
-    __shared__ __attribute__((aligned(16))) float As[2][GK * LDSA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK * LDSB];
-    const int n_tiles = (N + GT - 1) / GT, m_tiles = (M + GT - 1) / GT;
+    constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
+    constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
+    constexpr int ASZ = ((GK * LDSA + 3) / 4) * 4, BSZ = ((GK * LDSB + 3) / 4) * 4;   // keep 16-byte alignment
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][ASZ]
+    float* Bs = smem + 2 * ASZ;            // [2][BSZ]
+    const int n_tiles = (N + T - 1) / T, m_tiles = (M + T - 1) / T;
     const int L = xcd_remap(blockIdx.x, n_tiles * m_tiles);
-    const int n0 = (L % n_tiles) * GT, m0 = (L / n_tiles) * GT;
+    const int n0 = (L % n_tiles) * T, m0 = (L / n_tiles) * T;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wm0 = (wid >> 1) * 32, wn0 = (wid & 1) * 32;
+    const int wm0 = (wid >> 1) * (T / 2), wn0 = (wid & 1) * (T / 2);
     const int kl = lane >> 5, ml = lane & 31;
 
-    Stage<AKC> sa;
-    Stage<BKC> sb;
-    f32x16 acc;
+    Stage<AKC, T> sa;
+    Stage<BKC, T> sb;
+    f32x16 acc[TT][TT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int kiters = (K + GK - 1) / GK;
     sa.load(A, lda, m0, M, 0, K, a_al);
     sb.load(B, ldb, n0, N, 0, K, b_al);
-    sa.store(As[0]);
-    sb.store(Bs[0]);
+    sa.store(As);
+    sb.store(Bs);
     __syncthreads();
     for (int it = 0; it < kiters; ++it) {
         const int buf = it & 1;
@@ -103,55 +112,99 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             sa.load(A, lda, m0, M, (it + 1) * GK, K, a_al);
             sb.load(B, ldb, n0, N, (it + 1) * GK, K, b_al);
         }
-        const float* a = As[buf] + kl * LDSA + wm0 + ml;
-        const float* b = Bs[buf] + kl * LDSB + wn0 + ml;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a = As + buf * ASZ + kl * LDSA + wm0 + ml;
+        const float* b = Bs + buf * BSZ + kl * LDSB + wn0 + ml;
+        float af[2][TT], bf[2][TT];
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * LDSA], b[kk * LDSB], acc, 0, 0, 0);
+        for (int i = 0; i < TT; ++i) af[0][i] = a[i * 32];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) bf[0][j] = b[j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int ks = 0; ks < GK / 2; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < GK / 2) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i) af[nxt][i] = a[(2 * ks + 2) * LDSA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TT; ++j) bf[nxt][j] = b[(2 * ks + 2) * LDSB + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < GK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < kiters) {
-            sa.store(As[buf ^ 1]);
-            sb.store(Bs[buf ^ 1]);
+            sa.store(As + (buf ^ 1) * ASZ);
+            sb.store(Bs + (buf ^ 1) * BSZ);
         }
         __syncthreads();
     }
-    const int n = n0 + wn0 + ml;
-    if (n >= N) return;
-    const float bv = ep.bias ? ep.bias[n] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-        if (m >= M) continue;
-        float v = acc[r] * ep.alpha + bv;
-        size_t o;
-        if (ep.scatter) {
-            const int bb = m / ep.sc_T, t = m % ep.sc_T, b2 = n / ep.sc_N, nn = n % ep.sc_N;
-            o = (((size_t)bb * ep.sc_B + b2) * ep.sc_T + t) * ep.sc_N + nn;
-        } else {
-            o = (size_t)m * ldc + n;
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int n = n0 + wn0 + j * 32 + ml;
+            if (n >= N) continue;
+            const float bv = ep.bias ? ep.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m >= M) continue;
+                float v = acc[i][j][r] * ep.alpha + bv;
+                size_t o;
+                if (ep.scatter) {
+                    const int bb = m / ep.sc_T, t = m % ep.sc_T, b2 = n / ep.sc_N, nn = n % ep.sc_N;
+                    o = (((size_t)bb * ep.sc_B + b2) * ep.sc_T + t) * ep.sc_N + nn;
+                } else {
+                    o = (size_t)m * ldc + n;
+                }
+                if (ep.accumulate) v += C[o];
+                if (ep.act == 1) v = fmaxf(v, 0.0f);
+                else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+                C[o] = v;
+            }
         }
-        if (ep.accumulate) v += C[o];
-        if (ep.act == 1) v = fmaxf(v, 0.0f);
-        else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
-        C[o] = v;
+}
+
+template <bool AKC, bool BKC, int T>
+void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                   Epilogue ep, bool a_al, bool b_al, hipStream_t st) {
+    constexpr int ASZ = ((GK * Stage<AKC, T>::LD + 3) / 4) * 4, BSZ = ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
+    const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
     }
+    const int grid = ((M + T - 1) / T) * ((N + T - 1) / T);
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
+                       a_al, b_al);
 }
 
 int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M,
                 int N, int K, Epilogue ep, hipStream_t st) {
-    const int grid = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
     // A stored (M,K) -> k-contiguous; transA: stored (K,M) -> m-contiguous
     // B stored (K,N) -> n-contiguous; transB: stored (N,K) -> k-contiguous
     const bool akc = !transA, bkc = transB != 0;
-    if (akc && bkc)
-        hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
-    else if (akc && !bkc)
-        hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
-    else if (!akc && bkc)
-        hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
-    else
-        hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al);
+    // 128x128 tiles once they still fill the 256 CUs, 64x64 tiles for the small problems
+    const bool big = (long)((M + 127) / 128) * ((N + 127) / 128) >= 192;
+#define GEMM_DISPATCH(AK, BK_)                                                                          \
+    if (big) launch_gemm_t<AK, BK_, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, st);          \
+    else launch_gemm_t<AK, BK_, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, st);
+    if (akc && bkc) { GEMM_DISPATCH(true, true) }
+    else if (akc && !bkc) { GEMM_DISPATCH(true, false) }
+    else if (!akc && bkc) { GEMM_DISPATCH(false, true) }
+    else { GEMM_DISPATCH(false, false) }
+#undef GEMM_DISPATCH
     return 0;
 }
 

@@ -14,6 +14,13 @@
 //   (Cout,Cin,3,3) layout.
 #include "tag_common.h"
 
+// TAG_ABLATE (tools/ablate_conv.py builds private copies with -DTAG_ABLATE=n; the product is built with 0):
+//   1 no global loads after chunk 0 | 2 no LDS stores after chunk 0 | 4 no barrier | 8 no MFMA | 16 setprio(1) in the MFMA phase
+//   32 odd workgroups run at priority 1 throughout
+#ifndef TAG_ABLATE
+#define TAG_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int BM = 128;
@@ -35,6 +42,14 @@ __device__ __forceinline__ f32x4 apply_prologue(f32x4 v, int mode, f32x4 s, f32x
     return v;
 }
 
+// register image of one K chunk (32 channels of one tap) on its way from HBM to LDS
+template <int B_LOADS>
+struct FwdStage {
+    f32x4 ra[4], rb[B_LOADS];
+    unsigned ok;
+    int c0;
+};
+
 template <int BN_, int PRO>
 __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ wp,
@@ -47,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [2][BK][LDA]
     float* Bs = smem + 2 * BK * LDA;         // [2][BK][BN_]   (2*BK*LDA*4 bytes is a multiple of 16)
+    float* Ss = Bs + 2 * BK * BN_;           // [Cin] producer BN scale, then [Cin] shift (PRO != 0)
 
     const long M = (long)B * H * W;
     const int n_tiles = (Cout + BN_ - 1) / BN_;
@@ -58,63 +74,78 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
 
-    // ---- A staging geometry: 4 pixels per thread, 4 channels (one float4) each ----
+    if (PRO != 0)
+        for (int c = tid; c < Cin; c += 256) { Ss[c] = in_scale[c]; Ss[Cin + c] = in_shift[c]; }
+
+    // ---- staging geometry, fixed for the whole tile: 4 pixels x one channel quad per thread (A), B_LOADS
+    //      float4 of the weight chunk (B).  Per chunk only wave-uniform offsets change.  Byte offsets are
+    //      32-bit (every tensor of the path is < 4 GiB; checked by the launcher).
     const int q = tid & 7;                   // channel quad within the 32-channel chunk
-    int ph[4], pw_[4];
-    long pm[4];
-    bool pv[4];
+    unsigned aoffb[4];                       // byte offset of (pixel, channel quad) in x
+    unsigned tapok[4];                       // bit t set <=> tap t of this pixel lies inside the image
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = (tid >> 3) + 32 * i;
         const long m = m0 + p;
-        pv[i] = m < M;
-        const long mm = pv[i] ? m : 0;
+        const bool v = m < M;
+        const long mm = v ? m : 0;
         const int hw = (int)(mm % ((long)H * W));
-        ph[i] = hw / W;
-        pw_[i] = hw % W;
-        pm[i] = mm;
+        const int h = hw / W, w = hw % W;
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            mask |= (unsigned)(v & ((unsigned)hh < (unsigned)H) & ((unsigned)ww < (unsigned)W)) << t;
+        }
+        tapok[i] = mask;
+        aoffb[i] = (unsigned)((mm * Cin + q * 4) * 4);
+    }
+    unsigned boffb[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+        int n = n0 + n4 * 4;
+        n = n < Cout ? n : 0;                // (columns >= Cout are computed on garbage and never stored)
+        boffb[i] = (unsigned)((k * Cout + n) * 4);
     }
     const int cchunks = Cin / BK;
     const int kiters = 9 * cchunks;
 
-    // Loads are branch-free: an out-of-image tap reads the (valid) centre pixel instead and is zeroed when
-    // the chunk is written to LDS; the producer's BN+ReLU prologue is applied there too, so the global loads
-    // stay in flight across the whole MFMA phase of the previous chunk.
-    f32x4 ra[4], rb[B_LOADS], rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
-    unsigned okmask = 0;
-    auto load_chunk = [&](int it) {
+    // Loads are branch-free: an out-of-image tap reads the (valid) centre pixel instead and is zeroed when the
+    // chunk is written to LDS; the producer's BN+ReLU prologue is applied there too, so the global loads of
+    // chunk i+1 stay in flight across the whole MFMA phase of chunk i.
+    auto issue_chunk = [&](FwdStage<B_LOADS>& st, int it) {
         const int tap = it / cchunks, c0 = (it - tap * cchunks) * BK;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        if (PRO != 0) {
-            rs = ldg4(in_scale + c0 + q * 4);
-            rt = ldg4(in_shift + c0 + q * 4);
-        }
-        okmask = 0;
+        const int aoff = ((dy * W + dx) * Cin + c0) * 4;   // wave-uniform byte offsets
+        const int coff = c0 * 4;
+        st.ok = 0;
+        st.c0 = c0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int hh = ph[i] + dy, ww = pw_[i] + dx;
-            const unsigned ok = (unsigned)pv[i] & (unsigned)((unsigned)hh < (unsigned)H) & (unsigned)((unsigned)ww < (unsigned)W);
-            okmask |= ok << i;
-            const long off = (long)(dy * W + dx) * (long)ok;
-            ra[i] = ldg4(x + (pm[i] + off) * Cin + c0 + q * 4);
+            const unsigned ok = (tapok[i] >> tap) & 1u;
+            st.ok |= ok << i;
+            const unsigned off = aoffb[i] + (unsigned)(ok ? aoff : coff);   // 32-bit wrap-around sum (aoff < 0)
+            st.ra[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + off);
         }
-        const float* wrow = wp + ((size_t)tap * Cin + c0) * Cout;
+        const float* wchunk = wp + ((size_t)tap * Cin + c0) * Cout;   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int idx = tid + 256 * i;
-            const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-            int n = n0 + n4 * 4;
-            n = n < Cout ? n : 0;                          // (columns >= Cout are never stored)
-            rb[i] = ldg4(wrow + (size_t)k * Cout + n);
-        }
+        for (int i = 0; i < B_LOADS; ++i)
+            st.rb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wchunk) + boffb[i]);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](const FwdStage<B_LOADS>& st, int buf) {
         float* a = As + buf * BK * LDA;
+        f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (PRO != 0) {
+            rs = *reinterpret_cast<const f32x4*>(Ss + st.c0 + q * 4);
+            rt = *reinterpret_cast<const f32x4*>(Ss + Cin + st.c0 + q * 4);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = (tid >> 3) + 32 * i;
-            f32x4 v = apply_prologue(ra[i], PRO, rs, rt);
-            if (!((okmask >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 v = apply_prologue(st.ra[i], PRO, rs, rt);
+            if (!((st.ok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             a[(q * 4 + 0) * LDA + p] = v.x;
             a[(q * 4 + 1) * LDA + p] = v.y;
             a[(q * 4 + 2) * LDA + p] = v.z;
@@ -125,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = st.rb[i];
         }
     };
 
@@ -137,45 +168,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
     const int kl = lane >> 5, ml = lane & 31;
-    for (int it = 0; it < kiters; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < kiters) load_chunk(it + 1);
-        __builtin_amdgcn_sched_barrier(0);
+    // MFMA phase of one chunk; operand fragments are read PF k-steps ahead of their use
+    auto mma_chunk = [&](int buf) {
         const float* a = As + buf * BK * LDA + kl * LDA + wm0 + ml;
         const float* b = Bs + buf * BK * BN_ + kl * BN_ + wn0 + ml;
-        // MFMA operand fragments are read one k-step ahead of their use
-        float af[2][2], bf[2][TN];
+        constexpr int PF = 2, NS = BK / 2;
+        float af[PF + 1][2], bf[PF + 1][TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[0][i] = a[i * 32];
+        for (int s0 = 0; s0 < PF; ++s0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = b[j * 32];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            for (int i = 0; i < 2; ++i) af[s0][i] = a[(2 * s0) * LDA + i * 32];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < BK / 2) {
+            for (int j = 0; j < TN; ++j) bf[s0][j] = b[(2 * s0) * BN_ + j * 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[nxt][i] = a[(2 * ks + 2) * LDA + i * 32];
+        for (int ks = 0; ks < NS; ++ks) {
+            const int cur = ks % (PF + 1), nxt = (ks + PF) % (PF + 1);
+            if (ks + PF < NS) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[(2 * ks + 2) * BN_ + j * 32];
+                for (int i = 0; i < 2; ++i) af[nxt][i] = a[(2 * (ks + PF)) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[(2 * (ks + PF)) * BN_ + j * 32];
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            // pin the software pipeline: the reads of step ks+1 issue ahead of the MFMAs of step ks
-            if (ks + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (TAG_ABLATE & 8) acc[i][j][0] += af[cur][i] * bf[cur][j];
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                }
+            // pin the software pipeline: the reads of step ks+PF issue ahead of the MFMAs of step ks
+            if (ks + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
         }
+    };
+
+    FwdStage<B_LOADS> s0;
+    issue_chunk(s0, 0);
+    __syncthreads();                          // Ss (scale/shift table) visible
+    store_chunk(s0, 0);
+    __syncthreads();
+    for (int it = 0; it < kiters; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < kiters && !(TAG_ABLATE & 1)) issue_chunk(s0, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk(buf);
         // nothing that consumes the in-flight global loads may be hoisted into the MFMA phase
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < kiters) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (it + 1 < kiters && !(TAG_ABLATE & 2)) store_chunk(s0, buf ^ 1);
+        if (!(TAG_ABLATE & 4)) __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -658,7 +701,7 @@ static int launch_fwd(const float* x, const float* wp, int pro, const float* s, 
                       int W, int Cin, int Cout, hipStream_t st) {
     const long M = (long)B * H * W;
     const int grid = (int)((M + BM - 1) / BM) * ((Cout + BN_ - 1) / BN_);
-    const size_t lds = (size_t)(2 * BK * LDA + 2 * BK * BN_) * sizeof(float);
+    const size_t lds = (size_t)(2 * BK * LDA + 2 * BK * BN_ + 2 * 512) * sizeof(float);   // + scale/shift table
 #define LAUNCH_PRO(P)                                                                                            \
     {                                                                                                            \
         static bool attr_set = false;                                                                            \
@@ -684,7 +727,8 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
                                    const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
                                    void* stream) {
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0 && W > 0);
-    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0);
+    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
+    TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside the kernel
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     if (Cout >= 128)

@@ -140,8 +140,12 @@ int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p
  * models/audio_text_model.py:45-46,78-87), the GRU input projections and all their backward GEMMs.
  * act: 0 none, 1 relu.  bias (N) nullable.
  * ------------------------------------------------------------------------------------------- */
+/* ws (nullable): scratch of tag_gemm_ws_bytes(M,N,K) bytes enabling a deterministic split-K for problems whose
+ * MxN tile count cannot fill the chip (weight gradients: K = B*T); 0 bytes = not needed. */
+size_t tag_gemm_ws_bytes(int M, int N, int K);
 int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C,
-             int ldc, int M, int N, int K, const float* bias, int act, int accumulate, void* stream);
+             int ldc, int M, int N, int K, const float* bias, int act, int accumulate, void* ws,
+             void* stream);
 /* out[n] = sum_m x[m, n] (bias gradients); x (M,N) ld; ws >= tag_colsum_ws_bytes */
 size_t tag_colsum_ws_bytes(long M, int N);
 int tag_colsum(const float* x, int ld, long M, int N, float* out, void* ws, void* stream);

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void reduce2_kernel(Fn fn, long rows, int C, d
     const int c = (threadIdx.x % tpr) << 2;
     const int rsub = threadIdx.x / tpr;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    fn.prep(c);                             // per-channel constants -> registers (a thread keeps its channel quad)
     for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
         float4 a, b;
         fn(r, c, a, b);
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void reduce2_scalar_kernel(Fn1 fn, long rows, 
 
 struct StatsFn {
     const float* x; int C; int pre;
+    __device__ void prep(int) {}
     __device__ void operator()(long r, int c, float4& a, float4& b) const {
         float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
         if (pre == 1) { v.x = leaky01(v.x); v.y = leaky01(v.y); v.z = leaky01(v.z); v.w = leaky01(v.w); }
@@ -174,11 +176,14 @@ __global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x
 
 struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
     const float* x; const float* dy; const float* mean; const float* invstd; int C;
+    float4 m, is;
+    __device__ void prep(int c) {
+        m = *reinterpret_cast<const float4*>(mean + c);
+        is = *reinterpret_cast<const float4*>(invstd + c);
+    }
     __device__ void operator()(long r, int c, float4& a, float4& b) const {
         const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
         const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * C + c);
-        const float4 m = *reinterpret_cast<const float4*>(mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
         a = g;
         b = make_float4(g.x * (v.x - m.x) * is.x, g.y * (v.y - m.y) * is.y, g.z * (v.z - m.z) * is.z,
                         g.w * (v.w - m.w) * is.w);
@@ -194,20 +199,20 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __rest
                                                              const float* __restrict__ shift,
                                                              float* __restrict__ out, int B, int H, int W, int C,
                                                              int act, int pool, float drop_p, uint64_t seed) {
-    const int Ho = H / PH, Wo = W / PW, C4 = C >> 2;
-    const long total = (long)B * Ho * Wo * C4;
+    const int Ho = H / PH, Wo = W / PW, C4 = C >> 2, rpi = 256 / C4;
+    const int c = (threadIdx.x % C4) << 2, rsub = threadIdx.x / C4;
+    const long slots = (long)B * Ho * Wo;
     const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C4) << 2;
-        long q = i / C4;
-        const int wo = (int)(q % Wo); q /= Wo;
+    float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
+    if (scale) {
+        s = *reinterpret_cast<const float4*>(scale + c);
+        t = *reinterpret_cast<const float4*>(shift + c);
+    }
+    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
+        const long i = r * C4 + (c >> 2);            // flat float4 index of the output element
+        const int wo = (int)(r % Wo); long q = r / Wo;
         const int ho = (int)(q % Ho);
         const int b = (int)(q / Ho);
-        float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
-        if (scale) {
-            s = *reinterpret_cast<const float4*>(scale + c);
-            t = *reinterpret_cast<const float4*>(shift + c);
-        }
         float sum[4] = {0, 0, 0, 0}, mx[4];
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
@@ -228,13 +233,13 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __rest
                     }
                 }
             }
-        float r[4];
+        float rr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
-            if (drop_p > 0.0f) r[j] = tag_keep(seed, (uint64_t)i * 4 + j, drop_p) ? r[j] * keep_scale : 0.0f;
+            rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
+            if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)i * 4 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
         }
-        reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+        reinterpret_cast<float4*>(out)[i] = make_float4(rr[0], rr[1], rr[2], rr[3]);
     }
 }
 
@@ -247,16 +252,15 @@ template <int PH, int PW>
 struct PoolBwdCtx {
     const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
     const float* dout; int B, H, W, C; float drop_p; uint64_t seed;
+    float sv[4], tv[4], mv[4], iv[4];      // per-channel constants of this thread's channel quad
+    __device__ void prep(int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sv[j] = scale[c + j]; tv[j] = shift[c + j]; mv[j] = mean[c + j]; iv[j] = invstd[c + j]; }
+    }
     // dz for the slot (b, hs, ws, c..c+3); valid[dh][dw] tells which positions exist
     __device__ void slot(int b, int hs, int ws, int c, float dz[PH][PW][4], float xh[PH][PW][4],
                          bool ex[PH][PW]) const {
         const int Ho = H / PH, Wo = W / PW;
-        const float4 s = *reinterpret_cast<const float4*>(scale + c);
-        const float4 t = *reinterpret_cast<const float4*>(shift + c);
-        const float4 m = *reinterpret_cast<const float4*>(mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const float sv[4] = {s.x, s.y, s.z, s.w}, tv[4] = {t.x, t.y, t.z, t.w};
-        const float mv[4] = {m.x, m.y, m.z, m.w}, iv[4] = {is.x, is.y, is.z, is.w};
         const bool full = hs < Ho && ws < Wo;
         float a[PH][PW][4];
 #pragma unroll
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW>
     const int Ho = ctx.H / PH, Wo = ctx.W / PW;   // only full slots carry gradient
     const long slots = (long)ctx.B * Ho * Wo;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    ctx.prep(c);
     for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
         const int ws = (int)(r % Wo); long q = r / Wo;
         const int hs = (int)(q % Ho); const int b = (int)(q / Ho);
@@ -344,25 +349,24 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW> 
                                                              const float* __restrict__ dgamma,
                                                              const float* __restrict__ dbeta, int bn_train,
                                                              float* __restrict__ dy) {
-    const int C = ctx.C, C4 = C >> 2;
+    const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
     const int Hs = (ctx.H + PH - 1) / PH, Ws = (ctx.W + PW - 1) / PW;
-    const long total = (long)ctx.B * Hs * Ws * C4;
+    const long slots = (long)ctx.B * Hs * Ws;
     const float invN = 1.0f / (float)((long)ctx.B * ctx.H * ctx.W);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C4) << 2;
-        long q = i / C4;
-        const int ws = (int)(q % Ws); q /= Ws;
+    ctx.prep(c);
+    float k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        k0[j] = gamma[c + j] * ctx.iv[j];
+        k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
+        k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
+    }
+    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
+        const int ws = (int)(r % Ws); long q = r / Ws;
         const int hs = (int)(q % Hs); const int b = (int)(q / Hs);
         float dz[PH][PW][4], xh[PH][PW][4]; bool ex[PH][PW];
         ctx.slot(b, hs, ws, c, dz, xh, ex);
-        float k0[4], k1[4], k2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gi = gamma[c + j] * ctx.invstd[c + j];
-            k0[j] = gi;
-            k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
-            k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
-        }
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
@@ -382,13 +386,16 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW> 
 struct BnReluBwdFn {
     const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
     const float* da; int C;
+    float4 s, t, m, is;
+    __device__ void prep(int c) {
+        s = *reinterpret_cast<const float4*>(scale + c);
+        t = *reinterpret_cast<const float4*>(shift + c);
+        m = *reinterpret_cast<const float4*>(mean + c);
+        is = *reinterpret_cast<const float4*>(invstd + c);
+    }
     __device__ void operator()(long r, int c, float4& a, float4& b) const {
         const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + c);
         const float4 g = *reinterpret_cast<const float4*>(da + (size_t)r * C + c);
-        const float4 s = *reinterpret_cast<const float4*>(scale + c);
-        const float4 t = *reinterpret_cast<const float4*>(shift + c);
-        const float4 m = *reinterpret_cast<const float4*>(mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
         a.x = fmaf(v.x, s.x, t.x) > 0.0f ? g.x : 0.0f;
         a.y = fmaf(v.y, s.y, t.y) > 0.0f ? g.y : 0.0f;
         a.z = fmaf(v.z, s.z, t.z) > 0.0f ? g.z : 0.0f;
@@ -402,25 +409,26 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFn fn, c
                                                                const float* __restrict__ dgamma,
                                                                const float* __restrict__ dbeta, int bn_train,
                                                                long rows, float* __restrict__ dy) {
-    const int C = fn.C, C4 = C >> 2;
-    const long total = rows * C4;
+    const int C = fn.C, tpr = C >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
     const float invN = 1.0f / (float)rows;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C4) << 2;
-        const long r = i / C4;
+    fn.prep(c);
+    float k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        k0[j] = gamma[c + j] * fn.invstd[c + j];
+        k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
+        k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
+    }
+    const float mv[4] = {fn.m.x, fn.m.y, fn.m.z, fn.m.w}, iv[4] = {fn.is.x, fn.is.y, fn.is.z, fn.is.w};
+    for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
         float4 dz, dzx;
         fn(r, c, dz, dzx);
         const float4 v = *reinterpret_cast<const float4*>(fn.y + (size_t)r * C + c);
         const float vv[4] = {v.x, v.y, v.z, v.w}, dzv[4] = {dz.x, dz.y, dz.z, dz.w};
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float is = fn.invstd[c + j];
-            const float xh = (vv[j] - fn.mean[c + j]) * is;
-            const float k1 = bn_train ? dbeta[c + j] * invN : 0.0f;
-            const float k2 = bn_train ? dgamma[c + j] * invN : 0.0f;
-            o[j] = gamma[c + j] * is * (dzv[j] - k1 - xh * k2);
-        }
+        for (int j = 0; j < 4; ++j) o[j] = k0[j] * (dzv[j] - k1[j] - (vv[j] - mv[j]) * iv[j] * k2[j]);
         *reinterpret_cast<float4*>(dy + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -463,6 +471,13 @@ int red_blocks(long rows, int C) {
     if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
     if (nb < 1) nb = 1;
     return (int)nb;
+}
+// row-strided elementwise kernels: 256/(C/4) rows per block iteration, <= 8 iterations per thread at full size
+int apply_blocks(long rows, int C) {
+    const int rpi = 256 / (C >> 2);
+    long nb = (rows + (long)rpi * 4 - 1) / ((long)rpi * 4);
+    if (nb > 8192) nb = 8192;
+    return (int)(nb < 1 ? 1 : nb);
 }
 bool vec_ok(int C) { return C % 4 == 0 && C >= 4 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
 int ew_blocks(long n) {
@@ -547,9 +562,9 @@ extern "C" int tag_bnact_pool_forward(const float* y, const float* scale, const 
     TAG_CHECK_ARG(y && out && C % 4 == 0 && (act == 1 || act == 2) && (pool == 0 || pool == 1));
     TAG_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
-    const long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    TAG_CHECK_ARG(vec_ok(C));
     bool launched = false;
-    const int nb = ew_blocks(total);
+    const int nb = apply_blocks((long)B * (H / ph) * (W / pw), C);
     DISPATCH_POOL(2, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
                                            y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
     DISPATCH_POOL(1, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
@@ -574,8 +589,7 @@ extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, cons
     double* partials = static_cast<double*>(ws);
     const long slots = (long)B * (H / ph) * (W / pw);
     const int nblk = red_blocks(slots, C);
-    const long total = (long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (C / 4);
-    const int nb = ew_blocks(total);
+    const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C);
     bool launched = false;
 #define POOL_BWD_BODY                                                                                              \
     PoolBwdCtx<PH, PW> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                         \
@@ -607,7 +621,7 @@ extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const flo
     TAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, as_stream(stream), fn,
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn,
                        gamma, dgamma, dbeta, bn_train, rows, dy);
     TAG_LAUNCH_CHECK();
     return 0;

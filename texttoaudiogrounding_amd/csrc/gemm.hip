@@ -76,7 +76,8 @@ struct Epilogue {
 template <bool AKC, bool BKC, int T>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
-                                                   Epilogue ep, bool a_al, bool b_al) {
+                                                   Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
+                                                   float* __restrict__ partial) {
     constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
     constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
     constexpr int ASZ = ((GK * LDSA + 3) / 4) * 4, BSZ = ((GK * LDSB + 3) / 4) * 4;   // keep 16-byte alignment
@@ -84,8 +85,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     float* As = smem;                      // [2][ASZ]
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
     const int n_tiles = (N + T - 1) / T, m_tiles = (M + T - 1) / T;
-    const int L = xcd_remap(blockIdx.x, n_tiles * m_tiles);
+    int L = xcd_remap(blockIdx.x, n_tiles * m_tiles * splits);
+    const int split = L % splits;            // K slices of one tile are neighbours (same XCD, shared operands in L2)
+    L /= splits;
     const int n0 = (L % n_tiles) * T, m0 = (L / n_tiles) * T;
+    const int kbeg = split * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm0 = (wid >> 1) * (T / 2), wn0 = (wid & 1) * (T / 2);
     const int kl = lane >> 5, ml = lane & 31;
@@ -100,17 +105,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int kiters = (K + GK - 1) / GK;
-    sa.load(A, lda, m0, M, 0, K, a_al);
-    sb.load(B, ldb, n0, N, 0, K, b_al);
+    const int kiters = (kend - kbeg + GK - 1) / GK;
+    sa.load(A, lda, m0, M, kbeg, kend, a_al);
+    sb.load(B, ldb, n0, N, kbeg, kend, b_al);
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
     for (int it = 0; it < kiters; ++it) {
         const int buf = it & 1;
         if (it + 1 < kiters) {
-            sa.load(A, lda, m0, M, (it + 1) * GK, K, a_al);
-            sb.load(B, ldb, n0, N, (it + 1) * GK, K, b_al);
+            sa.load(A, lda, m0, M, kbeg + (it + 1) * GK, kend, a_al);
+            sb.load(B, ldb, n0, N, kbeg + (it + 1) * GK, kend, b_al);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* a = As + buf * ASZ + kl * LDSA + wm0 + ml;
@@ -156,6 +161,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 if (m >= M) continue;
+                if (splits > 1) {            // raw K-slice partial; the epilogue runs in splitk_reduce_kernel
+                    partial[((size_t)split * M + m) * N + n] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] * ep.alpha + bv;
                 size_t o;
                 if (ep.scatter) {
@@ -172,9 +181,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
 }
 
+// deterministic split-K combine + epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N,
+                                                            float* __restrict__ C, int ldc, Epilogue ep) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float s = 0.0f;
+        for (int sp = 0; sp < splits; ++sp) s += partial[(size_t)sp * total + i];
+        float v = s * ep.alpha + (ep.bias ? ep.bias[n] : 0.0f);
+        const size_t o = (size_t)m * ldc + n;
+        if (ep.accumulate) v += C[o];
+        if (ep.act == 1) v = fmaxf(v, 0.0f);
+        else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+        C[o] = v;
+    }
+}
+
+// K slices for a problem whose tile count cannot fill the chip (weight-gradient GEMMs: small MxN, K = B*T)
+int gemm_splits(int M, int N, int K) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 384 || K < 1024) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long maxs = K / 256;
+    if (s > maxs) s = maxs;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+}
+
 template <bool AKC, bool BKC, int T>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                   Epilogue ep, bool a_al, bool b_al, hipStream_t st) {
+                   Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st) {
     constexpr int ASZ = ((GK * Stage<AKC, T>::LD + 3) / 4) * 4, BSZ = ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
     static bool attr_set = false;
@@ -183,23 +220,31 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int grid = ((M + T - 1) / T) * ((N + T - 1) / T);
+    const int grid = ((M + T - 1) / T) * ((N + T - 1) / T) * splits;
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = (kchunk + GK - 1) / GK * GK;
     hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
-                       a_al, b_al);
+                       a_al, b_al, splits, kchunk, partial);
+    if (splits > 1) {
+        long nb = ((long)M * N + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, partial, splits, M, N, C, ldc, ep);
+    }
 }
 
 int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M,
-                int N, int K, Epilogue ep, hipStream_t st) {
+                int N, int K, Epilogue ep, float* ws, hipStream_t st) {
+    const int splits = (ws && !ep.scatter) ? gemm_splits(M, N, K) : 1;
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
     // A stored (M,K) -> k-contiguous; transA: stored (K,M) -> m-contiguous
     // B stored (K,N) -> n-contiguous; transB: stored (N,K) -> k-contiguous
     const bool akc = !transA, bkc = transB != 0;
     // 128x128 tiles once they still fill the 256 CUs, 64x64 tiles for the small problems
-    const bool big = (long)((M + 127) / 128) * ((N + 127) / 128) >= 192;
-#define GEMM_DISPATCH(AK, BK_)                                                                          \
-    if (big) launch_gemm_t<AK, BK_, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, st);          \
-    else launch_gemm_t<AK, BK_, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, st);
+    const bool big = splits == 1 && (long)((M + 127) / 128) * ((N + 127) / 128) >= 192;
+#define GEMM_DISPATCH(AK, BK_)                                                                                  \
+    if (big) launch_gemm_t<AK, BK_, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st);      \
+    else launch_gemm_t<AK, BK_, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, splits, ws, st);
     if (akc && bkc) { GEMM_DISPATCH(true, true) }
     else if (akc && !bkc) { GEMM_DISPATCH(true, false) }
     else if (!akc && bkc) { GEMM_DISPATCH(false, true) }
@@ -257,12 +302,17 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 
 }  // namespace
 
+extern "C" size_t tag_gemm_ws_bytes(int M, int N, int K) {
+    const int s = gemm_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 extern "C" int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
-                        int M, int N, int K, const float* bias, int act, int accumulate, void* stream) {
+                        int M, int N, int K, const float* bias, int act, int accumulate, void* ws, void* stream) {
     TAG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
     TAG_CHECK_ARG(act == 0 || act == 1);
     Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
-    launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, as_stream(stream));
+    launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -309,7 +359,7 @@ extern "C" int tag_align_dot_forward(const float* audio, const float* text, floa
     }
     Epilogue ep{nullptr, 2, 0, scaled ? 1.0f / sqrtf((float)D) : 1.0f, 1, T, N, B};
     // score[(b,t)][(b2,n)] = audio (B*T, D) x text^T (stored (B*N, D): k-contiguous -> transB)
-    launch_gemm(a, D, 0, t, D, 1, out, 0, B * T, B * N, D, ep, as_stream(stream));
+    launch_gemm(a, D, 0, t, D, 1, out, 0, B * T, B * N, D, ep, nullptr, as_stream(stream));
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -44,7 +44,8 @@ _SIGS = {
     "tag_dropout_mask": (c_int, [c_uint64, c_long, c_float, P, P]),
     "tag_mean_w_forward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_mean_w_backward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
-    "tag_gemm": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "tag_gemm_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "tag_gemm": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "tag_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
     "tag_colsum": (c_int, [P, c_int, c_long, c_int, P, P, P]),
     "tag_relu_backward": (c_int, [P, P, P, c_long, P]),

@@ -207,8 +207,10 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     if out is None:
         out = _empty(M, N, like=A)
     ldc = ldc if ldc is not None else N
+    nws = query("tag_gemm_ws_bytes", M, N, K)
+    ws = _ws(nws, A) if nws else None
     call("tag_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(out), ldc, M, N, K, ptr(bias), act,
-         int(accumulate))
+         int(accumulate), ptr(ws))
     return out
 
 

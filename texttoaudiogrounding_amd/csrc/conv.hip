@@ -20,6 +20,12 @@
 #ifndef TAG_ABLATE
 #define TAG_ABLATE 0
 #endif
+// LDS chunk buffers of the MFMA conv kernels: 2 = double buffered (one barrier per chunk, 2 workgroups/CU),
+// 1 = single buffered (two barriers per chunk, ~37 KB -> 3 workgroups/CU; the next chunk waits in registers).
+// Measured on MI355X: 1 buffer + 3 workgroups/CU is 4-7 % faster (more waves to cover load latency).
+#ifndef TAG_NBUF
+#define TAG_NBUF 1
+#endif
 
 namespace {
 
@@ -51,7 +57,7 @@ struct FwdStage {
 };
 
 template <int BN_, int PRO>
-__global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ wp,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
@@ -60,9 +66,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     constexpr int TN = BN_ / 64;            // 32-wide n tiles per wave (waves 2 x 2, wave tile 64 x BN_/2)
     constexpr int B_LOADS = BN_ / 32;       // float4 per thread for the B chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                        // [2][BK][LDA]
-    float* Bs = smem + 2 * BK * LDA;         // [2][BK][BN_]   (2*BK*LDA*4 bytes is a multiple of 16)
-    float* Ss = Bs + 2 * BK * BN_;           // [Cin] producer BN scale, then [Cin] shift (PRO != 0)
+    float* As = smem;                        // [NBUF][BK][LDA]
+    float* Bs = smem + TAG_NBUF * BK * LDA;  // [NBUF][BK][BN_]   (BK*LDA*4 bytes is a multiple of 16)
+    float* Ss = Bs + TAG_NBUF * BK * BN_;    // [Cin] producer BN scale, then [Cin] shift (PRO != 0)
 
     const long M = (long)B * H * W;
     const int n_tiles = (Cout + BN_ - 1) / BN_;
@@ -211,13 +217,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
     store_chunk(s0, 0);
     __syncthreads();
     for (int it = 0; it < kiters; ++it) {
-        const int buf = it & 1;
+        const int buf = TAG_NBUF == 2 ? (it & 1) : 0;
         if (it + 1 < kiters && !(TAG_ABLATE & 1)) issue_chunk(s0, it + 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_chunk(buf);
         // nothing that consumes the in-flight global loads may be hoisted into the MFMA phase
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < kiters && !(TAG_ABLATE & 2)) store_chunk(s0, buf ^ 1);
+        if (TAG_NBUF == 1) __syncthreads();       // every wave is done reading the single buffer
+        if (it + 1 < kiters && !(TAG_ABLATE & 2)) store_chunk(s0, TAG_NBUF == 2 ? (buf ^ 1) : 0);
         if (!(TAG_ABLATE & 4)) __syncthreads();
     }
 
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const float* __rest
 // wgrad: partial[split][tap][ci][co] = sum_{m in split} prologue(x)[m + shift(tap)][ci] * dy[m][co]
 // ------------------------------------------------------------------------------------------
 template <int TC, int PRO>   // TC x TC output tile (64 or 128)
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_wgrad_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ in_scale,
                                                                const float* __restrict__ in_shift,
                                                                const float* __restrict__ dy,
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     constexpr int TT = TC / 64;              // 32x32 tiles per wave per dim (waves 2 x 2)
     constexpr int LOADS = TC / 32;           // float4 per thread per operand per chunk (32 pixels x TC)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                        // [2][BK][TC]  (pixel-major, ci contiguous)
-    float* Bs = smem + 2 * BK * TC;          // [2][BK][TC]
+    float* As = smem;                        // [NBUF][BK][TC]  (pixel-major, ci contiguous)
+    float* Bs = smem + TAG_NBUF * BK * TC;   // [NBUF][BK][TC]
 
     const long M = (long)B * H * W;
     const int ci_tiles = (Cin + TC - 1) / TC, co_tiles = (Cout + TC - 1) / TC;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     }
     __syncthreads();
     for (int it = 0; it < kiters; ++it) {
-        const int buf = it & 1;
+        const int buf = TAG_NBUF == 2 ? (it & 1) : 0;
         if (it + 1 < kiters) load_chunk(it + 1);
         __builtin_amdgcn_sched_barrier(0);
         const float* a = As + (buf * BK + kl) * TC + wm0 + ml;
@@ -363,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
             __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < kiters) store_chunk(buf ^ 1);
+        if (TAG_NBUF == 1) __syncthreads();       // every wave is done reading the single buffer
+        if (it + 1 < kiters) store_chunk(TAG_NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
     float* out = partial + ((size_t)split * 9 + tap) * Cin * Cout;
@@ -675,9 +683,9 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
 }
 
 int wgrad_splits(long M, int Cin, int Cout, int TC) {
-    // two full residency rounds of 512 workgroup slots (2 per CU): floor, so the last round is not a stub
+    // two full residency rounds of 768 workgroup slots (3 per CU): floor, so the last round is not a stub
     const int tiles = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC);
-    long s = 1024 / tiles;
+    long s = 1536 / tiles;
     const long maxs = (M + 32 * 16 - 1) / (32 * 16);   // at least 16 K-chunks per split
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -701,7 +709,7 @@ static int launch_fwd(const float* x, const float* wp, int pro, const float* s, 
                       int W, int Cin, int Cout, hipStream_t st) {
     const long M = (long)B * H * W;
     const int grid = (int)((M + BM - 1) / BM) * ((Cout + BN_ - 1) / BN_);
-    const size_t lds = (size_t)(2 * BK * LDA + 2 * BK * BN_ + 2 * 512) * sizeof(float);   // + scale/shift table
+    const size_t lds = (size_t)(TAG_NBUF * (BK * LDA + BK * BN_) + 2 * 512) * sizeof(float);   // + scale/shift table
 #define LAUNCH_PRO(P)                                                                                            \
     {                                                                                                            \
         static bool attr_set = false;                                                                            \
@@ -749,7 +757,7 @@ template <int TC>
 static void launch_wgrad(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial,
                          int B, int H, int W, int Cin, int Cout, int splits, long chunk, hipStream_t st) {
     const int grid = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC) * splits;
-    const size_t lds = (size_t)(4 * BK * TC) * sizeof(float);
+    const size_t lds = (size_t)(TAG_NBUF * 2 * BK * TC) * sizeof(float);
 #define LAUNCH_PRO(P)                                                                                              \
     {                                                                                                              \
         static bool attr_set = false;                                                                              \

@@ -12,14 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "texttoaudiogrounding_amd", "csrc")
 OUT = "/tmp/ablate"
 os.makedirs(OUT, exist_ok=True)
-VARIANTS = {0: "baseline", 16: "setprio(1) in MFMA phase", 32: "static prio for odd-octet WGs", 0.5: "baseline again",
-            1: "no global loads", 2: "no LDS stores", 7: "no loads/stores/barrier"}
+VARIANTS = {0: "baseline (2 LDS buffers, 2 WG/CU)", 100: "1 LDS buffer, 3 WG/CU", 0.5: "baseline again", 100.5: "1 buffer again"}
 shapes = [(64, 250, 16, 256, 256), (64, 1001, 64, 64, 64)]
 dev = torch.device("cuda:0")
 for n, label in VARIANTS.items():
     so = f"{OUT}/conv_{n}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-fno-fast-math", "-ffp-contract=off", f"-DTAG_ABLATE={int(n)}", os.path.join(CSRC, "conv.hip"),
+                           "-fno-fast-math", "-ffp-contract=off", f"-DTAG_ABLATE={int(n) % 100}", f"-DTAG_NBUF={1 if n >= 100 else 2}", os.path.join(CSRC, "conv.hip"),
                            os.path.join(CSRC, "tag_lib.hip"), "-o", so], stderr=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     P, I = ctypes.c_void_p, ctypes.c_int

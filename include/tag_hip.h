@@ -161,13 +161,18 @@ int tag_relu_backward(const float* y, const float* dy, float* dx, long n, void* 
  *   gates(B,T,2,4H) saved r,z,n and (W_hn h + b_hn) for the backward pass (nullable in inference)
  * backward: dy (B,T,2H) -> dgi (B,T,2,3H), dgh (B,T,2,3H); hprev (B,T,2,H) is also written
  * (h_{t-1} per direction) so that dW_hh = dgh^T hprev is a plain GEMM for the caller.
- * scratch: (2,B,H) floats for the running dh.
+ * When (H/16)*ceil(B/16)*2 <= 256 the whole sequence is ONE persistent launch (weights in registers,
+ * state exchanged between workgroups through tagged 8-byte granules); otherwise one launch per step.
  * ------------------------------------------------------------------------------------------- */
+/* scratch for both directions of either pass: transposed weights + the exchange granules of the persistent
+ * kernels + an error word (last 256 bytes; non-zero after a sync = a bounded spin timed out) */
+size_t tag_gru_ws_bytes(int B, int T, int H);
 int tag_gru_forward(const float* gi, const float* w_hh, const float* b_hh, float* y, float* gates,
-                    float* ws /* 2*3*H*H floats */, int B, int T, int H, void* stream);
+                    void* ws /* tag_gru_ws_bytes */, int B, int T, int H, void* stream);
 int tag_gru_backward(const float* dy, const float* y, const float* gates, const float* w_hh,
-                     float* dgi, float* dgh, float* hprev, float* scratch, int B, int T, int H,
-                     void* stream);
+                     float* dgi, float* dgh, float* hprev, void* scratch /* tag_gru_ws_bytes */, int B, int T,
+                     int H, void* stream);
+int tag_gru_timed_out(const void* host_copy_of_err_word);
 
 /* ---------------------------------------------------------------------------------------------
  * T1 + T2: nn.Embedding gather + mean over valid tokens

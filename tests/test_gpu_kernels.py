@@ -240,7 +240,8 @@ def test_gemm(ops, dev, M, N, K, ta, tb):
 
 
 # ------------------------------------------------------------------------------------------- GRU
-@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (18, 6, 512, 256)])
+@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (18, 6, 512, 256), (64, 40, 512, 256), (5, 33, 128, 128),
+                                     (130, 5, 64, 256)])
 def test_gru_forward_backward(ops, dev, B, T, I, H):
     from texttoaudiogrounding_amd.lib import call, ptr
     g = torch.Generator().manual_seed(B)
@@ -269,13 +270,16 @@ def test_gru_forward_backward(ops, dev, B, T, I, H):
     gi = ops.gemm(xdv, w_ih, M, 6 * H, I, transB=True, bias=b_ih)
     y = torch.empty(B, T, 2 * H, device=dev)
     gates = torch.empty(B, T, 2, 4 * H, device=dev)
-    ws = torch.empty(6 * H * H, device=dev)
+    from texttoaudiogrounding_amd.lib import query
+    nws = query("tag_gru_ws_bytes", B, T, H)
+    ws = torch.zeros(nws // 4 + 1, device=dev)
     call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(ws), B, T, H)
     assert relerr(y, y_ref) < 5e-6
+    assert int(ws.view(torch.int32)[(nws - 256) // 4].item()) == 0        # no bounded spin timed out
     dgi = torch.empty(B, T, 2, 3 * H, device=dev)
     dgh = torch.empty(B, T, 2, 3 * H, device=dev)
     hprev = torch.empty(B, T, 2, H, device=dev)
-    scratch = torch.empty(2, B, H, device=dev)
+    scratch = torch.zeros(nws // 4 + 1, device=dev)
     call("tag_gru_backward", ptr(dy.to(dev)), ptr(y), ptr(gates), ptr(w_hh), ptr(dgi), ptr(dgh), ptr(hprev),
          ptr(scratch), B, T, H)
     dx = ops.gemm(dgi, w_ih, M, I, 6 * H)

@@ -180,46 +180,296 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
     hprev_out[cell * H + j] = hp;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent variants: ONE launch for the whole sequence.  Workgroup (unit tile, batch tile, direction) keeps its
+// slice of the recurrent weights in registers for all T steps; the 16 workgroups that share a batch tile exchange
+// the new hidden state (backward: the new gate gradients) through 8-byte {epoch tag, value} granules written and
+// read with agent-scope relaxed atomics (sc1: coherent across the 8 XCD L2s; the data IS the flag, so there is no
+// fence and no separate counter -- cdna_hip_programming.md Guideline 16, form R2).  Two parities: a workgroup can
+// be at most one step ahead of the slowest member of its group.  Every spin is bounded; a timeout raises *err.
+// Residency: the grid is (H/16) x ceil(B/16) x 2 <= 256 one-per-CU workgroups (checked by the launcher).
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+#define TAG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 21;
+
+__device__ __forceinline__ u64 granule(unsigned epoch, float v) {
+    return ((u64)epoch << 32) | (u64)__float_as_uint(v);
+}
+
+template <int HT>
+__global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __restrict__ gi,
+                                                                 const float* __restrict__ wt,
+                                                                 const float* __restrict__ b_hh, float* __restrict__ y,
+                                                                 float* __restrict__ gates, u64* hx, unsigned* err,
+                                                                 int B, int T) {
+    constexpr int H = HT, NI = HT / 16, KQ = HT / 4;
+    __shared__ float red[4][3][256];
+    const int dir = blockIdx.z, j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int Bpad = gridDim.y * 16;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    float wv[3][NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            wv[g][i] = wt[(((size_t)dir * 3 + g) * H + wid * KQ + lk + 4 * i) * H + j0 + li];
+    const int e = threadIdx.x, row = e >> 4, col = e & 15;
+    const int b = b0 + row, j = j0 + col;
+    const bool valid = b < B;
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = b_hh[(size_t)dir * 3 * H + g * H + j];
+    u64* hxd = hx + (size_t)dir * 2 * Bpad * H;
+    const bool arow = b0 + li < B;                    // rows >= B are never produced: do not wait for them
+    float hprev = 0.0f;
+    bool dead = false;
+    const int t0 = dir == 0 ? 0 : T - 1;
+    float gir = 0, giz = 0, gin = 0;
+    if (valid) {
+        const float* gx = gi + (((size_t)b * T + t0) * 2 + dir) * 3 * H;
+        gir = gx[j]; giz = gx[H + j]; gin = gx[2 * H + j];
+    }
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (s > 0) {
+            const u64* src = hxd + (size_t)((s - 1) & 1) * Bpad * H + (size_t)(b0 + li) * H + wid * KQ + lk;
+            float av[NI];
+            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;   // after one timeout never wait again (bounded total time)
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    u64 g = arow ? __hip_atomic_load(src + 4 * i, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
+                    av[i] = __uint_as_float((unsigned)g);
+                    ok &= (unsigned)(g >> 32) == (unsigned)s;
+                }
+                if (__all(ok)) break;
+                if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1u); dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wv[g][i], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid][g][(lk * 4 + r) * 16 + li] = acc[g][r];
+        __syncthreads();
+        // prefetch the next step's input projections while the gates are computed
+        float ngir = 0, ngiz = 0, ngin = 0;
+        if (valid && s + 1 < T) {
+            const int tn = dir == 0 ? t + 1 : t - 1;
+            const float* gx = gi + (((size_t)b * T + tn) * 2 + dir) * 3 * H;
+            ngir = gx[j]; ngiz = gx[H + j]; ngin = gx[2 * H + j];
+        }
+        if (valid) {
+            float gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gh[g] = red[0][g][e] + red[1][g][e] + red[2][g][e] + red[3][g][e] + bias[g];
+            const float r = sigmoidf_(gir + gh[0]);
+            const float z = sigmoidf_(giz + gh[1]);
+            const float n = tanhf(gin + r * gh[2]);
+            const float h = (1.0f - z) * n + z * hprev;
+            hprev = h;
+            __hip_atomic_store(hxd + (size_t)(s & 1) * Bpad * H + (size_t)b * H + j, granule((unsigned)(s + 1), h),
+                               TAG_RLX_AGENT);
+            y[(((size_t)b * T + t) * 2 + dir) * H + j] = h;
+            if (gates) {
+                float* gs = gates + (((size_t)b * T + t) * 2 + dir) * 4 * H;
+                gs[j] = r; gs[H + j] = z; gs[2 * H + j] = n; gs[3 * H + j] = gh[2];
+            }
+        }
+        gir = ngir; giz = ngiz; gin = ngin;
+        __syncthreads();                               // red[] is rewritten by the next step
+    }
+}
+
+template <int HT>
+__global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ gates,
+                                                                 const float* __restrict__ w_hh, float* __restrict__ dgi,
+                                                                 float* __restrict__ dgh, float* __restrict__ hprev_out,
+                                                                 u64* gxch, unsigned* err, int B, int T) {
+    constexpr int H = HT, K = 3 * HT, KQ = K / 4, NI = K / 16;
+    __shared__ float red[4][256];
+    const int dir = blockIdx.z, j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int Bpad = gridDim.y * 16;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    float wv[NI];                                     // W_hh[dir][k][j0 + li], k = wid*KQ + lk + 4 i
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wv[i] = w_hh[((size_t)dir * K + wid * KQ + lk + 4 * i) * H + j0 + li];
+    const int e = threadIdx.x, row = e >> 4, col = e & 15;
+    const int b = b0 + row, j = j0 + col;
+    const bool valid = b < B;
+    const bool arow = b0 + li < B;
+    u64* gxd = gxch + (size_t)dir * 2 * Bpad * K;
+    float dh_carry = 0.0f, z_next = 0.0f;            // dh and z of the step processed just before (own element)
+    bool dead = false;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;       // reverse of the forward order
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        // this step's saved quantities do not depend on the exchange: load them first
+        float g_r = 0, g_z = 0, g_n = 0, g_hn = 0, dyv = 0, hp = 0;
+        const size_t cell = ((size_t)(valid ? b : 0) * T + t) * 2 + dir;
+        if (valid) {
+            const float* gs = gates + cell * 4 * H;
+            g_r = gs[j]; g_z = gs[H + j]; g_n = gs[2 * H + j]; g_hn = gs[3 * H + j];
+            dyv = dy[cell * H + j];
+            const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+            hp = has_prev ? y[(((size_t)b * T + tp) * 2 + dir) * H + j] : 0.0f;
+        }
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (s > 0) {
+            const u64* src = gxd + (size_t)((s - 1) & 1) * Bpad * K + (size_t)(b0 + li) * K + wid * KQ + lk;
+            float av[NI];
+            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;   // after one timeout never wait again (bounded total time)
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    u64 g = arow ? __hip_atomic_load(src + 4 * i, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
+                    av[i] = __uint_as_float((unsigned)g);
+                    ok &= (unsigned)(g >> 32) == (unsigned)s;
+                }
+                if (__all(ok)) break;
+                if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1u); dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wv[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], wv[i + 1], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wid][(lk * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (valid) {
+            float dh = dyv;
+            if (s > 0) dh += red[0][e] + red[1][e] + red[2][e] + red[3][e] + dh_carry * z_next;
+            dh_carry = dh;
+            z_next = g_z;
+            const float dn = dh * (1.0f - g_z);
+            const float dz = dh * (hp - g_n);
+            const float dn_pre = dn * (1.0f - g_n * g_n);
+            const float dz_pre = dz * g_z * (1.0f - g_z);
+            const float dr_pre = dn_pre * g_hn * g_r * (1.0f - g_r);
+            const float dnr = dn_pre * g_r;
+            u64* dst = gxd + (size_t)(s & 1) * Bpad * K + (size_t)b * K;
+            __hip_atomic_store(dst + j, granule((unsigned)(s + 1), dr_pre), TAG_RLX_AGENT);
+            __hip_atomic_store(dst + H + j, granule((unsigned)(s + 1), dz_pre), TAG_RLX_AGENT);
+            __hip_atomic_store(dst + 2 * H + j, granule((unsigned)(s + 1), dnr), TAG_RLX_AGENT);
+            float* gi_o = dgi + cell * 3 * H;
+            float* gh_o = dgh + cell * 3 * H;
+            gi_o[j] = dr_pre; gi_o[H + j] = dz_pre; gi_o[2 * H + j] = dn_pre;
+            gh_o[j] = dr_pre; gh_o[H + j] = dz_pre; gh_o[2 * H + j] = dnr;
+            hprev_out[cell * H + j] = hp;
+        }
+        __syncthreads();
+    }
+}
+
+bool gru_persistent_ok(int B, int H) { return (H == 256 || H == 128) && (H / 16) * ((B + 15) / 16) * 2 <= 256; }
+
 }  // namespace
 
-// ws: 2*3*H*H floats (transposed recurrent weights)
+// ws layout: [ 6*H*H floats: transposed recurrent weights | exchange granules 2*2*Bpad*3H u64 | err word ]
+static size_t gru_ws_layout(int B, int H, size_t* off_x, size_t* off_err) {
+    const size_t Bpad = (size_t)((B + 15) / 16) * 16;
+    size_t o = (size_t)6 * H * H * sizeof(float);
+    o = (o + 255) / 256 * 256;
+    *off_x = o;
+    o += (size_t)2 * 2 * Bpad * 3 * H * sizeof(u64);
+    *off_err = o;
+    return o + 256;
+}
+extern "C" size_t tag_gru_ws_bytes(int B, int T, int H) {
+    (void)T;
+    size_t a, b;
+    return gru_ws_layout(B, H, &a, &b);
+}
+
 extern "C" int tag_gru_forward(const float* gi, const float* w_hh, const float* b_hh, float* y, float* gates,
-                               float* ws, int B, int T, int H, void* stream) {
+                               void* ws, int B, int T, int H, void* stream) {
     TAG_CHECK_ARG(gi && w_hh && b_hh && y && ws && B > 0 && T > 0);
     TAG_CHECK_ARG(H % 16 == 0 && H >= 16);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(gru_transpose_whh_kernel, dim3(cdiv((long)6 * H * H, 256)), dim3(256), 0, st, w_hh, ws, H);
+    size_t off_x, off_err;
+    gru_ws_layout(B, H, &off_x, &off_err);
+    float* wt = static_cast<float*>(ws);
+    hipLaunchKernelGGL(gru_transpose_whh_kernel, dim3(cdiv((long)6 * H * H, 256)), dim3(256), 0, st, w_hh, wt, H);
     TAG_LAUNCH_CHECK();
     const dim3 grid(H / 16, (B + 15) / 16, 2);
+    if (gru_persistent_ok(B, H) && T > 1) {
+        u64* hx = reinterpret_cast<u64*>(static_cast<char*>(ws) + off_x);
+        unsigned* err = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + off_err);
+        // tags must not match any epoch (1..T) before the first write; also clears the error word
+        if (hipMemsetAsync(hx, 0, off_err + 256 - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
+        if (H == 256)
+            hipLaunchKernelGGL(gru_fwd_persistent_kernel<256>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, hx, err, B, T);
+        else
+            hipLaunchKernelGGL(gru_fwd_persistent_kernel<128>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, hx, err, B, T);
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     for (int s = 0; s < T; ++s) {
         if (H == 256)
-            hipLaunchKernelGGL(gru_fwd_step_kernel<256>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+            hipLaunchKernelGGL(gru_fwd_step_kernel<256>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, B, T, H, s);
         else if (H == 128)
-            hipLaunchKernelGGL(gru_fwd_step_kernel<128>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+            hipLaunchKernelGGL(gru_fwd_step_kernel<128>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, B, T, H, s);
         else
-            hipLaunchKernelGGL(gru_fwd_step_kernel<0>, grid, dim3(256), 0, st, gi, ws, b_hh, y, gates, B, T, H, s);
+            hipLaunchKernelGGL(gru_fwd_step_kernel<0>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, B, T, H, s);
     }
     TAG_LAUNCH_CHECK();
     return 0;
 }
 
+// scratch: tag_gru_ws_bytes(B,T,H) bytes (the per-step fallback uses the first 2*B*H floats as the running dh)
 extern "C" int tag_gru_backward(const float* dy, const float* y, const float* gates, const float* w_hh, float* dgi,
-                                float* dgh, float* hprev, float* scratch, int B, int T, int H, void* stream) {
+                                float* dgh, float* hprev, void* scratch, int B, int T, int H, void* stream) {
     TAG_CHECK_ARG(dy && y && gates && w_hh && dgi && dgh && hprev && scratch && B > 0 && T > 0);
     TAG_CHECK_ARG(H % 16 == 0 && (3 * H) % 32 == 0);
     hipStream_t st = as_stream(stream);
     const dim3 grid(H / 16, (B + 15) / 16, 2);
+    if (gru_persistent_ok(B, H) && T > 1) {
+        size_t off_x, off_err;
+        gru_ws_layout(B, H, &off_x, &off_err);
+        u64* gx = reinterpret_cast<u64*>(static_cast<char*>(scratch) + off_x);
+        unsigned* err = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + off_err);
+        if (hipMemsetAsync(gx, 0, off_err + 256 - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
+        if (H == 256)
+            hipLaunchKernelGGL(gru_bwd_persistent_kernel<256>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev, gx, err, B, T);
+        else
+            hipLaunchKernelGGL(gru_bwd_persistent_kernel<128>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev, gx, err, B, T);
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
+    float* dhbuf = static_cast<float*>(scratch);
     for (int s = 0; s < T; ++s) {
         if (H == 256)
             hipLaunchKernelGGL(gru_bwd_step_kernel<256>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
-                               scratch, B, T, H, s);
+                               dhbuf, B, T, H, s);
         else if (H == 128)
             hipLaunchKernelGGL(gru_bwd_step_kernel<128>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
-                               scratch, B, T, H, s);
+                               dhbuf, B, T, H, s);
         else
             hipLaunchKernelGGL(gru_bwd_step_kernel<0>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev,
-                               scratch, B, T, H, s);
+                               dhbuf, B, T, H, s);
     }
     TAG_LAUNCH_CHECK();
     return 0;
+}
+
+// last persistent GRU launch that used this scratch timed out waiting for a neighbour (host-side check after a sync)
+extern "C" int tag_gru_timed_out(const void* ws_host_copy_of_err_word) {
+    return ws_host_copy_of_err_word && *static_cast<const unsigned*>(ws_host_copy_of_err_word) != 0;
 }

@@ -49,6 +49,8 @@ _SIGS = {
     "tag_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
     "tag_colsum": (c_int, [P, c_int, c_long, c_int, P, P, P]),
     "tag_relu_backward": (c_int, [P, P, P, c_long, P]),
+    "tag_gru_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "tag_gru_timed_out": (c_int, [P]),
     "tag_gru_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_gru_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_embed_mean_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -314,7 +314,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         y = _empty(Bx, Tp, 2 * Hh, like=x)
         need_grad = any(ctx.needs_input_grad[2:])
         gates = _empty(Bx, Tp, 2, 4 * Hh, like=x) if need_grad else None
-        wsr = _empty(6 * Hh * Hh, like=x)
+        wsr = _ws(query("tag_gru_ws_bytes", Bx, Tp, Hh), x)
         call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(wsr), Bx, Tp, Hh)
         if need_grad:
             ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gates=gates, y=y, w_ih=w_ih,
@@ -336,7 +336,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         dgi = _empty(B, T, 2, 3 * Hh, like=y)
         dgh = _empty(B, T, 2, 3 * Hh, like=y)
         hprev = _empty(B, T, 2, Hh, like=y)
-        scratch = _empty(2, B, Hh, like=y)
+        scratch = _ws(query("tag_gru_ws_bytes", B, T, Hh), y)
         call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
              ptr(scratch), B, T, Hh)
         fc = sv["fc"]

@@ -124,6 +124,15 @@ int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, 
                         const float* invstd, const float* gamma, const float* da, float* dy,
                         float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
                         void* stream);
+/* CrnnEncoder (cdur_block, models/audio_encoder.py:16-22,39-49): BatchNorm in FRONT of the conv, applied to
+ * v = pre(x), pre_op 0 identity | 1 leaky_relu(x, 0.1).  du = gradient wrt bn(v) (from the conv dgrad);
+ * dx = gradient wrt x; dgamma/dbeta the BN parameter gradients.  gamma nullable (= 1). */
+int tag_bn_act_backward(const float* x, int pre_op, const float* mean, const float* invstd,
+                        const float* gamma, const float* du, float* dx, float* dgamma, float* dbeta,
+                        long rows, int C, int bn_train, void* ws, void* stream);
+/* backward of dropout(LPPool2d(4,(ph,pw))(leaky_relu(y,0.1))) (forward: tag_bnact_pool_forward act=2 pool=1) */
+int tag_lppool_leaky_backward(const float* y, const float* dout, float* dy, int B, int H, int W, int C,
+                              int ph, int pw, float drop_p, uint64_t seed, void* stream);
 /* materialise the dropout keep-mask (0/1 bytes) the kernels above use, for parity tests */
 int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream);
 

@@ -80,6 +80,15 @@ def test_reference_shaped_interface():
                                     match.DotProduct(l2norm=False, scale=True, text_level="seq"), 512)
     assert not hasattr(m2, "audio_proj") and sum(p.numel() for p in m2.parameters()) == 8_804_800
     assert isinstance(losses.FrameBceLoss(), torch.nn.Module) and align.DotProduct(l2norm=False, scaled=False)
+    # the strong eg_config verbatim (cdur_w2vmean.yaml:45-70): CrnnEncoder(256) + EmbeddingAgg(256) + ExpNegL2
+    crnn = audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(sample_rate=32000, embed_dim=256),
+                                      text_encoder.EmbeddingAgg(embed_dim=256, vocab_size=5221, aggregation="mean"),
+                                      match.ExpNegL2(text_level="seq"), shared_dim=256)
+    assert sum(p.numel() for p in crnn.parameters()) == 2_015_074 and not hasattr(crnn, "audio_proj")   # appendix B
+    ck = set(crnn.audio_encoder.state_dict())
+    assert {"cnn.0.0.weight", "cnn.0.1.weight", "cnn.6.1.weight", "gru.weight_hh_l0_reverse"} <= ck
+    assert tuple(crnn.audio_encoder.cnn[0][0].weight.shape) == (1,)                    # 1-channel BatchNorm
+    assert (crnn.audio_encoder.hop_length, crnn.audio_encoder.embed_dim) == (640, 256)
     # length arithmetic (row A5) is host-side integer work
     length = torch.div(torch.div(torch.as_tensor([320000, 160000, 1]), 320, rounding_mode="floor") + 1, 4,
                        rounding_mode="floor")

@@ -198,6 +198,46 @@ def test_bnrelu_backward(ops, dev):
     assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
 
 
+@pytest.mark.parametrize("pre", [0, 1])
+def test_bn_act_backward(ops, dev, pre):
+    """BatchNorm in front of a conv (CrnnEncoder cdur_block): u = bn(pre(x)), pre = identity | leaky_relu(0.1)."""
+    B, C, H, W = 2, 32, 7, 6
+    g = torch.Generator().manual_seed(11 + pre)
+    x = torch.randn(B, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    xh = nhwc(x).to(dev)
+    st = ops.bn_stats(xh.view(-1, C), gamma.to(dev), beta.to(dev), None, None, True, pre_op=pre)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    v = F.leaky_relu(xd, 0.1) if pre else xd
+    u = F.batch_norm(v, None, None, gd, bd, True, 0.1, 1e-5)
+    du = torch.randn(u.shape, generator=g)
+    u.backward(du.double())
+    dx, dg, db = ops.bn_act_backward(xh, pre, st, gamma.to(dev), nhwc(du).to(dev))
+    assert relerr(nchw(dx), xd.grad) < 5e-6
+    assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
+
+
+@pytest.mark.parametrize("H,W,C,ph,pw,p", [(9, 16, 32, 2, 4, 0.0), (6, 4, 128, 1, 4, 0.3), (5, 8, 128, 2, 4, 0.0)])
+def test_lppool_leaky_fwd_bwd(ops, dev, H, W, C, ph, pw, p):
+    B = 2
+    g = torch.Generator().manual_seed(H + C)
+    y = torch.randn(B, C, H, W, generator=g)
+    yh = nhwc(y).to(dev)
+    seed = 777
+    out = ops.bnact_pool(yh, None, ph, pw, act=2, pool=1, drop_p=p, seed=seed)
+    yd = y.double().requires_grad_(True)
+    ref = F.lp_pool2d(F.leaky_relu(yd, 0.1), 4.0, (ph, pw))
+    if p > 0:
+        mask = ops.dropout_mask(seed, (B, H // ph, W // pw, C), p, dev).cpu().permute(0, 3, 1, 2)
+        ref = ref * mask.double() / (1 - p)
+    assert relerr(nchw(out), ref) < 2e-6
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout.double())
+    dy = ops.lppool_leaky_backward(yh, nhwc(dout).to(dev), ph, pw, p, seed)
+    assert relerr(nchw(dy), yd.grad) < 5e-6
+
+
 def test_bn_param_grad_and_mean_w(ops, dev):
     g = torch.Generator().manual_seed(4)
     rows, C = 1001, 64

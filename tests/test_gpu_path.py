@@ -198,3 +198,70 @@ def test_full_length_frame_sim_and_segments(dev):
                 near += int(np.any(np.abs(ofs[b].numpy().astype(np.float64) - t) < 1e-4))
                 assert np.any(np.abs(ofs[b].numpy().astype(np.float64) - t) < 1e-4), "segment mismatch away from a threshold"
     print(f"segments: {near} (clip,threshold) pairs differ only because a score sits within 1e-4 of the threshold")
+
+
+# ------------------------------------------------------------------------------------------- CrnnEncoder (row A1')
+def crnn_state(gold):
+    st = O.init_crnn_state(seed=7)
+    g = torch.Generator().manual_seed(8)
+    st["text_encoder.embedding.core.weight"] = (torch.rand(5221, 256, generator=g) * 2 - 1) * 0.9
+    for k in list(st):
+        if k.endswith(".0.weight"):
+            st[k] = 0.5 + torch.rand(st[k].shape, generator=g)
+        if k.endswith(".0.bias"):
+            st[k] = 0.2 * torch.randn(st[k].shape, generator=g)
+    for k in gold.files:
+        if k.startswith("before/"):
+            st[k[len("before/"):]] = torch.from_numpy(gold[k])
+    return st
+
+
+def build_crnn_model(st, dev):
+    """The strong eg_config verbatim: CrnnEncoder(256) + EmbeddingAgg(256, mean) + ExpNegL2 (cdur_w2vmean.yaml)."""
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
+    model = audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(sample_rate=32000, embed_dim=256),
+                                       text_encoder.EmbeddingAgg(5221, 256), match.ExpNegL2(), 256)
+    missing = model.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys and all("melspec_extractor" in k for k in missing.missing_keys)
+    assert not hasattr(model, "audio_proj")
+    return model.to(dev)
+
+
+def test_crnn_golden_eval(dev, golden_dir):
+    gold = np.load(f"{golden_dir}/crnn_expnegl2_eval.npz")
+    model = build_crnn_model(crnn_state(gold), dev).eval()
+    batch = make_batch(640)
+    with torch.no_grad():
+        emb = model.audio_encoder({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"]})
+        out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"],
+                     "text": batch["text"], "text_len": batch["text_len"], "specaug": False})
+    assert np.array_equal(out["length"].numpy(), gold["length"])
+    e_err = (emb["embedding"].cpu() - torch.from_numpy(gold["embedding_f64_as_f32"])).abs().max().item()
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    print(f"crnn eval: embedding err {e_err:.2e}, frame_sim err {fs_err:.2e}")
+    assert e_err < 1e-4 and fs_err < 1e-4
+
+
+def test_crnn_golden_train_step_grads(dev, golden_dir):
+    gold = np.load(f"{golden_dir}/crnn_expnegl2_train.npz")
+    model = build_crnn_model(crnn_state(gold), dev).train()
+    model.audio_encoder.dropout_p = 0.0
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    runner = StrongRunner(model, device=str(dev))
+    batch = make_batch(640)
+    loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    assert abs(loss.item() - float(gold["loss_f64"])) < 2e-5
+    worst = 0.0
+    for name, p in model.named_parameters():
+        want = gold[f"grad_f64/{name}"]
+        got = sample_grad(p.grad)
+        err = np.abs(got[2:] - want[2:]).max() / (want[1] + 1e-30)
+        nerr = abs(got[0] - want[0]) / (want[0] + 1e-30)
+        print(f"  {name:45s} hip {err:.2e} (norm {nerr:.2e})")
+        worst = max(worst, err, nerr)
+        assert err < 5e-2 and nerr < 5e-2, (name, err, nerr)      # train-mode BN at B=2: up to 1.6e-1 in fp32 (SURVEY 7)
+    sd = model.state_dict()
+    for k in gold.files:
+        if k.startswith("after/"):
+            assert np.allclose(sd[k[len("after/"):]].cpu().numpy(), gold[k], rtol=2e-4, atol=1e-5), k
+    print(f"crnn train: loss {loss.item():.7f} (ref f64 {float(gold['loss_f64']):.7f}); worst grad err {worst:.2e}")

@@ -433,6 +433,121 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFn fn, c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// CrnnEncoder (cdur_block = BN -> conv -> LeakyReLU, LPPool; models/audio_encoder.py:16-22,39-49):
+// BatchNorm sits in FRONT of the conv, on v = pre(x) with pre = identity (after a pool) or leaky_relu(.,0.1)
+// (after a conv).  Backward of u = bn(v): dv = g*invstd*(du - mean(du) - vhat*mean(du*vhat)), dx = dv*pre'(x).
+// ------------------------------------------------------------------------------------------
+struct BnActBwdFn {
+    const float* x; const float* mean; const float* invstd; const float* du; int C; int pre;
+    float4 m, is;
+    __device__ void prep(int c) {
+        m = *reinterpret_cast<const float4*>(mean + c);
+        is = *reinterpret_cast<const float4*>(invstd + c);
+    }
+    __device__ void operator()(long r, int c, float4& a, float4& b) const {
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+        if (pre == 1) { v.x = leaky01(v.x); v.y = leaky01(v.y); v.z = leaky01(v.z); v.w = leaky01(v.w); }
+        a = *reinterpret_cast<const float4*>(du + (size_t)r * C + c);
+        b = make_float4(a.x * (v.x - m.x) * is.x, a.y * (v.y - m.y) * is.y, a.z * (v.z - m.z) * is.z,
+                        a.w * (v.w - m.w) * is.w);
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActBwdFn fn, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dgamma,
+                                                               const float* __restrict__ dbeta, int bn_train,
+                                                               long rows, float* __restrict__ dx) {
+    const int C = fn.C, tpr = C >> 2, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    const float invN = 1.0f / (float)rows;
+    fn.prep(c);
+    float k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        k0[j] = (gamma ? gamma[c + j] : 1.0f) * fn.invstd[c + j];
+        k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
+        k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
+    }
+    const float mv[4] = {fn.m.x, fn.m.y, fn.m.z, fn.m.w}, iv[4] = {fn.is.x, fn.is.y, fn.is.z, fn.is.w};
+    for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
+        const float4 xv = *reinterpret_cast<const float4*>(fn.x + (size_t)r * C + c);
+        const float4 g = *reinterpret_cast<const float4*>(fn.du + (size_t)r * C + c);
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = fn.pre == 1 ? leaky01(xx[j]) : xx[j];
+            const float dv = k0[j] * (gg[j] - k1[j] - (v - mv[j]) * iv[j] * k2[j]);
+            o[j] = (fn.pre == 1 && xx[j] <= 0.0f) ? 0.1f * dv : dv;
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// backward of  out = dropout( LPPool4( leaky_relu(y, 0.1) ) ):  dy = dout * a^3 / out^3 * leaky'(y)
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void lppool_leaky_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                               float* __restrict__ dy, int B, int H, int W, int C,
+                                                               float drop_p, uint64_t seed) {
+    const int Ho = H / PH, Wo = W / PW, C4 = C >> 2, rpi = 256 / C4;
+    const int c = (threadIdx.x % C4) << 2, rsub = threadIdx.x / C4;
+    const int Hs = (H + PH - 1) / PH, Ws = (W + PW - 1) / PW;
+    const long slots = (long)B * Hs * Ws;
+    const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
+        const int ws = (int)(r % Ws); long q = r / Ws;
+        const int hs = (int)(q % Hs); const int b = (int)(q / Hs);
+        const bool full = hs < Ho && ws < Wo;
+        float a[PH][PW][4], yv[PH][PW][4], sum[4] = {0, 0, 0, 0};
+        bool ex[PH][PW];
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                const int h = hs * PH + dh, w = ws * PW + dw;
+                ex[dh][dw] = h < H && w < W;
+                float4 v = make_float4(0, 0, 0, 0);
+                if (ex[dh][dw]) v = *reinterpret_cast<const float4*>(y + (((size_t)b * H + h) * W + w) * C + c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    yv[dh][dw][j] = vv[j];
+                    a[dh][dw][j] = leaky01(vv[j]);
+                    const float a2 = a[dh][dw][j] * a[dh][dw][j];
+                    sum[j] += a2 * a2;
+                }
+            }
+        float k[4] = {0, 0, 0, 0};
+        if (full) {
+            const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + oi);
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (drop_p > 0.0f) g[j] = tag_keep(seed, (uint64_t)oi + j, drop_p) ? g[j] * keep_scale : 0.0f;
+                const float out = sqrtf(sqrtf(sum[j]));
+                k[j] = out > 0.0f ? g[j] / (out * out * out) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                if (!ex[dh][dw]) continue;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float aa = a[dh][dw][j];
+                    const float da = k[j] * aa * aa * aa;
+                    o[j] = yv[dh][dw][j] > 0.0f ? da : 0.1f * da;
+                }
+                const int h = hs * PH + dh, w = ws * PW + dw;
+                *reinterpret_cast<float4*>(dy + (((size_t)b * H + h) * W + w) * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+    }
+}
+
 __global__ void dropout_mask_kernel(uint64_t seed, long n, float p, uint8_t* mask) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         mask[i] = tag_keep(seed, (uint64_t)i, p) ? 1 : 0;
@@ -647,6 +762,40 @@ extern "C" int tag_mean_w_backward(const float* dout, long rows, int W, int C, f
     TAG_CHECK_ARG(dout && dx && rows > 0 && W > 0 && C > 0);
     hipLaunchKernelGGL(mean_w_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), dout, rows, W,
                        C, drop_p, seed, dx);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_bn_act_backward(const float* x, int pre_op, const float* mean, const float* invstd,
+                                   const float* gamma, const float* du, float* dx, float* dgamma, float* dbeta,
+                                   long rows, int C, int bn_train, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && mean && invstd && du && dx && dgamma && dbeta && ws && vec_ok(C) && (pre_op == 0 || pre_op == 1));
+    double* partials = static_cast<double*>(ws);
+    const int nblk = red_blocks(rows, C);
+    BnActBwdFn fn{x, mean, invstd, du, C, pre_op};
+    hipLaunchKernelGGL(reduce2_kernel<BnActBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double), as_stream(stream),
+                       fn, rows, C, partials);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn, gamma,
+                       dgamma, dbeta, bn_train, rows, dx);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_lppool_leaky_backward(const float* y, const float* dout, float* dy, int B, int H, int W, int C,
+                                         int ph, int pw, float drop_p, uint64_t seed, void* stream) {
+    TAG_CHECK_ARG(y && dout && dy && vec_ok(C) && H / ph > 0 && W / pw > 0);
+    const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C);
+    bool launched = false;
+    DISPATCH_POOL(2, 4, hipLaunchKernelGGL((lppool_leaky_bwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, dout, dy, B, H, W, C, drop_p, seed))
+    DISPATCH_POOL(1, 4, hipLaunchKernelGGL((lppool_leaky_bwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, dout, dy, B, H, W, C, drop_p, seed))
+    DISPATCH_POOL(2, 2, hipLaunchKernelGGL((lppool_leaky_bwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
+                                           y, dout, dy, B, H, W, C, drop_p, seed))
+    TAG_CHECK_ARG(launched);
     TAG_LAUNCH_CHECK();
     return 0;
 }

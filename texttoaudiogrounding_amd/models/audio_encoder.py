@@ -55,6 +55,74 @@ class _MelFrontendBuffers(nn.Module):
         self.mel_scale.register_buffer("fb", fb)
 
 
+def htk_mel_filterbank(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """(n_freqs, n_mels) HTK-scale triangles without normalisation = torchaudio's MelScale defaults, which is what
+    the reference's CrnnEncoder frontend uses (models/audio_encoder.py:29-35)."""
+    hz2mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+
+
+def cdur_block(cin, cout, kernel_size=3, padding=1):
+    """Parameter container with the reference's layout (models/audio_encoder.py:16-22): [BN, conv, LeakyReLU]."""
+    return nn.Sequential(nn.BatchNorm2d(cin), nn.Conv2d(cin, cout, kernel_size=kernel_size, padding=padding, bias=False),
+                         nn.LeakyReLU(inplace=True, negative_slope=0.1))
+
+
+class CrnnEncoder(nn.Module):
+    """The encoder the strong eg_config instantiates (models/audio_encoder.py:25-86): same constructor, attributes,
+    forward contract and state-dict keys (cnn.{0,2,3,5,6}.{0,1}.*, gru.*); arithmetic in libtag_hip.so."""
+
+    def __init__(self, sample_rate, embed_dim):
+        super().__init__()
+        from .utils import init_weights
+        self.downsample_ratio = 4
+        self.n_fft = 2048
+        self.win_length = 40 * sample_rate // 1000
+        self.hop_length = 20 * sample_rate // 1000
+        self.time_resolution = 4 * self.hop_length / sample_rate
+        if self.win_length > self.n_fft:
+            raise ValueError("win_length must not exceed n_fft=2048")
+        self.melspec_extractor = _MelFrontendBuffers(
+            torch.hann_window(self.win_length),
+            htk_mel_filterbank(self.n_fft // 2 + 1, 0.0, float(sample_rate // 2), 64, sample_rate))
+        self.embed_dim = embed_dim
+        self.cnn = nn.Sequential(cdur_block(1, 32), nn.LPPool2d(4, (2, 4)), cdur_block(32, 128), cdur_block(128, 128),
+                                 nn.LPPool2d(4, (2, 4)), cdur_block(128, 128), cdur_block(128, 128),
+                                 nn.LPPool2d(4, (1, 4)), nn.Dropout(0.3))
+        self.gru = nn.GRU(128, embed_dim // 2, bidirectional=True, batch_first=True)
+        self.dropout_p = 0.3
+        self.apply(init_weights)
+
+    window = property(lambda self: self.melspec_extractor.spectrogram.window)
+    mel_fb = property(lambda self: self.melspec_extractor.mel_scale.fb)
+
+    def _bn_modules(self):
+        return [self.cnn[i][0] for i in (0, 2, 3, 5, 6)]
+
+    def _flat_params(self):
+        ps = []
+        for i in (0, 2, 3, 5, 6):
+            ps += [self.cnn[i][0].weight, self.cnn[i][0].bias, self.cnn[i][1].weight]
+        for sfx in ("", "_reverse"):
+            ps += [getattr(self.gru, f"weight_ih_l0{sfx}"), getattr(self.gru, f"weight_hh_l0{sfx}"),
+                   getattr(self.gru, f"bias_ih_l0{sfx}"), getattr(self.gru, f"bias_hh_l0{sfx}")]
+        return ps
+
+    def forward(self, input_dict: Dict):
+        if self.training:
+            for m in self._bn_modules():
+                m.num_batches_tracked += 1
+        x = ops.CrnnFunction.apply(input_dict["waveform"], self, *self._flat_params())
+        length = torch.div(torch.as_tensor(input_dict["waveform_len"]), self.hop_length, rounding_mode="floor") + 1
+        length = torch.div(length, self.downsample_ratio, rounding_mode="floor")
+        return {"embedding": x, "length": length}
+
+
 class Cnn8Rnn(nn.Module):
     def __init__(self, sample_rate: int, freeze_cnn: bool = False, freeze_bn: bool = False,
                  pretrained: "str | None" = None, output_fn=sys.stdout.write):

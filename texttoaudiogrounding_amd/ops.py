@@ -251,6 +251,53 @@ def align_dot(audio, text, l2norm=False, scaled=False):
 
 
 # ------------------------------------------------------------------------------------------------
+# bidirectional GRU (row A4): input projection GEMM + persistent recurrence, and its backward
+# ------------------------------------------------------------------------------------------------
+
+def gru_bidir_forward(x2d, rnn, B, T, need_grad):
+    """x2d (B*T, I); rnn = [w_ih, w_hh, b_ih, b_hh] x (forward, reverse).  Returns y (B,T,2H) and the saved state."""
+    Hh = rnn[1].shape[1]
+    M = B * T
+    w_ih = torch.cat([rnn[0], rnn[4]], 0)            # (2*3H, I)
+    b_ih = torch.cat([rnn[2], rnn[6]], 0)
+    w_hh = torch.stack([rnn[1], rnn[5]], 0).contiguous()   # (2,3H,H)
+    b_hh = torch.stack([rnn[3], rnn[7]], 0).contiguous()
+    gi = gemm(x2d, w_ih, M, 6 * Hh, x2d.shape[1], transB=True, bias=b_ih)
+    y = _empty(B, T, 2 * Hh, like=x2d)
+    gates = _empty(B, T, 2, 4 * Hh, like=x2d) if need_grad else None
+    wsr = _ws(query("tag_gru_ws_bytes", B, T, Hh), x2d)
+    call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(wsr), B, T, Hh)
+    return y, (dict(gates=gates, y=y, w_ih=w_ih, w_hh=w_hh, Hh=Hh) if need_grad else None)
+
+
+def gru_bidir_backward(dy, x2d, sv):
+    """Returns (dx2d, [8 parameter gradients in nn.GRU order])."""
+    Hh, y, gates = sv["Hh"], sv["y"], sv["gates"]
+    B, T, _ = y.shape
+    M = B * T
+    dgi = _empty(B, T, 2, 3 * Hh, like=y)
+    dgh = _empty(B, T, 2, 3 * Hh, like=y)
+    hprev = _empty(B, T, 2, Hh, like=y)
+    scratch = _ws(query("tag_gru_ws_bytes", B, T, Hh), y)
+    call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
+         ptr(scratch), B, T, Hh)
+    I = x2d.shape[1]
+    dw_ih = gemm(dgi, x2d, 6 * Hh, I, M, transA=True, lda=6 * Hh)                  # (6H, I)
+    db_ih = colsum(dgi, M, 6 * Hh)
+    db_hh = colsum(dgh, M, 6 * Hh)
+    g = [None] * 8
+    for d in range(2):
+        a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
+        hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
+        g[4 * d + 0] = dw_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
+        g[4 * d + 1] = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh)
+        g[4 * d + 2] = db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
+        g[4 * d + 3] = db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
+    dx = gemm(dgi, sv["w_ih"], M, I, 6 * Hh)
+    return dx, g
+
+
+# ------------------------------------------------------------------------------------------------
 # Cnn8Rnn: the whole audio encoder as one autograd node (rows F1-F3, A1-A4 forward + backward)
 # ------------------------------------------------------------------------------------------------
 
@@ -305,20 +352,11 @@ class Cnn8RnnFunction(torch.autograd.Function):
         call("tag_mean_w_forward", ptr(x), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(xm))
         M = Bx * Tp
         fc = gemm(xm, fc_w, M, fc_w.shape[0], C, transB=True, bias=fc_b, act=1)
-        Hh = rnn[1].shape[1]
-        w_ih = torch.cat([rnn[0], rnn[4]], 0)            # (2*3H, 512)
-        b_ih = torch.cat([rnn[2], rnn[6]], 0)
-        w_hh = torch.stack([rnn[1], rnn[5]], 0).contiguous()   # (2,3H,H)
-        b_hh = torch.stack([rnn[3], rnn[7]], 0).contiguous()
-        gi = gemm(fc, w_ih, M, 6 * Hh, fc.shape[1], transB=True, bias=b_ih)
-        y = _empty(Bx, Tp, 2 * Hh, like=x)
         need_grad = any(ctx.needs_input_grad[2:])
-        gates = _empty(Bx, Tp, 2, 4 * Hh, like=x) if need_grad else None
-        wsr = _ws(query("tag_gru_ws_bytes", Bx, Tp, Hh), x)
-        call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(wsr), Bx, Tp, Hh)
+        y, gsave = gru_bidir_forward(fc, rnn, Bx, Tp, need_grad)
         if need_grad:
-            ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gates=gates, y=y, w_ih=w_ih,
-                             w_hh=w_hh, p=p, drop=drop, seeds=seeds, Hh=Hh)
+            ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gsave=gsave, p=p, drop=drop,
+                             seeds=seeds)
         mod._last_dropout = dict(p=drop, seeds=seeds)
         return y
 
@@ -326,33 +364,13 @@ class Cnn8RnnFunction(torch.autograd.Function):
     def backward(ctx, dy):
         sv = ctx.saved
         ctx.saved = None
-        p, Hh, y, gates = sv["p"], sv["Hh"], sv["y"], sv["gates"]
+        p = sv["p"]
         drop, seeds = sv["drop"], sv["seeds"]
         dy = _chk(dy, "grad_output")
-        B, T, _ = y.shape
-        M = B * T
         grads: List[Optional[torch.Tensor]] = [None] * len(p)
-        # ---- GRU ----
-        dgi = _empty(B, T, 2, 3 * Hh, like=y)
-        dgh = _empty(B, T, 2, 3 * Hh, like=y)
-        hprev = _empty(B, T, 2, Hh, like=y)
-        scratch = _ws(query("tag_gru_ws_bytes", B, T, Hh), y)
-        call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
-             ptr(scratch), B, T, Hh)
         fc = sv["fc"]
-        dw_ih = gemm(dgi, fc, 6 * Hh, fc.shape[1], M, transA=True, lda=6 * Hh)          # (6H, 512)
-        db_ih = colsum(dgi, M, 6 * Hh)
-        db_hh = colsum(dgh, M, 6 * Hh)
-        for d in range(2):
-            a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
-            hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
-            dw_hh = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh)
-            grads[28 + 4 * d + 0] = dw_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
-            grads[28 + 4 * d + 1] = dw_hh
-            grads[28 + 4 * d + 2] = db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
-            grads[28 + 4 * d + 3] = db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
-        dfc = gemm(dgi, sv["w_ih"], M, fc.shape[1], 6 * Hh)                              # (M, 512)
-        del dgi, dgh, hprev
+        dfc, grads[28:36] = gru_bidir_backward(dy, fc, sv["gsave"])
+        M = fc.shape[0]
         dfc = relu_backward(fc, dfc)
         xm = sv["xm"]
         fc_w = p[26]
@@ -387,6 +405,127 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 grads[0], grads[1] = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0)
             del dy1, da1
             sv["acts"][i] = None
+        return (None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# CrnnEncoder (row A1'): cdur_block = BN -> conv3x3 -> LeakyReLU(0.1), LPPool2d(4), Dropout(0.3), BiGRU(128)
+# ------------------------------------------------------------------------------------------------
+
+def bn_act_backward(x, pre_op, st: BNStat, gamma, du):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dg, db = _empty(C, like=x), _empty(C, like=x)
+    ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), x)
+    call("tag_bn_act_backward", ptr(x), pre_op, ptr(st.mean), ptr(st.invstd), ptr(gamma), ptr(du), ptr(dx), ptr(dg),
+         ptr(db), rows, C, int(st.train), ptr(ws))
+    return dx, dg, db
+
+
+def lppool_leaky_backward(y, dout, ph, pw, drop_p=0.0, seed=0):
+    B, H, W, C = y.shape
+    dy = torch.empty_like(y)
+    call("tag_lppool_leaky_backward", ptr(y), ptr(dout), ptr(dy), B, H, W, C, ph, pw, float(drop_p), seed)
+    return dy
+
+
+CRNN_POOLS = [(2, 4), (2, 4), (1, 4)]
+
+
+class CrnnFunction(torch.autograd.Function):
+    """params order: 5 x (bn.w, bn.b, conv.w) for cnn.{0,2,3,5,6}, then gru (w_ih, w_hh, b_ih, b_hh) x (fwd, reverse).
+
+    Layer plan (channels-last): lm -> [bn0 scalar | conv 1->32] -> LP(2,4) -> [bn | conv 32->128] -> [leaky,bn | conv]
+    -> LP(2,4) -> [bn | conv] -> [leaky,bn | conv] -> LP(1,4)+dropout -> GRU.  Every BatchNorm is folded into the
+    A-operand load of the conv that follows it (prologue 3 after a pool, prologue 2 after a conv)."""
+
+    @staticmethod
+    def forward(ctx, waveform, mod, *params):
+        wave = _chk(waveform, "waveform")
+        training = mod.training
+        p = [_chk(t.detach(), "parameter") for t in params]
+        blk = [p[3 * i: 3 * i + 3] for i in range(5)]
+        rnn = p[15:23]
+        bns = mod._bn_modules()
+        drop = mod.dropout_p if training else 0.0
+        seed = new_seed() if training and drop > 0 else 0
+
+        lm = logmel(wave, mod.n_fft, mod.win_length, mod.hop_length, mod.window, mod.mel_fb)   # (B,F,64)
+        B, Fr, NM = lm.shape
+
+        def stats(x2d, i, pre_op):
+            return bn_stats(x2d, blk[i][0], blk[i][1], bns[i].running_mean, bns[i].running_var, training, bns[i].eps,
+                            bns[i].momentum, pre_op)
+
+        st = [None] * 5
+        st[0] = stats(lm.view(-1, 1), 0, 0)                       # BatchNorm2d(1): one scalar affine
+        cs, ct = st[0].scale.expand(NM).contiguous(), st[0].shift.expand(NM).contiguous()
+        y0 = conv3x3_c1(lm, blk[0][2], cs, ct)                     # (B,F,64,32)
+        p1 = bnact_pool(y0, None, 2, 4, act=2, pool=1)            # leaky + LPPool -> (B,F/2,16,32)
+        st[1] = stats(p1.view(-1, p1.shape[3]), 1, 0)
+        wf1, wd1 = pack_conv_weight(blk[1][2])
+        y1 = conv3x3(p1, wf1, 128, prologue=3, scale=st[1].scale, shift=st[1].shift)
+        st[2] = stats(y1.view(-1, 128), 2, 1)
+        wf2, wd2 = pack_conv_weight(blk[2][2])
+        y2 = conv3x3(y1, wf2, 128, prologue=2, scale=st[2].scale, shift=st[2].shift)
+        p2 = bnact_pool(y2, None, 2, 4, act=2, pool=1)            # (B,F/4,4,128)
+        st[3] = stats(p2.view(-1, 128), 3, 0)
+        wf3, wd3 = pack_conv_weight(blk[3][2])
+        y3 = conv3x3(p2, wf3, 128, prologue=3, scale=st[3].scale, shift=st[3].shift)
+        st[4] = stats(y3.view(-1, 128), 4, 1)
+        wf4, wd4 = pack_conv_weight(blk[4][2])
+        y4 = conv3x3(y3, wf4, 128, prologue=2, scale=st[4].scale, shift=st[4].shift)
+        p3 = bnact_pool(y4, None, 1, 4, act=2, pool=1, drop_p=drop, seed=seed)     # (B,T',1,128)
+        Bx, Tp = p3.shape[0], p3.shape[1]
+        x2d = p3.view(Bx * Tp, -1)
+        need_grad = any(ctx.needs_input_grad[2:])
+        y, gsave = gru_bidir_forward(x2d, rnn, Bx, Tp, need_grad)
+        if need_grad:
+            ctx.saved = dict(lm=lm, cs=cs, ct=ct, st=st, y=[y0, y1, y2, y3, y4], pool=[p1, p2, p3], wd=[wd1, wd2, wd3, wd4],
+                             x2d=x2d, gsave=gsave, p=p, drop=drop, seed=seed)
+        mod._last_dropout = dict(p=drop, seeds=[seed])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv = ctx.saved
+        ctx.saved = None
+        p, st, ys, pools, wd = sv["p"], sv["st"], sv["y"], sv["pool"], sv["wd"]
+        blk = [p[3 * i: 3 * i + 3] for i in range(5)]
+        grads: List[Optional[torch.Tensor]] = [None] * len(p)
+        dy = _chk(dy, "grad_output")
+        dx2d, grads[15:23] = gru_bidir_backward(dy, sv["x2d"], sv["gsave"])
+        y0, y1, y2, y3, y4 = ys
+        p1, p2, p3 = pools
+        # block 6 (cnn.6): conv(bn(leaky(y3)))
+        dy4 = lppool_leaky_backward(y4, dx2d.view(p3.shape), 1, 4, sv["drop"], sv["seed"])
+        grads[14] = conv3x3_wgrad(y3, dy4, prologue=2, scale=st[4].scale, shift=st[4].shift)
+        du = conv3x3(dy4, wd[3], 128)
+        dy3, grads[12], grads[13] = bn_act_backward(y3, 1, st[4], blk[4][0], du)
+        # block 5 (cnn.5): conv(bn(p2))
+        grads[11] = conv3x3_wgrad(p2, dy3, prologue=3, scale=st[3].scale, shift=st[3].shift)
+        du = conv3x3(dy3, wd[2], 128)
+        dp2, grads[9], grads[10] = bn_act_backward(p2, 0, st[3], blk[3][0], du)
+        dy2 = lppool_leaky_backward(y2, dp2, 2, 4)
+        # block 3 (cnn.3)
+        grads[8] = conv3x3_wgrad(y1, dy2, prologue=2, scale=st[2].scale, shift=st[2].shift)
+        du = conv3x3(dy2, wd[1], 128)
+        dy1, grads[6], grads[7] = bn_act_backward(y1, 1, st[2], blk[2][0], du)
+        # block 2 (cnn.2)
+        grads[5] = conv3x3_wgrad(p1, dy1, prologue=3, scale=st[1].scale, shift=st[1].shift)
+        du = conv3x3(dy1, wd[0], p1.shape[3])
+        dp1, grads[3], grads[4] = bn_act_backward(p1, 0, st[1], blk[1][0], du)
+        dy0 = lppool_leaky_backward(y0, dp1, 2, 4)
+        # block 0 (cnn.0): conv(bn_scalar(lm))
+        lm = sv["lm"]
+        grads[2] = conv3x3_c1_wgrad(lm, dy0, sv["cs"], sv["ct"])
+        du0 = conv3x3_c1_dgrad(dy0, blk[0][2])                                     # (B,F,64) grad wrt bn output
+        B, Fr, NM = lm.shape
+        st0c = BNStat()
+        st0c.mean, st0c.invstd = st[0].mean.expand(NM).contiguous(), st[0].invstd.expand(NM).contiguous()
+        dgc, dbc = bn_param_grad(lm.view(B * Fr, NM), du0.view(B * Fr, NM), st0c)
+        grads[0], grads[1] = dgc.sum().view(1), dbc.sum().view(1)                   # 64 columns share one channel
         return (None, None, *grads)
 
 

@@ -209,6 +209,12 @@ int tag_match_backward(const float* audio, const float* text, const float* sim, 
 int tag_align_dot_forward(const float* audio, const float* text, float* out, int l2norm, int scaled,
                           int B, int T, int N, int D, float* ws /* (B*T + B*N)*D floats when l2norm */,
                           void* stream);
+/* backward pieces of M3 (composed by the host with two tag_gemm calls: daudio = ds x text, dtext = ds^T x audio):
+ * ds (B*T, B*N) = dout * p(1-p) * [1/sqrt(D)] through the clamp; F.normalize forward / backward on rows */
+int tag_align_dot_dscore(const float* out, const float* dout, float* ds, int scaled, int B, int T, int N,
+                         int D, void* stream);
+int tag_l2norm_rows_forward(const float* x, float* y, long rows, int D, void* stream);
+int tag_l2norm_rows_backward(const float* x, const float* du, float* dx, long rows, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * R1 + L1: FrameBceLoss losses.py:12-24 after the label alignment of run_strong.py:107-118.

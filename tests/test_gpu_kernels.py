@@ -407,6 +407,22 @@ def test_align_dot(ops, dev, golden_dir):
             assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("l2norm,scaled", [(False, False), (True, True), (False, True)])
+def test_align_dot_backward(dev, l2norm, scaled):
+    from texttoaudiogrounding_amd.models import align
+    g = torch.Generator().manual_seed(31)
+    audio, text = torch.randn(3, 21, 64, generator=g), torch.randn(3, 5, 64, generator=g)
+    a, t = audio.to(dev).requires_grad_(True), text.to(dev).requires_grad_(True)
+    out = align.DotProduct(l2norm=l2norm, scaled=scaled)(a, t)
+    ad, td = audio.double().requires_grad_(True), text.double().requires_grad_(True)
+    ref = O.align_dot_product(ad, td, l2norm, scaled)
+    assert relerr(out, ref) < 2e-6
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout.double())
+    out.backward(dout.to(dev))
+    assert relerr(a.grad, ad.grad) < 2e-5 and relerr(t.grad, td.grad) < 2e-5
+
+
 def test_segments_bit_exact_vs_reference_golden(ops, dev, golden_dir):
     """P1: integer segment indices, bit-exact against what the reference's own eval_util produced."""
     gold = np.load(f"{golden_dir}/postproc.npz")

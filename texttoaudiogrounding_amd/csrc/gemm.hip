@@ -300,6 +300,41 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int d = lane; d < D; d += 64) y[row * D + d] = x[row * D + d] * inv;
 }
 
+// dx = (du - u (u.du)) / max(||x||, 1e-12), u = x / max(||x||, 1e-12)   (backward of F.normalize)
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                              float* __restrict__ dx, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float ss = 0.0f, xd = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = x[row * D + d];
+        ss = fmaf(v, v, ss);
+        xd = fmaf(v, du[row * D + d], xd);
+    }
+    ss = wave_sum(ss);
+    xd = wave_sum(xd);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const float ud = xd * inv;                        // u . du
+    for (int d = lane; d < D; d += 64) dx[row * D + d] = (du[row * D + d] - x[row * D + d] * inv * ud) * inv;
+}
+
+// ds[(b,t)][(b2,n)] = dout[b][b2][t][n] * p (1-p) * alpha * [p >= 1e-7], p = out (sigmoid, clamp(1e-7, 1))
+__global__ __launch_bounds__(256) void align_dscore_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                           float* __restrict__ ds, float alpha, int B, int T, int N) {
+    const long total = (long)B * B * T * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % N);
+        long r = i / N;
+        const int t = (int)(r % T); r /= T;
+        const int b2 = (int)(r % B);
+        const int b = (int)(r / B);
+        const float p = out[i];
+        const float g = p > 1e-7f ? dout[i] * p * (1.0f - p) * alpha : 0.0f;
+        ds[((size_t)b * T + t) * ((size_t)B * N) + (size_t)b2 * N + n] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t tag_gemm_ws_bytes(int M, int N, int K) {
@@ -360,6 +395,30 @@ extern "C" int tag_align_dot_forward(const float* audio, const float* text, floa
     Epilogue ep{nullptr, 2, 0, scaled ? 1.0f / sqrtf((float)D) : 1.0f, 1, T, N, B};
     // score[(b,t)][(b2,n)] = audio (B*T, D) x text^T (stored (B*N, D): k-contiguous -> transB)
     launch_gemm(a, D, 0, t, D, 1, out, 0, B * T, B * N, D, ep, nullptr, as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_l2norm_rows_forward(const float* x, float* y, long rows, int D, void* stream) {
+    TAG_CHECK_ARG(x && y && rows > 0 && D > 0);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, y, rows, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_l2norm_rows_backward(const float* x, const float* du, float* dx, long rows, int D, void* stream) {
+    TAG_CHECK_ARG(x && du && dx && rows > 0 && D > 0);
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, du, dx, rows, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_align_dot_dscore(const float* out, const float* dout, float* ds, int scaled, int B, int T, int N,
+                                    int D, void* stream) {
+    TAG_CHECK_ARG(out && dout && ds && B > 0 && T > 0 && N > 0 && D > 0);
+    const long total = (long)B * B * T * N;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(align_dscore_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), out, dout, ds,
+                       scaled ? 1.0f / sqrtf((float)D) : 1.0f, B, T, N);
     TAG_LAUNCH_CHECK();
     return 0;
 }

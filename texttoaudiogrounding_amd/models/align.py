@@ -16,6 +16,4 @@ class DotProduct(nn.Module):
         t_bs, _, t_dim = text.size()
         assert a_bs == t_bs
         assert a_dim == t_dim
-        if audio.requires_grad or text.requires_grad:
-            raise NotImplementedError("align.DotProduct backward is not on the round-1 hot path")
-        return ops.align_dot(audio, text, self.l2norm, self.scaled)
+        return ops.AlignDotFunction.apply(audio, text, self.l2norm, self.scaled)

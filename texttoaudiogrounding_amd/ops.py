@@ -635,6 +635,43 @@ class FrameBceFunction(torch.autograd.Function):
         return ds, None, None, None
 
 
+class AlignDotFunction(torch.autograd.Function):
+    """align.DotProduct (models/align.py:14-31) with gradients: (B,T,D),(B,N,D) -> (B,B,T,N)."""
+
+    @staticmethod
+    def forward(ctx, audio, text, l2norm, scaled):
+        a, t = _chk(audio, "audio"), _chk(text, "text")
+        B, T, D = a.shape
+        N = t.shape[1]
+        an, tn = a, t
+        if l2norm:
+            an, tn = torch.empty_like(a), torch.empty_like(t)
+            call("tag_l2norm_rows_forward", ptr(a), ptr(an), B * T, D)
+            call("tag_l2norm_rows_forward", ptr(t), ptr(tn), B * N, D)
+        out = _empty(B, B, T, N, like=a)
+        call("tag_align_dot_forward", ptr(an), ptr(tn), ptr(out), 0, int(scaled), B, T, N, D, None)
+        ctx.save_for_backward(a, t, an, tn, out)
+        ctx.cfg = (bool(l2norm), bool(scaled))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, t, an, tn, out = ctx.saved_tensors
+        l2norm, scaled = ctx.cfg
+        B, T, D = a.shape
+        N = t.shape[1]
+        ds = _empty(B * T, B * N, like=a)
+        call("tag_align_dot_dscore", ptr(out), ptr(_chk(dout, "grad")), ptr(ds), int(scaled), B, T, N, D)
+        da = gemm(ds, tn.view(B * N, D), B * T, D, B * N)                       # (B*T, D)
+        dt = gemm(ds, an.view(B * T, D), B * N, D, B * T, transA=True, lda=B * N)   # (B*N, D)
+        if l2norm:
+            da2, dt2 = torch.empty_like(da), torch.empty_like(dt)
+            call("tag_l2norm_rows_backward", ptr(a), ptr(da), ptr(da2), B * T, D)
+            call("tag_l2norm_rows_backward", ptr(t), ptr(dt), ptr(dt2), B * N, D)
+            da, dt = da2, dt2
+        return da.view(B, T, D), dt.view(B, N, D), None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser step on flat buffers (O1)
 # ------------------------------------------------------------------------------------------------

@@ -291,25 +291,42 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_wgrad_kern
             rt[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
+    // per-thread constants of the staging pattern; per chunk only the (wave-uniform) pixel origin changes
+    int pixi[LOADS];
+    unsigned cab[LOADS], cbb[LOADS];          // byte offsets of the channel quads (clamped: masked columns are never stored)
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int c4 = (idx % (TC / 4)) * 4;
+        pixi[i] = idx / (TC / 4);
+        cab[i] = (unsigned)((ci0 + c4 < Cin ? ci0 + c4 : 0) * 4);
+        cbb[i] = (unsigned)((co0 + c4 < Cout ? co0 + c4 : 0) * 4);
+    }
+    const unsigned rW = (65536u + (unsigned)W - 1u) / (unsigned)W;   // t / W == (t * rW) >> 16 for t < 64 + W <= 2^7
+    const int tapoff = dyy * W + dxx;
     auto load_chunk = [&](int it) {
-        const long kb = kbeg + (long)it * BK;
+        const unsigned kb = (unsigned)(kbeg + (long)it * BK);         // M < 2^31 (checked by the launcher)
+        const unsigned hw0 = kb % (unsigned)iHW;                     // wave-uniform: scalar ALU
+        const int h0 = (int)(hw0 / (unsigned)W), w0 = (int)(hw0 - (unsigned)h0 * (unsigned)W);
         amask = bmask = 0;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
-            const int idx = tid + 256 * i;
-            const int pix = idx / (TC / 4), c4 = (idx % (TC / 4)) * 4;
-            long m = kb + pix;
-            const bool in_range = m < kend;
-            m = in_range ? m : kend - 1;
-            const unsigned hw = (unsigned)m % (unsigned)iHW;     // M < 2^31 (checked by the launcher)
-            const int hh = (int)(hw / (unsigned)W) + dyy, ww = (int)(hw % (unsigned)W) + dxx;
-            const unsigned aok = (unsigned)in_range & (unsigned)((unsigned)hh < (unsigned)H) & (unsigned)((unsigned)ww < (unsigned)W);
+            unsigned m = kb + (unsigned)pixi[i];
+            const bool in_range = (long)m < kend;
+            m = in_range ? m : (unsigned)(kend - 1);
+            const int t = w0 + pixi[i];                               // < W + 32
+            const int dh = W >= 32 ? (t >= W ? 1 : 0) : (int)(((unsigned)t * rW) >> 16);
+            int hh = h0 + dh;
+            hh = hh >= H ? hh - H : hh;                               // a chunk may run into the next image
+            hh += dyy;
+            const int ww = t - dh * W + dxx;
+            const unsigned aok = (unsigned)in_range & (unsigned)((unsigned)hh < (unsigned)H) &
+                                 (unsigned)((unsigned)ww < (unsigned)W);
             amask |= aok << i;
             bmask |= (unsigned)in_range << i;
-            const long moff = (long)(dyy * W + dxx) * (long)aok;
-            const int ca = ci0 + c4 < Cin ? ci0 + c4 : 0, cb = co0 + c4 < Cout ? co0 + c4 : 0;
-            ra[i] = ldg4(x + (m + moff) * Cin + ca);
-            rb[i] = ldg4(dy + m * Cout + cb);
+            const unsigned ma = m + (unsigned)(aok ? tapoff : 0);
+            ra[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + (ma * (unsigned)Cin * 4u + cab[i]));
+            rb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(dy) + (m * (unsigned)Cout * 4u + cbb[i]));
         }
     };
     auto store_chunk = [&](int buf) {
@@ -785,7 +802,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     TAG_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
-    TAG_CHECK_ARG(M < (1L << 31));
+    TAG_CHECK_ARG(M < (1L << 31) && M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32) && W <= 64);
     const int TC = wgrad_tile(Cin, Cout);
     const int splits = wgrad_splits(M, Cin, Cout, TC);
     long chunk = (M + splits - 1) / splits;

@@ -12,6 +12,7 @@
 // wgrad             M = Cin, N = Cout, K = pixels (x9 taps), split over the pixel axis; partials
 //   are reduced in a fixed order by a second kernel that also writes the reference's
 //   (Cout,Cin,3,3) layout.
+#include <stdlib.h>
 #include "tag_common.h"
 
 // TAG_ABLATE (tools/ablate_conv.py builds private copies with -DTAG_ABLATE=n; the product is built with 0):
@@ -238,6 +239,205 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
             for (int r = 0; r < 16; ++r) {
                 const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 if (m < M && n < Cout) y[m * Cout + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Halo-tile forward / dgrad kernel (images whose width is 8, 16, 32 or 64 -- every Cnn8Rnn / CrnnEncoder layer).
+// The 128 output pixels of a workgroup form a TH x TW rectangle of ONE image; for each 32-channel chunk the
+// (TH+2) x (TW+2) input patch is staged ONCE in LDS (k-major, BN+ReLU prologue and zero padding applied there)
+// and all 9 taps read it at a shifted base -- 4-7x fewer global loads and LDS stores than the tap-by-tap kernel
+// above, no per-tap masks.  The 32 x BN_ weight chunk of each (chunk, tap) step is double buffered in LDS.
+// ------------------------------------------------------------------------------------------
+#ifndef TAG_HALO_NB
+#define TAG_HALO_NB 1
+#endif
+template <int TW>
+struct HaloGeom {
+    static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
+    static constexpr int LDP = ((PP + 6) / 8) * 8 + 1;            // = 1 (mod 8): conflict-free transposing stores
+    static constexpr int ITEMS = (PP * 8 + 255) / 256;            // float4 per thread per patch chunk
+};
+
+template <int BN_, int PRO, int TW>
+__global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift, float* __restrict__ y,
+                                                              int B, int H, int W, int Cin, int Cout) {
+    using G = HaloGeom<TW>;
+    constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = TAG_HALO_NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ASZ = ((BK * G::LDP + 3) / 4) * 4;
+    float* As = smem;                          // [BK][LDP] patch, k-major
+    float* Bs = smem + ASZ;                    // [NB][BK][BN_]
+    float* Ss = Bs + NB * BK * BN_;            // [2][Cin] producer BN scale / shift
+
+    const int n_tiles = (Cout + BN_ - 1) / BN_;
+    const int row_tiles = (H + G::TH - 1) / G::TH;               // W == TW: one tile column
+    const int m_tiles = B * row_tiles;
+    const int L = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int n0 = (L % n_tiles) * BN_;
+    const int mt = L / n_tiles;
+    const int img = mt / row_tiles, h0 = (mt % row_tiles) * G::TH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
+    const int kl = lane >> 5, ml = lane & 31;
+    if (PRO != 0)
+        for (int c = tid; c < Cin; c += 256) { Ss[c] = in_scale[c]; Ss[Cin + c] = in_shift[c]; }
+
+    // ---- patch staging geometry (loop invariant): item = (patch pixel, channel quad) ----
+    const int q = tid & 7;
+    unsigned poff[G::ITEMS];                   // byte offset of the item in x (clamped to a valid pixel)
+    unsigned pvalid = 0;                       // bit i: the pixel lies inside the image
+    unsigned pexist = 0;                       // bit i: the item exists (idx < PP*8)
+#pragma unroll
+    for (int i = 0; i < G::ITEMS; ++i) {
+        const int idx = tid + 256 * i;
+        const int pp = idx >> 3;
+        const int pr = pp / G::PW, pc = pp - pr * G::PW;
+        const int h = h0 - 1 + pr, w = pc - 1;
+        const bool ex = pp < G::PP;
+        const bool ok = ex && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        pexist |= (unsigned)ex << i;
+        pvalid |= (unsigned)ok << i;
+        const long pix = ok ? ((long)img * H + h) * W + w : (long)img * H * W;
+        poff[i] = (unsigned)((pix * Cin + q * 4) * 4);
+    }
+    unsigned boffb[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+        int n = n0 + n4 * 4;
+        n = n < Cout ? n : 0;
+        boffb[i] = (unsigned)((k * Cout + n) * 4);
+    }
+    // per-lane patch position of the two 32-pixel MFMA row tiles (tap (0,0) = +1,+1 inside the patch)
+    int pbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm0 + i * 32 + ml;
+        pbase[i] = (m / TW + 1) * G::PW + (m % TW) + 1;
+    }
+
+    const int cchunks = Cin / BK;
+    const int total = cchunks * 9;
+    f32x4 ra[G::ITEMS], rb[B_LOADS];
+    auto issue_patch = [&](int cc) {
+        const unsigned coff = (unsigned)(cc * BK * 4);
+#pragma unroll
+        for (int i = 0; i < G::ITEMS; ++i)
+            ra[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + (poff[i] + coff));
+    };
+    auto store_patch = [&](int cc) {
+        f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (PRO != 0) {
+            rs = *reinterpret_cast<const f32x4*>(Ss + cc * BK + q * 4);
+            rt = *reinterpret_cast<const f32x4*>(Ss + Cin + cc * BK + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < G::ITEMS; ++i) {
+            if (!((pexist >> i) & 1u)) continue;
+            const int pp = (tid + 256 * i) >> 3;
+            f32x4 v = apply_prologue(ra[i], PRO, rs, rt);
+            if (!((pvalid >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            As[(q * 4 + 0) * G::LDP + pp] = v.x;
+            As[(q * 4 + 1) * G::LDP + pp] = v.y;
+            As[(q * 4 + 2) * G::LDP + pp] = v.z;
+            As[(q * 4 + 3) * G::LDP + pp] = v.w;
+        }
+    };
+    auto issue_b = [&](int it) {
+        const int cc = it / 9, tap = it - cc * 9;
+        const float* wchunk = wp + ((size_t)tap * Cin + cc * BK) * Cout;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            rb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wchunk) + boffb[i]);
+    };
+    auto store_b = [&](int buf) {
+        float* b = Bs + buf * BK * BN_;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + 256 * i;
+            const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto mma_tap = [&](int buf, int tap) {
+        const int shift = (tap / 3 - 1) * G::PW + (tap % 3 - 1);
+        const float* a0 = As + kl * G::LDP + pbase[0] + shift;
+        const float* a1 = As + kl * G::LDP + pbase[1] + shift;
+        const float* b = Bs + buf * BK * BN_ + kl * BN_ + wn0 + ml;
+        constexpr int PF = 2, NS = BK / 2;
+        float af[PF + 1][2], bf[PF + 1][TN];
+#pragma unroll
+        for (int s0 = 0; s0 < PF; ++s0) {
+            af[s0][0] = a0[(2 * s0) * G::LDP];
+            af[s0][1] = a1[(2 * s0) * G::LDP];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[s0][j] = b[(2 * s0) * BN_ + j * 32];
+        }
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const int cur = ks % (PF + 1), nxt = (ks + PF) % (PF + 1);
+            if (ks + PF < NS) {
+                af[nxt][0] = a0[(2 * (ks + PF)) * G::LDP];
+                af[nxt][1] = a1[(2 * (ks + PF)) * G::LDP];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[(2 * (ks + PF)) * BN_ + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue_patch(0);
+    issue_b(0);
+    __syncthreads();                           // Ss visible
+    store_patch(0);
+    store_b(0);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int cc = it / 9, tap = it - cc * 9;
+        const int buf = NB == 2 ? (it & 1) : 0;
+        const bool more = it + 1 < total;
+        const bool newpatch = tap == 8 && cc + 1 < cchunks;
+        if (more) issue_b(it + 1);
+        if (newpatch) issue_patch(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tap(buf, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NB == 1 || newpatch) __syncthreads();          // all waves are done reading what is overwritten next
+        if (more) store_b(NB == 2 ? (buf ^ 1) : 0);
+        if (newpatch) store_patch(cc + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + ml;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;     // pixel inside the tile
+                const int h = h0 + m / TW, w = m % TW;
+                if (h < H && n < Cout) y[(((size_t)img * H + h) * W + w) * Cout + n] = acc[i][j][r];
             }
         }
 }
@@ -748,6 +948,42 @@ static int launch_fwd(const float* x, const float* wp, int pro, const float* s, 
     return 0;
 }
 
+template <int BN_, int TW>
+static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, int B, int H,
+                        int W, int Cin, int Cout, hipStream_t st) {
+    using G = HaloGeom<TW>;
+    const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
+    const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + TAG_HALO_NB * BK * BN_ + 2 * 512) * sizeof(float);
+#define LAUNCH_PRO(P)                                                                                             \
+    {                                                                                                             \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, P, TW>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, B, H, \
+                           W, Cin, Cout);                                                                         \
+    }
+    switch (pro) {
+        case 0: LAUNCH_PRO(0) break;
+        case 1: LAUNCH_PRO(1) break;
+        case 2: LAUNCH_PRO(2) break;
+        default: LAUNCH_PRO(3) break;
+    }
+#undef LAUNCH_PRO
+}
+
+// TAG_CONV_IMPL (environment, read once): 0 = auto (halo-tile kernel when the width allows), 1 = tap-by-tap kernel
+static int conv_impl() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TAG_CONV_IMPL");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
                                    const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
                                    void* stream) {
@@ -756,10 +992,21 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside the kernel
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
-    if (Cout >= 128)
-        launch_fwd<128>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, as_stream(stream));
-    else
-        launch_fwd<64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, as_stream(stream));
+    hipStream_t st = as_stream(stream);
+    const bool halo = conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64);
+#define HALO_BY_W(BN_)                                                                                   \
+    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);        \
+    else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
+    else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
+    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
+    if (halo) {
+        if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+    } else if (Cout >= 128) {
+        launch_fwd<128>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
+    } else {
+        launch_fwd<64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
+    }
+#undef HALO_BY_W
     TAG_LAUNCH_CHECK();
     return 0;
 }

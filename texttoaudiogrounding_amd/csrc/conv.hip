@@ -605,6 +605,155 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_wgrad_kern
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// All-taps wgrad (image widths 8/16/32/64): a workgroup owns a 64(ci) x 64(co) block of ALL nine taps
+// (9 x 16 accumulator registers per wave) and walks its share of the pixels in chunks of 32 output pixels
+// (a CH x CW rectangle).  Per chunk the (CH+2) x (CW+2) x 64ci input patch and the 32 x 64co dy tile are staged
+// ONCE in LDS (pixel-major = their HBM layout, straight float4 copies; producer BN+ReLU and zero padding applied
+// at the store) and feed 9 x 16 MFMAs per wave: 9x fewer operand loads per FLOP than the per-tap kernel above.
+// ------------------------------------------------------------------------------------------
+template <int TW>
+struct WgGeom {
+    static constexpr int CW = TW >= 32 ? 32 : TW, CH = 32 / CW, PW = CW + 2, PH = CH + 2, PP = PH * PW;
+    static constexpr int XITEMS = (PP * 16 + 255) / 256;          // float4 per thread for the 64-channel patch
+};
+
+template <int TW, int PRO>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ in_scale,
+                                                                       const float* __restrict__ in_shift,
+                                                                       const float* __restrict__ dy,
+                                                                       float* __restrict__ partial, int B, int H, int W,
+                                                                       int Cin, int Cout, int splits, int chunks_per_split) {
+    using G = WgGeom<TW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [PP][64]  input patch, pixel-major
+    float* Bs = smem + G::PP * 64;             // [32][64]  dy chunk
+
+    const int ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 63) / 64;
+    int L = xcd_remap(blockIdx.x, ci_tiles * co_tiles * splits);
+    const int cot = L % co_tiles; L /= co_tiles;
+    const int cit = L % ci_tiles; L /= ci_tiles;
+    const int split = L;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    const int rb_per_img = (H + G::CH - 1) / G::CH, cb_per_row = TW / G::CW;
+    const int chunks_total = B * rb_per_img * cb_per_row;
+    const int cbeg = split * chunks_per_split;
+    int cend = cbeg + chunks_per_split;
+    if (cend > chunks_total) cend = chunks_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wci = (wid >> 1) * 32, wco = (wid & 1) * 32;
+    const int kl = lane >> 5, ml = lane & 31;
+
+    // staging geometry (loop invariant): patch item = (patch pixel, channel quad), dy item = (pixel, channel quad)
+    int xpr[G::XITEMS], xpc[G::XITEMS];
+    unsigned xex = 0;
+    const int c4 = (tid & 15) * 4;
+    const int ca = ci0 + c4 < Cin ? ci0 + c4 : 0, cb = co0 + c4 < Cout ? co0 + c4 : 0;
+#pragma unroll
+    for (int i = 0; i < G::XITEMS; ++i) {
+        const int pp = (tid + 256 * i) >> 4;
+        xex |= (unsigned)(pp < G::PP) << i;
+        xpr[i] = pp / G::PW;
+        xpc[i] = pp - xpr[i] * G::PW;
+    }
+    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRO != 0) { rs = ldg4(in_scale + ca); rt = ldg4(in_shift + ca); }
+
+    f32x4 rx[G::XITEMS], rd[2];
+    unsigned xok = 0, dok = 0;
+    auto issue_chunk = [&](int c) {
+        // wave-uniform chunk origin
+        const int cbk = c % cb_per_row; int r = c / cb_per_row;
+        const int rbk = r % rb_per_img; const int img = r / rb_per_img;
+        const int h0 = rbk * G::CH, w0 = cbk * G::CW;
+        const long ibase = (long)img * H * W;
+        xok = dok = 0;
+#pragma unroll
+        for (int i = 0; i < G::XITEMS; ++i) {
+            const int h = h0 - 1 + xpr[i], w = w0 - 1 + xpc[i];
+            const unsigned ok = ((xex >> i) & 1u) & (unsigned)((unsigned)h < (unsigned)H) & (unsigned)((unsigned)w < (unsigned)W);
+            xok |= ok << i;
+            const long pix = ok ? ibase + (long)h * W + w : ibase;
+            rx[i] = ldg4(x + pix * Cin + ca);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;                     // pixel of the chunk, row-major in the rectangle
+            const int h = h0 + k / G::CW, w = w0 + k % G::CW;
+            const unsigned ok = (unsigned)(h < H);
+            dok |= ok << i;
+            const long pix = ok ? ibase + (long)h * W + w : ibase;
+            rd[i] = ldg4(dy + pix * Cout + cb);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < G::XITEMS; ++i) {
+            if (!((xex >> i) & 1u)) continue;
+            const int pp = (tid + 256 * i) >> 4;
+            f32x4 v = apply_prologue(rx[i], PRO, rs, rt);
+            if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(As + pp * 64 + c4) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;
+            f32x4 v = rd[i];
+            if (!((dok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(Bs + k * 64 + c4) = v;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    if (cbeg < cend) {
+        issue_chunk(cbeg);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = cbeg; c < cend; ++c) {
+        if (c + 1 < cend) issue_chunk(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a = As + kl * 64 + wci + ml;
+        const float* b = Bs + kl * 64 + wco + ml;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            // pixel pair (2ks, 2ks+1) of the chunk rectangle -> patch position of tap (0,0)
+            constexpr int dummy = 0; (void)dummy;
+            const int pr = (2 * ks) / G::CW, pc = (2 * ks) % G::CW;
+            const int pbase = (pr + 1) * G::PW + pc + 1;
+            const float bf = b[(2 * ks) * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int shift = (t / 3 - 1) * G::PW + (t % 3 - 1);
+                const float af = a[(pbase + shift) * 64];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // every wave is done reading the chunk
+        if (c + 1 < cend) store_chunk();
+        __syncthreads();
+    }
+    // partial[split][tap][ci][co]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = partial + ((size_t)split * 9 + t) * Cin * Cout;
+        const int co = co0 + wco + ml;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[t][r];
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum_split partial[split][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cin,
                                                            int Cout, float* __restrict__ dw) {
@@ -912,6 +1061,18 @@ int wgrad_tile(int Cin, int Cout) { return (Cin >= 128 && Cout >= 128) ? 128 : 6
 
 }  // namespace
 
+// TAG_CONV_IMPL (environment, read once): 0 = auto (halo-tile kernel when the width allows), 1 = tap-by-tap kernel
+static int conv_impl() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TAG_CONV_IMPL");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+
+
 extern "C" int tag_pack_conv_weight(const float* w, float* wfwd, float* wdgrad, int Cin, int Cout, void* stream) {
     TAG_CHECK_ARG(w && wfwd && Cin > 0 && Cout > 0);
     const long n = (long)9 * Cin * Cout;
@@ -974,16 +1135,6 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 #undef LAUNCH_PRO
 }
 
-// TAG_CONV_IMPL (environment, read once): 0 = auto (halo-tile kernel when the width allows), 1 = tap-by-tap kernel
-static int conv_impl() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TAG_CONV_IMPL");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
                                    const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
                                    void* stream) {
@@ -1011,10 +1162,53 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     return 0;
 }
 
+static bool wgrad_alltaps_ok(int W) { return conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64); }
+// all-taps kernel: K slices (in chunks of 32 pixels) so that ~1024 workgroups (2 rounds of 2 per CU) are launched
+static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split) {
+    const int cw = W >= 32 ? 32 : W, ch = 32 / cw;
+    const int chunks = B * ((H + ch - 1) / ch) * (W / cw);
+    const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64);
+    int s = 1024 / tiles;
+    if (s > chunks / 8) s = chunks / 8;
+    if (s < 1) s = 1;
+    *chunks_per_split = (chunks + s - 1) / s;
+    return (chunks + *chunks_per_split - 1) / *chunks_per_split;
+}
+
 extern "C" size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
     const long M = (long)B * H * W;
+    if (wgrad_alltaps_ok(W)) {
+        int cps;
+        return (size_t)alltaps_splits(B, H, W, Cin, Cout, &cps) * 9 * Cin * Cout * sizeof(float);
+    }
     const int TC = wgrad_tile(Cin, Cout);
     return (size_t)wgrad_splits(M, Cin, Cout, TC) * 9 * Cin * Cout * sizeof(float);
+}
+
+template <int TW>
+static void launch_wgrad_alltaps(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial,
+                                 int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
+    using G = WgGeom<TW>;
+    const int grid = ((Cin + 63) / 64) * ((Cout + 63) / 64) * splits;
+    const size_t lds = (size_t)(G::PP * 64 + 32 * 64) * sizeof(float);
+#define LAUNCH_PRO(P)                                                                                               \
+    {                                                                                                               \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_alltaps_kernel<TW, P>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((conv3x3_wgrad_alltaps_kernel<TW, P>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
+                           B, H, W, Cin, Cout, splits, cps);                                                        \
+    }
+    switch (pro) {
+        case 0: LAUNCH_PRO(0) break;
+        case 1: LAUNCH_PRO(1) break;
+        case 2: LAUNCH_PRO(2) break;
+        default: LAUNCH_PRO(3) break;
+    }
+#undef LAUNCH_PRO
 }
 
 template <int TC>
@@ -1050,11 +1244,26 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
     TAG_CHECK_ARG(M < (1L << 31) && M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32) && W <= 64);
+    float* partial = static_cast<float*>(ws);
+    hipStream_t st = as_stream(stream);
+    const long nred = (long)9 * Cin * Cout;
+    if (wgrad_alltaps_ok(W)) {
+        int cps;
+        const int sp = alltaps_splits(B, H, W, Cin, Cout, &cps);
+        if (W == 8) launch_wgrad_alltaps<8>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        else if (W == 16) launch_wgrad_alltaps<16>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        else if (W == 32) launch_wgrad_alltaps<32>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        else launch_wgrad_alltaps<64>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        TAG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 256) > 2048 ? 2048 : cdiv(nred, 256)), dim3(256), 0, st,
+                           partial, sp, Cin, Cout, dw);
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     const int TC = wgrad_tile(Cin, Cout);
     const int splits = wgrad_splits(M, Cin, Cout, TC);
     long chunk = (M + splits - 1) / splits;
     chunk = (chunk + BK - 1) / BK * BK;
-    float* partial = static_cast<float*>(ws);
     if (TC == 128)
         launch_wgrad<128>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, splits, chunk,
                           as_stream(stream));

@@ -757,15 +757,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
 // dw[co][ci][tap] = sum_split partial[split][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cin,
                                                            int Cout, float* __restrict__ dw) {
+    // 64 consecutive elements x 4 interleaved split groups per block, folded through LDS in a fixed order
+    __shared__ float sh[4][64];
     const long n = (long)9 * Cin * Cout;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        // i indexes partial layout [tap][ci][co] (coalesced reads)
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {
+        const long i = base + e;                  // indexes partial layout [tap][ci][co] (coalesced reads)
         float s = 0.0f;
-        for (int sp = 0; sp < splits; ++sp) s += partial[(size_t)sp * n + i];
-        const int co = (int)(i % Cout);
-        const long r = i / Cout;
-        const int ci = (int)(r % Cin), tap = (int)(r / Cin);
-        dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+        if (i < n)
+            for (int sp = g; sp < splits; sp += 4) s += partial[(size_t)sp * n + i];
+        sh[g][e] = s;
+        __syncthreads();
+        if (g == 0 && i < n) {
+            const float t = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+            const int co = (int)(i % Cout);
+            const long r = i / Cout;
+            const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+            dw[((size_t)co * Cin + ci) * 9 + tap] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1255,7 +1265,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
         else if (W == 32) launch_wgrad_alltaps<32>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         else launch_wgrad_alltaps<64>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         TAG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 256) > 2048 ? 2048 : cdiv(nred, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 4096 ? 4096 : cdiv(nred, 64)), dim3(256), 0, st,
                            partial, sp, Cin, Cout, dw);
         TAG_LAUNCH_CHECK();
         return 0;
@@ -1272,7 +1282,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
                          as_stream(stream));
     TAG_LAUNCH_CHECK();
     const long n = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64) > 4096 ? 4096 : cdiv(n, 64)), dim3(256), 0,
                        as_stream(stream), partial, splits, Cin, Cout, dw);
     TAG_LAUNCH_CHECK();
     return 0;

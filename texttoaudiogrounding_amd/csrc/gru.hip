@@ -292,32 +292,45 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __
     }
 }
 
+// Backward, K-partitioned: a workgroup multiplies ITS OWN 48 new gate-gradient columns (kept in LDS, never
+// exchanged) with the matching 48 rows of W_hh for ALL H outputs and publishes the 16 x H partial products; the
+// consumer of unit tile u' adds the 16 producers' partials of its 16 units in a fixed order.  Each thread polls
+// exactly 16 granules per step (the per-thread (row, unit) element from 16 producers) instead of every lane
+// sweeping 3H/16 of them.
 template <int HT>
 __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ gates,
                                                                  const float* __restrict__ w_hh, float* __restrict__ dgi,
                                                                  float* __restrict__ dgh, float* __restrict__ hprev_out,
                                                                  u64* gxch, unsigned* err, int B, int T) {
-    constexpr int H = HT, K = 3 * HT, KQ = K / 4, NI = K / 16;
-    __shared__ float red[4][256];
-    const int dir = blockIdx.z, j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    const int Bpad = gridDim.y * 16;
+    constexpr int H = HT, NU = HT / 16;              // NU producers per batch tile
+    constexpr int NT = HT / 64;                      // 16-wide output tiles per wave (4 waves cover H)
+    __shared__ float At[16][48 + 1];                 // this step's dgh tile: [row][gate*16 + unit]
+    const int dir = blockIdx.z, u = blockIdx.x, j0 = u * 16, bt = blockIdx.y, b0 = bt * 16;
+    const int nbt = gridDim.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    float wv[NI];                                     // W_hh[dir][k][j0 + li], k = wid*KQ + lk + 4 i
+    // W_hh rows of the own 48 gate columns, all H outputs: wave w owns outputs [64w, 64w+64)
+    float wv[NT][12];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wv[i] = w_hh[((size_t)dir * K + wid * KQ + lk + 4 * i) * H + j0 + li];
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            const int kk = 4 * ks + lk;              // 0..47 = gate*16 + unit
+            wv[nt][ks] = w_hh[((size_t)dir * 3 * H + (kk >> 4) * H + j0 + (kk & 15)) * H + wid * (H / 4) + nt * 16 + li];
+        }
     const int e = threadIdx.x, row = e >> 4, col = e & 15;
     const int b = b0 + row, j = j0 + col;
     const bool valid = b < B;
-    const bool arow = b0 + li < B;
-    u64* gxd = gxch + (size_t)dir * 2 * Bpad * K;
-    float dh_carry = 0.0f, z_next = 0.0f;            // dh and z of the step processed just before (own element)
+    // exchange layout: [parity][dir][bt][producer][row][H]
+    const size_t slab = (size_t)16 * H;
+    u64* xbase = gxch + ((size_t)dir * nbt + bt) * NU * slab;
+    const size_t parity_stride = (size_t)2 * nbt * NU * slab;
+    float dh_carry = 0.0f, z_next = 0.0f;
     bool dead = false;
     for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;       // reverse of the forward order
+        const int t = dir == 0 ? T - 1 - s : s;
         const int tp = dir == 0 ? t - 1 : t + 1;
-        // this step's saved quantities do not depend on the exchange: load them first
         float g_r = 0, g_z = 0, g_n = 0, g_hn = 0, dyv = 0, hp = 0;
         const size_t cell = ((size_t)(valid ? b : 0) * T + t) * 2 + dir;
         if (valid) {
@@ -327,17 +340,17 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
             const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
             hp = has_prev ? y[(((size_t)b * T + tp) * 2 + dir) * H + j] : 0.0f;
         }
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        float msum = 0.0f;
         if (s > 0) {
-            const u64* src = gxd + (size_t)((s - 1) & 1) * Bpad * K + (size_t)(b0 + li) * K + wid * KQ + lk;
-            float av[NI];
-            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;   // after one timeout never wait again (bounded total time)
+            const u64* src = xbase + (size_t)((s - 1) & 1) * parity_stride + (size_t)row * H + j;
+            float pv[NU];
+            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;
             while (true) {
                 bool ok = true;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    u64 g = arow ? __hip_atomic_load(src + 4 * i, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
-                    av[i] = __uint_as_float((unsigned)g);
+                for (int p = 0; p < NU; ++p) {
+                    u64 g = valid ? __hip_atomic_load(src + (size_t)p * slab, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
+                    pv[p] = __uint_as_float((unsigned)g);
                     ok &= (unsigned)(g >> 32) == (unsigned)s;
                 }
                 if (__all(ok)) break;
@@ -345,17 +358,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
-            for (int i = 0; i < NI; i += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wv[i], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], wv[i + 1], acc1, 0, 0, 0);
-            }
+            for (int p = 0; p < NU; ++p) msum += pv[p];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wid][(lk * 4 + r) * 16 + li] = acc0[r] + acc1[r];
-        __syncthreads();
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
         if (valid) {
             float dh = dyv;
-            if (s > 0) dh += red[0][e] + red[1][e] + red[2][e] + red[3][e] + dh_carry * z_next;
+            if (s > 0) dh += msum + dh_carry * z_next;
             dh_carry = dh;
             z_next = g_z;
             const float dn = dh * (1.0f - g_z);
@@ -364,17 +372,35 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
             const float dz_pre = dz * g_z * (1.0f - g_z);
             const float dr_pre = dn_pre * g_hn * g_r * (1.0f - g_r);
             const float dnr = dn_pre * g_r;
-            u64* dst = gxd + (size_t)(s & 1) * Bpad * K + (size_t)b * K;
-            __hip_atomic_store(dst + j, granule((unsigned)(s + 1), dr_pre), TAG_RLX_AGENT);
-            __hip_atomic_store(dst + H + j, granule((unsigned)(s + 1), dz_pre), TAG_RLX_AGENT);
-            __hip_atomic_store(dst + 2 * H + j, granule((unsigned)(s + 1), dnr), TAG_RLX_AGENT);
+            v0 = dr_pre; v1 = dz_pre; v2 = dnr;
             float* gi_o = dgi + cell * 3 * H;
             float* gh_o = dgh + cell * 3 * H;
             gi_o[j] = dr_pre; gi_o[H + j] = dz_pre; gi_o[2 * H + j] = dn_pre;
             gh_o[j] = dr_pre; gh_o[H + j] = dz_pre; gh_o[2 * H + j] = dnr;
             hprev_out[cell * H + j] = hp;
         }
+        At[row][col] = v0; At[row][16 + col] = v1; At[row][32 + col] = v2;
         __syncthreads();
+        if (s + 1 < T) {                             // the last step's products are never consumed
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const float a = At[li][4 * ks + lk];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[nt][ks], acc[nt], 0, 0, 0);
+            }
+            u64* dst = xbase + (size_t)(s & 1) * parity_stride + (size_t)u * slab;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(dst + (size_t)(lk * 4 + r) * H + wid * (H / 4) + nt * 16 + li,
+                                       granule((unsigned)(s + 1), acc[nt][r]), TAG_RLX_AGENT);
+        }
+        __syncthreads();                             // At is rewritten by the next step
     }
 }
 
@@ -388,7 +414,8 @@ static size_t gru_ws_layout(int B, int H, size_t* off_x, size_t* off_err) {
     size_t o = (size_t)6 * H * H * sizeof(float);
     o = (o + 255) / 256 * 256;
     *off_x = o;
-    o += (size_t)2 * 2 * Bpad * 3 * H * sizeof(u64);
+    // forward: [2 dirs][2 parities][Bpad][H] granules; backward: [2 parities][2 dirs][Bpad/16][H/16][16][H]
+    o += (size_t)2 * 2 * Bpad * H * (size_t)(H / 16) * sizeof(u64);
     *off_err = o;
     return o + 256;
 }

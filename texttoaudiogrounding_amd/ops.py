@@ -305,6 +305,44 @@ def gru_bidir_backward(dy, x2d, sv):
 
 CNN8_POOLS = [(2, 2), (2, 2), (1, 2), (1, 2)]
 
+#: weight-gradient convolutions are off the critical path of backward (only the optimiser needs them): they run on
+#: a second HIP stream so that their workgroups fill the tails / small-grid gaps of the dgrad + BatchNorm chain.
+import os as _os
+WGRAD_SIDE_STREAM = _os.environ.get("TAG_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _SideWgrad:
+    """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them."""
+
+    def __init__(self, device):
+        self.on = WGRAD_SIDE_STREAM
+        self.main = torch.cuda.current_stream(device)
+        self.side = _side_stream(device) if self.on else None
+
+    def wgrad(self, x, dy, prologue=0, scale=None, shift=None):
+        if not self.on:
+            return conv3x3_wgrad(x, dy, prologue, scale, shift)
+        self.side.wait_stream(self.main)                 # x, dy (and the BN constants) are ready
+        with torch.cuda.stream(self.side):
+            dw = conv3x3_wgrad(x, dy, prologue, scale, shift)
+        for t in (x, dy, scale, shift):
+            if t is not None:
+                t.record_stream(self.side)               # the caching allocator must not recycle them early
+        dw.record_stream(self.main)
+        return dw
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
 
 class Cnn8RnnFunction(torch.autograd.Function):
     """params order: bn0.w, bn0.b, 4 x (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b), fc1.w, fc1.b,
@@ -385,6 +423,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         call("tag_mean_w_backward", ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
         # ---- conv blocks, last to first ----
         lm, st0 = sv["lm"], sv["st0"]
+        sw = _SideWgrad(dy.device)
         for i in range(3, -1, -1):
             x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
             c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]
@@ -393,12 +432,12 @@ class Cnn8RnnFunction(torch.autograd.Function):
             dy2, grads[2 + 6 * i + 4], grads[2 + 6 * i + 5] = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0],
                                                                                    seeds[i])
             del dx
-            grads[2 + 6 * i + 3] = conv3x3_wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift)
+            grads[2 + 6 * i + 3] = sw.wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift)
             da1 = conv3x3(dy2, wd2, C)
             del dy2
             dy1, grads[2 + 6 * i + 1], grads[2 + 6 * i + 2] = bnrelu_backward(y1, s1, g1, da1)
             if i > 0:
-                grads[2 + 6 * i] = conv3x3_wgrad(x_in, dy1)
+                grads[2 + 6 * i] = sw.wgrad(x_in, dy1)
                 dx = conv3x3(dy1, wd1, x_in.shape[3])
             else:
                 grads[2] = conv3x3_c1_wgrad(lm, dy1, st0.scale, st0.shift)
@@ -407,6 +446,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 grads[0], grads[1] = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0)
             del dy1, da1
             sv["acts"][i] = None
+        sw.join()
         return (None, None, *grads)
 
 

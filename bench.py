@@ -158,9 +158,9 @@ def main():
         if os.path.exists(tpath):      # PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) are collected offline
             tj = json.load(open(tpath))
             rows = [v for k, v in tj.items() if k.startswith(dom)]
-            n = sum(v["launches_per_2steps"] for v in rows)
+            n = sum(v["launches_in_run"] for v in rows)
             if n:
-                traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_per_2steps"]
+                traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
                                     for v in rows) / n, 3)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC)",

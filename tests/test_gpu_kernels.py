@@ -97,7 +97,12 @@ def test_bn_stats(ops, dev, C, rows):
 
 # ------------------------------------------------------------------------------------------- convolutions
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pro", [(2, 9, 8, 32, 64, 0), (1, 17, 16, 64, 128, 1), (2, 5, 4, 128, 256, 1),
-                                                (1, 7, 8, 64, 64, 3), (1, 6, 8, 32, 32, 2), (3, 11, 8, 256, 512, 0)])
+                                                (1, 7, 8, 64, 64, 3), (1, 6, 8, 32, 32, 2), (3, 11, 8, 256, 512, 0),
+                                                # the BASELINE (10 s clip) layer shapes of Cnn8Rnn, B=2
+                                                (2, 1001, 64, 64, 64, 1), (2, 500, 32, 64, 128, 0),
+                                                (2, 500, 32, 128, 128, 1), (2, 250, 16, 128, 256, 0),
+                                                (2, 250, 16, 256, 256, 1), (2, 250, 8, 256, 512, 0),
+                                                (3, 250, 8, 512, 512, 1)])
 def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -133,9 +138,10 @@ def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert relerr(dw, wd.grad) < tol
 
 
-def test_conv3x3_c1(ops, dev):
+@pytest.mark.parametrize("B,H", [(2, 21), (3, 1001)])
+def test_conv3x3_c1(ops, dev, B, H):
     g = torch.Generator().manual_seed(7)
-    B, H, W, Cout = 2, 21, 64, 64
+    W, Cout = 64, 64
     x = torch.randn(B, H, W, generator=g) * 10 - 30
     cs, ct = torch.rand(W, generator=g) * 0.1 + 0.05, torch.randn(W, generator=g)
     w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
@@ -154,7 +160,10 @@ def test_conv3x3_c1(ops, dev):
 
 # ------------------------------------------------------------------------------------------- bn+relu+pool
 @pytest.mark.parametrize("H,W,C,ph,pw,train,p", [(9, 8, 64, 2, 2, True, 0.0), (7, 8, 128, 1, 2, True, 0.2),
-                                                 (5, 6, 256, 2, 2, False, 0.0), (4, 4, 512, 1, 2, True, 0.0)])
+                                                 (5, 6, 256, 2, 2, False, 0.0), (4, 4, 512, 1, 2, True, 0.0),
+                                                 # BASELINE (10 s clip) shapes of the four Cnn8Rnn blocks
+                                                 (1001, 64, 64, 2, 2, True, 0.2), (500, 32, 128, 2, 2, True, 0.2),
+                                                 (250, 16, 256, 1, 2, True, 0.2), (250, 8, 512, 1, 2, True, 0.2)])
 def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
     B = 2
     g = torch.Generator().manual_seed(H * 100 + C)
@@ -177,8 +186,17 @@ def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
     dout = torch.randn(ref.shape, generator=g)
     ref.backward(dout.double())
     dy, dg, db = ops.bnrelu_pool_backward(yh, st, gamma.to(dev), nhwc(dout).to(dev), ph, pw, p, seed)
-    assert relerr(nchw(dy), yd.grad) < 5e-6
-    assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
+    if H < 100:
+        assert relerr(nchw(dy), yd.grad) < 5e-6
+        assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
+    else:
+        # millions of ReLU / arg-max decisions: the handful whose operands sit within fp32 rounding of a tie may
+        # legitimately fall the other way than in the fp64 reference; everything else must agree to round-off
+        d = (nchw(dy).cpu().double() - yd.grad).abs() / yd.grad.abs().max()
+        nbad = int((d > 5e-6).sum())
+        print(f"bnrelu_pool_backward {B}x{H}x{W}x{C}: {nbad} of {d.numel()} elements beyond 5e-6 (decision ties)")
+        assert nbad <= max(8, d.numel() // 500000)
+        assert relerr(dg, gd.grad) < 1e-4 and relerr(db, bd.grad) < 1e-4
 
 
 def test_bnrelu_backward(ops, dev):

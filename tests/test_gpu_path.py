@@ -265,3 +265,57 @@ def test_crnn_golden_train_step_grads(dev, golden_dir):
         if k.startswith("after/"):
             assert np.allclose(sd[k[len("after/"):]].cpu().numpy(), gold[k], rtol=2e-4, atol=1e-5), k
     print(f"crnn train: loss {loss.item():.7f} (ref f64 {float(gold['loss_f64']):.7f}); worst grad err {worst:.2e}")
+
+
+def test_full_length_train_step_vs_oracle(dev):
+    """BASELINE clip length, B=6, one full training step (train-mode BN, dropout replayed): loss, frame_sim and the
+    gradient of every parameter against the fp64 CPU oracle; then clip_grad_norm_ + Adam against torch.optim.Adam."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=5, logit_gain=120.0)
+    batch = O.synthetic_batch(6, 320000, seed=99, ragged=True)
+    torch.manual_seed(7)
+    model = build_hip_model(st, "dot", dev).train()
+    runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(dev))
+    before = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    info = model.audio_encoder._last_dropout
+    shapes = [(6, 500, 32, 64), (6, 250, 16, 128), (6, 250, 8, 256), (6, 250, 4, 512)]
+    masks = {f"drop{i + 1}": ops.dropout_mask(info["seeds"][i], shp, 0.2, dev).cpu().permute(0, 3, 1, 2).double()
+             for i, shp in enumerate(shapes)}
+    masks["drop5"] = ops.dropout_mask(info["seeds"][4], (6, 250, 512), 0.5, dev).cpu().double()
+    st_o = O.state_to(st, torch.float64, requires_grad=True)
+    bo = dict(batch)
+    bo["waveform"], bo["label"] = batch["waveform"].double(), batch["label"].double()
+    oloss, oout = O.train_step_loss(st_o, bo, "dot", "cnn8rnn", True, None, masks)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 2e-5
+    # the same step by the CPU oracle in fp32: its distance from fp64 is the noise floor of ANY fp32 implementation
+    # (ReLU / max-pool decisions that flip under rounding; 10 M+ decisions per layer at this size)
+    st_f = O.state_to(st, torch.float32, requires_grad=True)
+    m32 = {k: v.float() for k, v in masks.items()}
+    floss, _ = O.train_step_loss(st_f, batch, "dot", "cnn8rnn", True, None, m32)
+    floss.backward()
+    errs, floor = [], []
+    for name, p in model.named_parameters():
+        gref = st_o[name].grad
+        scale = gref.abs().max().item() + 1e-30
+        errs.append((p.grad.cpu().double() - gref).abs().max().item() / scale)
+        floor.append((st_f[name].grad.double() - gref).abs().max().item() / scale)
+        print(f"  {name:55s} hip {errs[-1]:.2e}  cpu-fp32 {floor[-1]:.2e}")
+    print(f"full-length train step: loss {loss.item():.7f} vs {oloss.item():.7f}; grad err median {np.median(errs):.2e} "
+          f"max {max(errs):.2e}; cpu-fp32-oracle floor median {np.median(floor):.2e} max {max(floor):.2e}")
+    assert float(np.median(errs)) < max(2e-5, 4 * float(np.median(floor)))
+    for name, e in zip([n for n, _ in model.named_parameters()], errs):
+        assert e < 5e-2, (name, e)
+    # optimiser at full parameter size: clip_grad_norm_(1.0) + Adam in fp64 on the SAME (HIP) gradients
+    # (the first Adam step is lr * g/|g|, so it must be fed identical gradients to be comparable)
+    params = [before[k].double().requires_grad_(True) for k, _ in model.named_parameters()]
+    for q, (_, p) in zip(params, model.named_parameters()):
+        q.grad = p.grad.detach().cpu().double()
+    opt = torch.optim.Adam(params, lr=1e-3)
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt.step()
+    runner.optimizer_step()
+    for (name, p), q in zip(model.named_parameters(), params):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name

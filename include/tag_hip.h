@@ -84,6 +84,19 @@ int tag_pack_conv_weight(const float* w /*(Cout,Cin,3,3)*/, float* wfwd /*(9,Cin
 int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
                         const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
                         void* stream);
+
+/* Alternative arithmetic for the same convolution (forward and dgrad): every fp32 operand is split exactly into
+ * three bf16 terms and the products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation --
+ * 6 of the 9 partial products by default (error of the dropped terms <= 2^-23 per product), TAG_X3_PRODUCTS=9
+ * for all of them, =1 for plain bf16.  Opt-in; tag_conv3x3_forward above stays the exact-fp32 default.
+ *   wfwd / wdgrad: tag_conv3x3_x3_pack_bytes(Cin, Cout) bytes each (pre-split, MFMA-fragment order).
+ *   Requires W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0. */
+size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout);
+int tag_pack_conv_weight_x3(const float* w /*(Cout,Cin,3,3)*/, void* wfwd, void* wdgrad, int Cin, int Cout,
+                            void* stream);
+int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
+                           const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
 /* dw (Cout,Cin,3,3) = sum over pixels of prologue(x)[shifted] * dy ; ws from *_ws_bytes */
 size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift,

@@ -138,6 +138,47 @@ def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert relerr(dw, wd.grad) < tol
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", [(2, 9, 8, 32, 64, 0), (1, 17, 16, 64, 128, 1), (2, 21, 32, 64, 64, 1),
+                                                (1, 7, 64, 64, 64, 3), (1, 6, 8, 32, 128, 2), (3, 11, 8, 256, 512, 0),
+                                                (2, 1001, 64, 64, 64, 1), (2, 500, 32, 64, 128, 0),
+                                                (2, 500, 32, 128, 128, 1), (2, 250, 16, 128, 256, 0),
+                                                (2, 250, 16, 256, 256, 1), (2, 250, 8, 256, 512, 0),
+                                                (3, 250, 8, 512, 512, 1)])
+def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
+    """Opt-in arithmetic (conv_x3.hip): fp32 operands split exactly into 3 bf16 terms, 6 partial products on the bf16
+    MFMA, fp32 accumulate -- held to the SAME tolerance against fp64 as the exact-fp32 kernels."""
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    s, t = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    sc, sh = s.view(1, -1, 1, 1).double(), t.view(1, -1, 1, 1).double()
+    xd = x.double()
+    a = {0: xd, 1: F.relu(xd * sc + sh), 2: F.leaky_relu(xd, 0.1) * sc + sh, 3: xd * sc + sh}[pro]
+    y_ref = F.conv2d(a, w.double(), None, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    da_ref = torch.nn.grad.conv2d_input(a.shape, w.double(), dy.double(), 1, 1)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = "x3"
+    try:
+        wf, wdg = ops.pack_conv_weight(w.to(dev), W=W)
+        assert wf.dtype == torch.uint8
+        sd, td = (s.to(dev), t.to(dev)) if pro else (None, None)
+        y = ops.conv3x3(nhwc(x).to(dev), wf, Cout, pro, sd, td)
+        e_f = relerr(nchw(y), y_ref)
+        e_d = None
+        if wdg.dtype == torch.uint8:                       # dgrad needs Cin % 64 == 0
+            da = ops.conv3x3(nhwc(dy).to(dev), wdg, Cin)
+            e_d = relerr(nchw(da), da_ref)
+    finally:
+        ops.CONV_MATH = old
+    # what the exact-fp32 kernel gives on the same data
+    pf, _ = ops.pack_conv_weight(w.to(dev))
+    e_32 = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), pf, Cout, pro, sd, td)), y_ref)
+    print(f"x3 conv {B}x{H}x{W} {Cin}->{Cout} pro {pro}: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e})"
+          + (f", dgrad err {e_d:.2e}" if e_d is not None else ""))
+    assert e_f < 5e-6 and (e_d is None or e_d < 5e-6)
+
+
 @pytest.mark.parametrize("B,H", [(2, 21), (3, 1001)])
 def test_conv3x3_c1(ops, dev, B, H):
     g = torch.Generator().manual_seed(7)

@@ -54,7 +54,18 @@ def sample_grad(g):
     return np.concatenate([[g.norm().item(), g.abs().max().item()], g[idx].numpy()])
 
 
-def test_golden_eval(dev, golden_dir):
+@pytest.fixture(params=["fp32", "x3"])
+def conv_math(request):
+    """Both arithmetics of the 3x3 convolutions: exact fp32 MFMA (default) and the opt-in 3 x bf16 split (conv_x3.hip);
+    the assertions (tolerances) are the same for both."""
+    from texttoaudiogrounding_amd import ops
+    old = ops.CONV_MATH
+    ops.CONV_MATH = request.param
+    yield request.param
+    ops.CONV_MATH = old
+
+
+def test_golden_eval(dev, golden_dir, conv_math):
     gold = np.load(f"{golden_dir}/cnn8rnn_dot_eval.npz")
     st = gold_state(gold)
     batch = make_batch(320)
@@ -77,7 +88,7 @@ def test_golden_eval(dev, golden_dir):
     assert logit_err < 2e-3        # logits span +-3.3
 
 
-def test_golden_train_step_grads(dev, golden_dir):
+def test_golden_train_step_grads(dev, golden_dir, conv_math):
     """Train-mode BN, dropout off: loss, frame_sim, running stats and every parameter gradient
     against the reference's fp64 twin.  Gradient tolerance is per tensor, normalised by max|g|:
     the reference's own fp32-vs-fp64 error with train-mode BN at B=2 is up to 4e-3."""
@@ -159,7 +170,7 @@ def test_proj_expnegl2_dropout_replay_vs_oracle(dev):
     assert float(np.median([e for e, _ in errs.values()])) < 2e-5     # typical tensor: fp32 round-off only
 
 
-def test_full_length_frame_sim_and_segments(dev):
+def test_full_length_frame_sim_and_segments(dev, conv_math):
     """BASELINE clip length (10 s @ 32 kHz -> T'=250), eval mode, B=3 ragged: frame_sim within 1e-4 of the
     CPU oracle and bit-exact integer segments at all 50 thresholds (n_connect 13 @ 0.04 s)."""
     from texttoaudiogrounding_amd.utils import eval_util

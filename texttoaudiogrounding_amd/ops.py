@@ -7,6 +7,7 @@ no eager fallback -- a CPU tensor or a missing library raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -104,17 +105,44 @@ def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     return st
 
 
-def pack_conv_weight(w, want_dgrad=True):
+# Arithmetic of the 3x3 convolutions (forward + dgrad): "fp32" = exact fp32 MFMA (default); "x3" = fp32 operands split
+# exactly into 3 bf16 terms, 6 partial products on the bf16 MFMA, fp32 accumulate (conv_x3.hip; opt-in).
+CONV_MATH = os.environ.get("TAG_CONV_MATH", "fp32")
+
+
+def _x3_ok(W, K, N):
+    return CONV_MATH == "x3" and W in (8, 16, 32, 64) and K % 32 == 0 and N % 64 == 0
+
+
+def pack_conv_weight(w, want_dgrad=True, W=None):
+    """(Cout,Cin,3,3) -> (forward pack, dgrad pack).  A pack is fp32 (9,K,N) for the exact kernels or a uint8 blob of
+    pre-split bf16 fragments for the x3 kernels (when CONV_MATH == "x3" and the layer shape allows it)."""
     Cout, Cin = w.shape[0], w.shape[1]
-    wf = _empty(9, Cin, Cout, like=w)
-    wd = _empty(9, Cout, Cin, like=w) if want_dgrad else None
-    call("tag_pack_conv_weight", ptr(w), ptr(wf), ptr(wd), Cin, Cout)
-    return wf, wd
+    fx3, dx3 = _x3_ok(W, Cin, Cout), want_dgrad and _x3_ok(W, Cout, Cin)
+    wf = wd = None
+    if fx3 or dx3:
+        nbytes = query("tag_conv3x3_x3_pack_bytes", Cin, Cout)
+        xf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        xd = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        call("tag_pack_conv_weight_x3", ptr(w), ptr(xf), ptr(xd), Cin, Cout)
+        wf, wd = (xf if fx3 else None), (xd if dx3 else None)
+    if wf is None or (want_dgrad and wd is None):
+        pf = _empty(9, Cin, Cout, like=w)
+        pd = _empty(9, Cout, Cin, like=w) if want_dgrad else None
+        call("tag_pack_conv_weight", ptr(w), ptr(pf), ptr(pd), Cin, Cout)
+        wf = pf if wf is None else wf
+        wd = pd if wd is None else wd
+    return wf, (wd if want_dgrad else None)
 
 
 def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
     B, H, W, Cin = x.shape
     y = _empty(B, H, W, Cout, like=x)
+    if wpack.dtype == torch.uint8:
+        with _timed(("conv3x3_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W, Cin,
+                 Cout)
+        return y
     kname = "conv3x3_halo_kernel" if W in (8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
     with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
         call("tag_conv3x3_forward", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout)
@@ -374,12 +402,12 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 y1 = conv3x3_c1(lm, c1w, st0.scale, st0.shift)
                 wf1 = wd1 = None
             else:
-                wf1, wd1 = pack_conv_weight(c1w)
+                wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
                 y1 = conv3x3(x, wf1, c1w.shape[0])
             Bx, H, W, C = y1.shape
             s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
                           blk.bn1.momentum)
-            wf2, wd2 = pack_conv_weight(c2w)
+            wf2, wd2 = pack_conv_weight(c2w, W=y1.shape[2])
             y2 = conv3x3(y1, wf2, C, prologue=1, scale=s1.scale, shift=s1.shift)
             s2 = bn_stats(y2.view(-1, C), g2, b2, blk.bn2.running_mean, blk.bn2.running_var, bn_train, blk.bn2.eps,
                           blk.bn2.momentum)
@@ -506,17 +534,17 @@ class CrnnFunction(torch.autograd.Function):
         y0 = conv3x3_c1(lm, blk[0][2], cs, ct)                     # (B,F,64,32)
         p1 = bnact_pool(y0, None, 2, 4, act=2, pool=1)            # leaky + LPPool -> (B,F/2,16,32)
         st[1] = stats(p1.view(-1, p1.shape[3]), 1, 0)
-        wf1, wd1 = pack_conv_weight(blk[1][2])
+        wf1, wd1 = pack_conv_weight(blk[1][2], W=p1.shape[2])
         y1 = conv3x3(p1, wf1, 128, prologue=3, scale=st[1].scale, shift=st[1].shift)
         st[2] = stats(y1.view(-1, 128), 2, 1)
-        wf2, wd2 = pack_conv_weight(blk[2][2])
+        wf2, wd2 = pack_conv_weight(blk[2][2], W=y1.shape[2])
         y2 = conv3x3(y1, wf2, 128, prologue=2, scale=st[2].scale, shift=st[2].shift)
         p2 = bnact_pool(y2, None, 2, 4, act=2, pool=1)            # (B,F/4,4,128)
         st[3] = stats(p2.view(-1, 128), 3, 0)
-        wf3, wd3 = pack_conv_weight(blk[3][2])
+        wf3, wd3 = pack_conv_weight(blk[3][2], W=p2.shape[2])
         y3 = conv3x3(p2, wf3, 128, prologue=3, scale=st[3].scale, shift=st[3].shift)
         st[4] = stats(y3.view(-1, 128), 4, 1)
-        wf4, wd4 = pack_conv_weight(blk[4][2])
+        wf4, wd4 = pack_conv_weight(blk[4][2], W=y3.shape[2])
         y4 = conv3x3(y3, wf4, 128, prologue=2, scale=st[4].scale, shift=st[4].shift)
         p3 = bnact_pool(y4, None, 1, 4, act=2, pool=1, drop_p=drop, seed=seed)     # (B,T',1,128)
         Bx, Tp = p3.shape[0], p3.shape[1]

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--math", default="fp32", help="fp32 | x3 (bf16x3-split MFMA forward/dgrad)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -42,7 +43,8 @@ def main():
         dy = torch.randn(B, H, W, Cout, device=dev)
         w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
         s, t = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
-        wf, wd = ops.pack_conv_weight(w)
+        ops.CONV_MATH = a.math
+        wf, wd = ops.pack_conv_weight(w, W=W)
         flop = 2.0 * B * H * W * 9 * Cin * Cout
         res = {}
         if a.only in ("", "fwd"):

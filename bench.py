@@ -169,7 +169,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dta = t.item()
         alt = {"conv_math": "x3: fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
-                            "v_mfma_f32_32x32x16_bf16, f32 accumulate (forward+dgrad convs only; opt-in, TAG_CONV_MATH=x3)",
+                            "v_mfma_f32_32x32x16_bf16, f32 accumulate (forward, dgrad and wgrad convs; opt-in, TAG_CONV_MATH=x3)",
                "value": round(clips / dta, 2), "unit": "clips/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
     dom = max(fam, key=lambda k: fam[k]["flop"]) if fam else None
     roof = None

@@ -169,14 +169,19 @@ def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
         if wdg.dtype == torch.uint8:                       # dgrad needs Cin % 64 == 0
             da = ops.conv3x3(nhwc(dy).to(dev), wdg, Cin)
             e_d = relerr(nchw(da), da_ref)
+        e_w = None
+        if Cin % 64 == 0:
+            dw_ref = torch.nn.grad.conv2d_weight(a, w.shape, dy.double(), 1, 1)
+            dw = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev), pro, sd, td)
+            e_w = relerr(dw, dw_ref)
     finally:
         ops.CONV_MATH = old
     # what the exact-fp32 kernel gives on the same data
     pf, _ = ops.pack_conv_weight(w.to(dev))
     e_32 = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), pf, Cout, pro, sd, td)), y_ref)
     print(f"x3 conv {B}x{H}x{W} {Cin}->{Cout} pro {pro}: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e})"
-          + (f", dgrad err {e_d:.2e}" if e_d is not None else ""))
-    assert e_f < 5e-6 and (e_d is None or e_d < 5e-6)
+          + (f", dgrad err {e_d:.2e}" if e_d is not None else "") + (f", wgrad err {e_w:.2e}" if e_w is not None else ""))
+    assert e_f < 5e-6 and (e_d is None or e_d < 5e-6) and (e_w is None or e_w < 5e-6)
 
 
 @pytest.mark.parametrize("B,H", [(2, 21), (3, 1001)])

@@ -1185,6 +1185,18 @@ static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_pe
     return (chunks + *chunks_per_split - 1) / *chunks_per_split;
 }
 
+// shared with conv_x3.hip (same K split and the same deterministic reduction)
+int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split) {
+    return alltaps_splits(B, H, W, Cin, Cout, chunks_per_split);
+}
+int tag_launch_wgrad_reduce(const float* partial, int splits, int Cin, int Cout, float* dw, hipStream_t st) {
+    const long nred = (long)9 * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 4096 ? 4096 : cdiv(nred, 64)), dim3(256), 0, st,
+                       partial, splits, Cin, Cout, dw);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
     const long M = (long)B * H * W;
     if (wgrad_alltaps_ok(W)) {

@@ -18,6 +18,12 @@
 #include <stdlib.h>
 #include "tag_common.h"
 
+// schedule pinning of the wgrad MFMA phase: 0 = fences between plane-steps only (measured best: 213 TFLOP/s),
+// 1 = + sched_group_barrier interleave of reads and MFMAs (206), 2 = interleave without fences
+#ifndef TAG_WX3_PIN
+#define TAG_WX3_PIN 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -295,6 +301,315 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// wgrad with the same arithmetic: partial[split][tap][ci][co] = sum_{pixels of the split} X[p + tap][ci] * dY[p][co].
+// GEMM with M = ci, N = co, K = pixels: both operands are consumed K-major while LDS (like HBM) holds them
+// pixel-major, so the fragments are fetched with the gfx950 transposing read ds_read_b64_tr_b16 (a 16-lane group
+// reads 4 pixels x 16 channels and each lane receives the 4 pixels of its channel).  A workgroup owns 64 ci x 64 co of
+// all nine taps (4 waves x 32x32x9 = 144 accumulator registers) and walks DOWN one column strip of one image in
+// chunks of 32 pixels (CH rows x CW columns): the input rows live in a ring of 2*CH+2 row slots, so each chunk
+// stages only its CH new rows (not the whole (CH+2)-row halo patch), into slots the running chunk does not read --
+// one barrier per chunk, staging of chunk c+1 overlaps the MFMAs of chunk c.
+// LDS image: X planes [split 3][ci block 2][ring row][PW pixels][32 ch bf16 = 64 B]; dY planes [2 buffers][split 3]
+// [co block 2][32 pixels][64 B]: the 4 pixels x 64 B of a transposing read are contiguous -> conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int TW>
+struct WX3Geom {
+    static constexpr int CW = TW >= 32 ? 32 : TW, CH = 32 / CW, PW = CW + 2, R = 2 * CH + 2;
+    static constexpr int XROWB = PW * 64;                                       // bytes of one ring row in one plane
+    static constexpr int XPL = R * XROWB + ((R * XROWB) % 256 == 0 ? 128 : 0);  // plane stride = 128 (mod 256)
+    static constexpr int YPL = 32 * 64;
+    static constexpr int XBYTES = 6 * XPL, YBYTES = 6 * YPL;                    // per dY buffer
+    static constexpr int LDS_BYTES = XBYTES + 2 * YBYTES;
+    static constexpr int XITEMS = (CH * PW * 16 + 255) / 256;                   // (pixel, channel quad) items of CH new rows
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 lds_tr_read(const unsigned char* p) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <int TW, int PRO, int NP>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ in_scale,
+                                                                  const float* __restrict__ in_shift,
+                                                                  const float* __restrict__ dy,
+                                                                  float* __restrict__ partial, int B, int H, int W,
+                                                                  int Cin, int Cout, int splits, int chunks_per_split) {
+    using G = WX3Geom<TW>;
+    constexpr int CW = G::CW, CH = G::CH, PW = G::PW, R = G::R;
+    constexpr int NSPL = NP == 1 ? 1 : 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Xs = smem;
+    unsigned char* Ys = smem + G::XBYTES;
+
+    const int ci_tiles = Cin / 64, co_tiles = Cout / 64;
+    int L = xcd_remap(blockIdx.x, ci_tiles * co_tiles * splits);
+    const int cot = L % co_tiles; L /= co_tiles;
+    const int cit = L % ci_tiles; L /= ci_tiles;
+    const int split = L;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    const int rb_per_img = (H + CH - 1) / CH, cb_per_row = TW / CW;
+    const int chunks_total = B * rb_per_img * cb_per_row;
+    const int cbeg = split * chunks_per_split;
+    int cend = cbeg + chunks_per_split;
+    if (cend > chunks_total) cend = chunks_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = wid >> 1, wj = wid & 1;                       // ci / co 32-block of the wave
+    const int kl = lane >> 5, half = (lane >> 4) & 1, li = lane & 15;
+
+    // ---- staging geometry: item = (pixel, channel quad); quad = tid & 15 -> block (quad>>3), 8 B at (quad&7)*8 ----
+    const int quad = tid & 15;
+    const int ca = ci0 + quad * 4, cb = co0 + quad * 4;
+    const unsigned qoff = (unsigned)((quad >> 3) * 1 /*block*/), qbyte = (unsigned)((quad & 7) * 8);
+    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRO != 0) { rs = *reinterpret_cast<const f32x4*>(in_scale + ca); rt = *reinterpret_cast<const f32x4*>(in_shift + ca); }
+
+    f32x4 rx[G::XITEMS], rd[2];
+    unsigned xok = 0, dok = 0;
+    // chunk index -> (img, h0, w0); row blocks run fastest so that consecutive chunks walk down a strip
+    auto origin = [&](int c, int& img, int& h0, int& w0) {
+        const int rbk = c % rb_per_img; const int t = c / rb_per_img;
+        const int cbk = t % cb_per_row; img = t / cb_per_row;
+        h0 = rbk * CH; w0 = cbk * CW;
+    };
+    auto load_rows = [&](int img, int first_row, int w0) {       // CH input rows [first_row, first_row+CH), PW columns
+        const long ibase = (long)img * H * W;
+        xok = 0;
+#pragma unroll
+        for (int i = 0; i < G::XITEMS; ++i) {
+            const int pp = (tid + 256 * i) >> 4;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            const int h = first_row + pr, w = w0 - 1 + pc;
+            const unsigned ok = (unsigned)(pp < CH * PW) & (unsigned)((unsigned)h < (unsigned)H) &
+                                (unsigned)((unsigned)w < (unsigned)W);
+            xok |= ok << i;
+            const long pix = ok ? ibase + (long)h * W + w : ibase;
+            rx[i] = *reinterpret_cast<const f32x4*>(x + pix * Cin + ca);
+        }
+    };
+    auto store_rows = [&](int first_row, int last_wanted) {      // rows > last_wanted are not stored (priming overshoot)
+#pragma unroll
+        for (int i = 0; i < G::XITEMS; ++i) {
+            const int pp = (tid + 256 * i) >> 4;
+            if (pp >= CH * PW) continue;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            const int row = first_row + pr;
+            if (row > last_wanted) continue;
+            const int slot = (row + 4 * R) % R;
+            f32x4 v;
+            v.x = prologue1(rx[i].x, PRO, rs.x, rt.x);
+            v.y = prologue1(rx[i].y, PRO, rs.y, rt.y);
+            v.z = prologue1(rx[i].z, PRO, rs.z, rt.z);
+            v.w = prologue1(rx[i].w, PRO, rs.w, rt.w);
+            if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+            split_pack(v.x, v.y, h0_, m0_, l0_);
+            split_pack(v.z, v.w, h1_, m1_, l1_);
+            unsigned char* dst = Xs + qoff * G::XPL + (slot * PW + pc) * 64 + qbyte;
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+            if (NSPL == 3) {
+                *reinterpret_cast<u32x2*>(dst + 2 * G::XPL) = (u32x2){m0_, m1_};
+                *reinterpret_cast<u32x2*>(dst + 4 * G::XPL) = (u32x2){l0_, l1_};
+            }
+        }
+    };
+    auto load_dy = [&](int img, int h0, int w0) {
+        const long ibase = (long)img * H * W;
+        dok = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;
+            const int h = h0 + k / CW, w = w0 + k % CW;
+            const unsigned ok = (unsigned)(h < H);
+            dok |= ok << i;
+            const long pix = ok ? ibase + (long)h * W + w : ibase;
+            rd[i] = *reinterpret_cast<const f32x4*>(dy + pix * Cout + cb);
+        }
+    };
+    auto store_dy = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;
+            f32x4 v = rd[i];
+            if (!((dok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+            split_pack(v.x, v.y, h0_, m0_, l0_);
+            split_pack(v.z, v.w, h1_, m1_, l1_);
+            unsigned char* dst = Ys + buf * G::YBYTES + qoff * G::YPL + k * 64 + qbyte;
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+            if (NSPL == 3) {
+                *reinterpret_cast<u32x2*>(dst + 2 * G::YPL) = (u32x2){m0_, m1_};
+                *reinterpret_cast<u32x2*>(dst + 4 * G::YPL) = (u32x2){l0_, l1_};
+            }
+        }
+    };
+    // regular staging of chunk c = its CH new rows (h0+1 .. h0+CH) + its dy tile
+    auto issue_chunk = [&](int c) {
+        int img, h0, w0;
+        origin(c, img, h0, w0);
+        load_rows(img, h0 + 1, w0);
+        load_dy(img, h0, w0);
+    };
+    auto store_chunk = [&](int c) {
+        int img, h0, w0;
+        origin(c, img, h0, w0);
+        store_rows(h0 + 1, h0 + CH);
+        store_dy((c - cbeg) & 1);
+    };
+    // first chunk of a strip: rows h0-1 .. h0 are not in the ring yet (synchronous; once per strip)
+    auto prime = [&](int c) {
+        int img, h0, w0;
+        origin(c, img, h0, w0);
+        constexpr int NPRIME = (2 + CH - 1) / CH;
+#pragma unroll
+        for (int k = NPRIME; k >= 1; --k) {
+            load_rows(img, h0 + 1 - k * CH, w0);
+            store_rows(h0 + 1 - k * CH, h0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // per-lane fragment bases (bytes): 16-lane group = (half, kl); lane li: pixel row (li>>2), channel quad (li&3)
+    const unsigned lq = (unsigned)(half * 32 + (li & 3) * 8);
+    const unsigned va = (unsigned)(wi * G::XPL) + lq + (unsigned)((CW == 8 ? (li >> 2) : (kl * 8 + (li >> 2))) * 64);
+    const unsigned vb = (unsigned)(wj * G::YPL) + lq + (unsigned)((kl * 8 + (li >> 2)) * 64);
+    constexpr int PA[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+    constexpr int PB[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0};
+    constexpr int P0 = NP == 1 ? 8 : 9 - NP;
+
+    // MFMA phase of one chunk as 18 plane-steps q = ((s*3 + ky)*3 + o): the A fragments (3 taps kx) of ONE split plane
+    // (o = 0 lo, 1 mid, 2 hi) are live at a time and feed every product that uses that plane (lo: a_l*b_h; mid:
+    // a_m*b_m, a_m*b_h; hi: a_h*b_l, a_h*b_m, a_h*b_h; NP = 9 adds a_l*b_l, a_l*b_m, a_m*b_l); the fragments of
+    // plane-step q+1 are read while the MFMAs of q run (pinned with sched_group_barrier).
+    auto mma_chunk = [&](int c) {
+        int img, h0, w0;
+        origin(c, img, h0, w0);
+        const int slot0 = (h0 - 1 + 4 * R) % R;
+        unsigned rowb[CH + 2];
+#pragma unroll
+        for (int j = 0; j < CH + 2; ++j) {
+            int sl = slot0 + j;
+            sl = sl >= R ? sl - R : sl;
+            rowb[j] = (unsigned)(sl * G::XROWB);
+        }
+        const unsigned char* yb = Ys + ((c - cbeg) & 1) * G::YBYTES + vb;
+        constexpr int NQ = NSPL == 1 ? 6 : 18;
+        auto plane_of = [](int q) { return NSPL == 1 ? 0 : 2 - (q % 3); };          // lo (2), mid (1), hi (0)
+        auto load_a = [&](int q, u32x4 (&af)[3]) {
+            const int g = NSPL == 1 ? q : q / 3, s = g / 3, ky = g % 3, sp = plane_of(q);
+            unsigned arow;
+            if (CW == 8) arow = kl ? rowb[2 * s + 1 + ky] : rowb[2 * s + ky];
+            else if (CW == 16) arow = rowb[s + ky];
+            else arow = rowb[ky];
+            const unsigned char* xa = Xs + va + arow;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int imm = sp * 2 * G::XPL + (kx + (CW == 32 ? s * 16 : 0)) * 64;
+                const u32x2 t0 = lds_tr_read(xa + imm);
+                const u32x2 t1 = lds_tr_read(xa + imm + 256);
+                af[kx] = (u32x4){t0.x, t0.y, t1.x, t1.y};
+            }
+        };
+        u32x4 bf[2][NSPL];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int sp = 0; sp < NSPL; ++sp) {
+                const u32x2 t0 = lds_tr_read(yb + sp * 2 * G::YPL + s * 1024);
+                const u32x2 t1 = lds_tr_read(yb + sp * 2 * G::YPL + s * 1024 + 256);
+                bf[s][sp] = (u32x4){t0.x, t0.y, t1.x, t1.y};
+            }
+        u32x4 afb[2][3];
+        load_a(0, afb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int g = NSPL == 1 ? q : q / 3, s = g / 3, ky = g % 3, sp = plane_of(q);
+            if (q + 1 < NQ) load_a(q + 1, afb[(q + 1) & 1]);
+            // b planes paired with this a plane, smallest product first
+            int nb = 0, bl[3] = {0, 0, 0};
+            if (NP == 1) { nb = 1; bl[0] = 0; }
+            else if (NP == 6) {
+                if (sp == 2) { nb = 1; bl[0] = 0; }
+                else if (sp == 1) { nb = 2; bl[0] = 1; bl[1] = 0; }
+                else { nb = 3; bl[0] = 2; bl[1] = 1; bl[2] = 0; }
+            } else { nb = 3; bl[0] = 2; bl[1] = 1; bl[2] = 0; }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b >= nb) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = mfma_bf16(afb[q & 1][kx], bf[s][bl[b]], acc[ky * 3 + kx]);
+            }
+            // pin: the 6 transposing reads of the next plane-step are spread over this step's MFMAs
+            const int nm = 3 * nb;
+            if (TAG_WX3_PIN && q + 1 < NQ) {
+                if (nm >= 6) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+            }
+            if (TAG_WX3_PIN != 2) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto fresh = [&](int c) { return c % rb_per_img == 0; };
+    if (cbeg < cend) {
+        prime(cbeg);
+        issue_chunk(cbeg);
+        store_chunk(cbeg);
+        __syncthreads();
+        if (cbeg + 1 < cend && !fresh(cbeg + 1)) issue_chunk(cbeg + 1);
+    }
+    for (int c = cbeg; c < cend; ++c) {
+        const bool next = c + 1 < cend;
+        const bool next_fresh = next && fresh(c + 1);
+        if (next && !next_fresh) {
+            store_chunk(c + 1);                                   // into ring slots / dy buffer chunk c does not read
+            if (c + 2 < cend && !fresh(c + 2)) issue_chunk(c + 2);
+        }
+        mma_chunk(c);
+        __syncthreads();
+        if (next_fresh) {                                         // new strip: rebuild the ring (rare)
+            prime(c + 1);
+            issue_chunk(c + 1);
+            store_chunk(c + 1);
+            __syncthreads();
+            if (c + 2 < cend && !fresh(c + 2)) issue_chunk(c + 2);
+        }
+    }
+    // partial[split][tap][ci][co]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = partial + ((size_t)split * 9 + t) * Cin * Cout;
+        const int co = co0 + wj * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            out[(size_t)ci * Cout + co] = acc[t][r];
+        }
+    }
+}
+
 static int x3_products() {
     static int v = -1;
     if (v < 0) {
@@ -341,6 +656,41 @@ void launch_x3_w(const float* x, const u32x4* wp, int pro, const float* s, const
     else launch_x3<MB, 64, NP>(x, wp, pro, s, t, y, B, H, W, Cin, Cout, st);
 }
 
+template <int TW, int NP>
+void launch_wgrad_x3(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial, int B,
+                     int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
+    using G = WX3Geom<TW>;
+    const int grid = (Cin / 64) * (Cout / 64) * splits;
+    const size_t lds = G::LDS_BYTES;
+#define LAUNCH_PRO(P)                                                                                                \
+    {                                                                                                                \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_x3_kernel<TW, P, NP>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<TW, P, NP>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
+                           B, H, W, Cin, Cout, splits, cps);                                                         \
+    }
+    switch (pro) {
+        case 0: LAUNCH_PRO(0) break;
+        case 1: LAUNCH_PRO(1) break;
+        case 2: LAUNCH_PRO(2) break;
+        default: LAUNCH_PRO(3) break;
+    }
+#undef LAUNCH_PRO
+}
+
+template <int NP>
+void launch_wgrad_x3_w(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial, int B,
+                       int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
+    if (W == 8) launch_wgrad_x3<8, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else if (W == 16) launch_wgrad_x3<16, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else if (W == 32) launch_wgrad_x3<32, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else launch_wgrad_x3<64, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+}
+
 }  // namespace
 
 extern "C" size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * 3 * 2; }
@@ -374,4 +724,30 @@ extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int pro
 #undef BY_NP
     TAG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" size_t tag_conv3x3_wgrad_x3_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    int cps;
+    return (size_t)tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps) * 9 * Cin * Cout * sizeof(float);
+}
+
+extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* in_scale, const float* in_shift,
+                                    const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                    void* stream) {
+    TAG_CHECK_ARG(x && dy && dw && ws && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
+    TAG_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && prologue >= 0 && prologue <= 3);
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    const long M = (long)B * H * W;
+    TAG_CHECK_ARG(M < (1L << 31) && M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32));
+    float* partial = static_cast<float*>(ws);
+    hipStream_t st = as_stream(stream);
+    int cps;
+    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps);
+    const int np = x3_products();
+    if (np == 6) launch_wgrad_x3_w<6>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+    else if (np == 9) launch_wgrad_x3_w<9>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+    else launch_wgrad_x3_w<1>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+    TAG_LAUNCH_CHECK();
+    return tag_launch_wgrad_reduce(partial, sp, Cin, Cout, dw, st);
 }

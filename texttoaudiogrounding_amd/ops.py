@@ -153,6 +153,12 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     dw = _empty(Cout, Cin, 3, 3, like=x)
+    if CONV_MATH == "x3" and W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0:
+        ws = _ws(query("tag_conv3x3_wgrad_x3_ws_bytes", B, H, W, Cin, Cout), x)
+        with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_wgrad_x3", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
+                 ptr(ws))
+        return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     kname = "conv3x3_wgrad_alltaps_kernel" if W in (8, 16, 32, 64) else "conv3x3_wgrad_kernel"
     with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):

@@ -118,6 +118,11 @@ int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, const float* co
                          void* stream);
 int tag_conv3x3_c1_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int Cout,
                          void* stream);
+/* fused wgrad + dgrad of the Cin = 1 convolution: ONE pass over dy (W == 64, Cout == 64 only) */
+size_t tag_conv3x3_c1_backward_ws_bytes(int B, int H, int W, int Cout);
+int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float* col_shift, const float* dy,
+                            const float* w /*(Cout,1,3,3)*/, float* dw /*(Cout,1,3,3)*/, float* dx /*(B,H,W)*/,
+                            int B, int H, int W, int Cout, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1 + A2: relu(bn(y)) -> avg_pool + max_pool (kernel = stride = (ph,pw), floor) -> dropout

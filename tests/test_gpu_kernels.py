@@ -202,6 +202,8 @@ def test_conv3x3_c1(ops, dev, B, H):
     assert relerr(dw, wd.grad) < 2e-6
     dx = ops.conv3x3_c1_dgrad(nhwc(dy).to(dev), w.to(dev))
     assert relerr(dx, xin.grad[:, 0]) < 2e-6
+    dw2, dx2 = ops.conv3x3_c1_backward(x.to(dev), nhwc(dy).to(dev), w.to(dev), cs.to(dev), ct.to(dev))   # fused pass
+    assert relerr(dw2, wd.grad) < 2e-6 and relerr(dx2, xin.grad[:, 0]) < 2e-6
 
 
 # ------------------------------------------------------------------------------------------- bn+relu+pool

@@ -1058,6 +1058,143 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
     }
 }
 
+// Fused backward of the Cin = 1 convolution for W = 64 mel bins, Cout = 64: ONE pass over dy (the 1 GB tensor at
+// batch 64) produces both dw (64 x 9) and dx (the gradient of the bn0 output, needed for bn0's weight / bias).
+// A workgroup walks down a strip of rows of one image; per row (64 pixels x 64 couts = 16 KB, one float4 per thread
+// and 16-pixel quarter) every dy value is read once and feeds
+//   wgrad:  acc[j][tap] += xin[h+ky-1][w+kx-1] * dy[h][w][c+j]            (xin rows in an LDS ring, bn0 affine applied)
+//   dgrad:  G[h][w][tap] = sum_co dy[h][w][co] * wgt[co][tap]  (16-lane butterfly), kept in an LDS ring of 4 rows;
+//           dx[h-1][w] = sum_tap G[h-1-(ky-1)][w-(kx-1)][tap] once row h is in.
+// The next row's dy is in flight while the current one is processed; one barrier per row.
+constexpr int C1B_GW = 66, C1B_GT = 10;        // G ring row: 64 + 2 halo pixels, 9 taps + 1 pad
+// sum over each aligned group of 16 lanes, result in all 16 (DPP: quad swaps, then half-row and row mirrors)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float sum16(float v) {
+    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);       // row_half_mirror
+    v = dpp_add<0x140>(v);       // row_mirror
+    return v;
+}
+__global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                          const float* __restrict__ ct, const float* __restrict__ dy,
+                                                          const float* __restrict__ wgt, float* __restrict__ dx,
+                                                          double* __restrict__ partials, int H, int strips,
+                                                          int rows_per_strip) {
+    constexpr int W = 64, Cout = 64;
+    __shared__ float Gs[4][C1B_GW][C1B_GT];
+    __shared__ float Xs[4][C1B_GW];
+    __shared__ float red[4][16][36];
+    const int img = blockIdx.x / strips, strip = blockIdx.x % strips;
+    const int r0 = strip * rows_per_strip;
+    int r1 = r0 + rows_per_strip;
+    if (r1 > H) r1 = H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cq = lane & 15, c = cq << 2, psub = lane >> 4;             // channel quad, pixel inside a 4-pixel load
+    float wr[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[j][t] = wgt[(c + j) * 9 + t];
+    float acc[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
+    for (int i = tid; i < 4 * C1B_GW * C1B_GT; i += 256) (&Gs[0][0][0])[i] = 0.0f;      // halo columns stay zero
+    const float* ximg = x + (size_t)img * H * W;
+    const float* dimg = dy + (size_t)img * H * W * Cout;
+    auto stage_x = [&](int row) {                                         // bn0 affine applied; zero outside the image
+        if (tid < C1B_GW) {
+            const int w = tid - 1;
+            float v = 0.0f;
+            if ((unsigned)row < (unsigned)H && (unsigned)w < (unsigned)W) {
+                v = ximg[(size_t)row * W + w];
+                if (cs) v = fmaf(v, cs[w], ct[w]);
+            }
+            Xs[(row + 8) & 3][tid] = v;
+        }
+    };
+    f32x4 g[4], gn[4];
+    auto load_dy = [&](int row, f32x4 (&dst)[4]) {
+        const bool ok = (unsigned)row < (unsigned)H;
+        const float* p = dimg + ((size_t)(ok ? row : 0) * W + wid * 16 + psub) * Cout + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[i] = *reinterpret_cast<const f32x4*>(p + (size_t)i * 4 * Cout);
+            if (!ok) dst[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    stage_x(r0 - 1);
+    stage_x(r0);
+    load_dy(r0 - 1, g);
+    __syncthreads();
+    for (int h = r0 - 1; h <= r1; ++h) {
+        stage_x(h + 2 > r1 + 1 ? -1 : h + 2);                             // rows beyond r1+1 are never read
+        if (h < r1) load_dy(h + 1, gn);
+        const bool own = h >= r0 && h < r1;
+        const int gs = (h + 8) & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = wid * 16 + i * 4 + psub;
+            const float gv[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
+            float gp[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float sgp = gv[0] * wr[0][t];
+                sgp = fmaf(gv[1], wr[1][t], sgp);
+                sgp = fmaf(gv[2], wr[2][t], sgp);
+                sgp = fmaf(gv[3], wr[3][t], sgp);
+                gp[t] = sgp;
+            }
+            if (own) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = Xs[(h + t / 3 - 1 + 8) & 3][px + t % 3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][t] = fmaf(xv, gv[j], acc[j][t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = sum16(gp[t]);
+                if (cq == t) Gs[gs][px + 1][t] = v;
+            }
+        }
+        __syncthreads();
+        const int ho = h - 1;                                             // output row whose three G rows are now present
+        if (ho >= r0 && ho < r1 && tid < W) {
+            float sdx = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)                                   // dx[p] = sum_tap G[p - shift(tap)][tap]
+                sdx += Gs[(ho - (t / 3 - 1) + 8) & 3][tid + 1 - (t % 3 - 1)][t];
+            dx[((size_t)img * H + ho) * W + tid] = sdx;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = gn[i];
+    }
+    // dw partial of this workgroup: fold the 4 pixel sub-lanes, then the 4 waves (fixed order), in fp64 across workgroups
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v = acc[j][t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (psub == 0) red[wid][cq][j * 9 + t] = v;
+        }
+    __syncthreads();
+    for (int e = tid; e < 16 * 36; e += 256) {
+        const int q = e / 36, r = e % 36;
+        const double sum = ((double)red[0][q][r] + (double)red[1][q][r]) + ((double)red[2][q][r] + (double)red[3][q][r]);
+        partials[(size_t)blockIdx.x * Cout * 9 + (q * 4 + r / 9) * 9 + r % 9] = sum;
+    }
+}
+
 int wgrad_splits(long M, int Cin, int Cout, int TC) {
     // two full residency rounds of 768 workgroup slots (3 per CU): floor, so the last round is not a stub
     const int tiles = 9 * ((Cin + TC - 1) / TC) * ((Cout + TC - 1) / TC);
@@ -1354,6 +1491,39 @@ extern "C" int tag_conv3x3_c1_dgrad(const float* dy, const float* w, float* dx, 
     long nb = (M + rpi - 1) / rpi;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), dy, w, dx, M, H, W, Cout);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// fused wgrad + dgrad of the Cin = 1 convolution (one pass over dy); W == 64 and Cout == 64 only
+static void c1_bwd_geom(int B, int H, int* strips, int* rows) {
+    int s = 2048 / (B > 0 ? B : 1);
+    if (s < 1) s = 1;
+    int r = (H + s - 1) / s;
+    if (r < 8) r = 8;                       // two halo rows are recomputed per strip
+    *rows = r;
+    *strips = (H + r - 1) / r;
+}
+extern "C" size_t tag_conv3x3_c1_backward_ws_bytes(int B, int H, int W, int Cout) {
+    (void)W;
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    return (size_t)B * strips * Cout * 9 * sizeof(double);
+}
+extern "C" int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float* col_shift, const float* dy,
+                                       const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
+                                       void* stream) {
+    TAG_CHECK_ARG(x && dy && w && dw && dx && ws && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 64 && Cout == 64);
+    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    double* partials = static_cast<double*>(ws);
+    hipLaunchKernelGGL(conv_c1_bwd_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, dy,
+                       w, dx, partials, H, strips, rows);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
+                       partials, B * strips, Cout * 9, dw);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -184,6 +184,20 @@ def conv3x3_c1_wgrad(x, dy, col_scale=None, col_shift=None):
     return dw
 
 
+def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None):
+    """(dw, dx) of the Cin = 1 convolution; one fused pass over dy when the shape allows (W == 64, Cout == 64)."""
+    B, H, W = x.shape
+    Cout = dy.shape[3]
+    if W == 64 and Cout == 64:
+        dw = _empty(Cout, 1, 3, 3, like=x)
+        dx = _empty(B, H, W, like=x)
+        ws = _ws(query("tag_conv3x3_c1_backward_ws_bytes", B, H, W, Cout), x)
+        call("tag_conv3x3_c1_backward", ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(w), ptr(dw), ptr(dx), B, H,
+             W, Cout, ptr(ws))
+        return dw, dx
+    return conv3x3_c1_wgrad(x, dy, col_scale, col_shift), conv3x3_c1_dgrad(dy, w)
+
+
 def conv3x3_c1_dgrad(dy, w):
     B, H, W, Cout = dy.shape
     dx = _empty(B, H, W, like=dy)
@@ -474,8 +488,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 grads[2 + 6 * i] = sw.wgrad(x_in, dy1)
                 dx = conv3x3(dy1, wd1, x_in.shape[3])
             else:
-                grads[2] = conv3x3_c1_wgrad(lm, dy1, st0.scale, st0.shift)
-                dbn0 = conv3x3_c1_dgrad(dy1, c1w)                                   # (B,F,64) grad wrt bn0 output
+                grads[2], dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift)   # dbn0: (B,F,64) grad wrt bn0 output
                 Bq, Fr, NM = lm.shape
                 grads[0], grads[1] = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0)
             del dy1, da1

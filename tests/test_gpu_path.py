@@ -167,7 +167,8 @@ def test_proj_expnegl2_dropout_replay_vs_oracle(dev):
     # the loss / forward agreement above.
     for name, (err, e32) in errs.items():
         assert err < 5e-2, (name, err, e32)
-    assert float(np.median([e for e, _ in errs.values()])) < 2e-5     # typical tensor: fp32 round-off only
+        if "conv_block" not in name and "bn0" not in name:          # above the last ReLU/max-pool: round-off only
+            assert err < 2e-5, (name, err, e32)
 
 
 def test_full_length_frame_sim_and_segments(dev, conv_math):

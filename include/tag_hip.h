@@ -171,7 +171,7 @@ int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p
  *   op(A): transA ? A^T : A, A stored (M,K) ld=lda or (K,M) when transA; same for B (K,N)/(N,K).
  * Serves nn.Linear fc1 / audio_proj / text_proj (models/audio_encoder.py:140,216;
  * models/audio_text_model.py:45-46,78-87), the GRU input projections and all their backward GEMMs.
- * act: 0 none, 1 relu.  bias (N) nullable.
+ * act: 0 none, 1 relu, 3 gelu (erf form), 4 tanh.  bias (N) nullable.
  * ------------------------------------------------------------------------------------------- */
 /* ws (nullable): scratch of tag_gemm_ws_bytes(M,N,K) bytes enabling a deterministic split-K for problems whose
  * MxN tile count cannot fill the chip (weight gradients: K = B*T); 0 bytes = not needed. */
@@ -272,6 +272,23 @@ int tag_sumsq(const float* g, long n, double* out, void* ws, void* stream);
 int tag_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, int step, const double* gnorm_sq, float max_norm,
                   float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inference path, text tower (next row of the scope table: models/hf_modeling_grounding.py:183-199 LaionClapEncoder =
+ * Hugging Face ClapTextModel + ClapProjectionLayer, RoBERTa-style post-LayerNorm encoder), forward only.  Dense
+ * layers are tag_gemm calls (bias + GELU / tanh / ReLU epilogues); these are the row kernels in between.
+ * ------------------------------------------------------------------------------------------- */
+/* out[b,l,:] = LayerNorm(word[ids] + type0 + pos[position_id]), position_id = cumsum(ids != pad)*(ids != pad) + pad */
+int tag_roberta_embed_ln(const long* ids /*(B,L)*/, const float* word, const float* type0, const float* pos,
+                         const float* gamma, const float* beta, float eps, float* out /*(B*L,D)*/, int B, int L,
+                         int D, int pad_id, void* stream);
+/* out = LayerNorm(x + res) * gamma + beta over rows of D (res nullable) */
+int tag_add_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                      float* out, long rows, int D, void* stream);
+/* softmax(q k^T / sqrt(dh) + key mask) v per (sequence, head); qkv (B*L, 3*heads*dh) = [q|k|v]; L <= 64;
+ * dh in {16,32,64}; mask (B,L) int64 (0 = padded key) */
+int tag_mha_small(const float* qkv, const long* mask, float* out /*(B*L, heads*dh)*/, int B, int L, int heads,
+                  int dh, void* stream);
 
 #ifdef __cplusplus
 }

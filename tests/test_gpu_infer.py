@@ -1,0 +1,107 @@
+"""Inference path (BASELINE config 5: models/hf_modeling_grounding.py in the reference):
+LAION-CLAP text tower kernels against the Hugging Face golden vectors and the CPU restatement, and the whole
+Cnn8Rnn + CLAP + projections + DotProduct model on 30 s clips against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import clap_text_oracle as C
+from oracle import tag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build_text_encoder(st, cfg, dev):
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import LaionClapEncoder
+    enc = LaionClapEncoder(config=cfg)
+    missing = enc.load_state_dict(st, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return enc.to(dev).eval()
+
+
+def test_clap_text_tower_golden(dev, golden_dir):
+    """HIP text tower == real transformers ClapTextModel + ClapProjectionLayer outputs (tiny config fixture)."""
+    g = np.load(f"{golden_dir}/clap_text_tiny.npz")
+    st = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    D = st["model.embeddings.word_embeddings.weight"].shape[1]
+    cfg = dict(vocab_size=st["model.embeddings.word_embeddings.weight"].shape[0], hidden_size=D,
+               num_hidden_layers=2, num_attention_heads=int(g["n_heads"]),
+               intermediate_size=st["model.encoder.layer.0.intermediate.dense.weight"].shape[0],
+               max_position_embeddings=st["model.embeddings.position_embeddings.weight"].shape[0],
+               projection_dim=st["projection.linear2.weight"].shape[0], layer_norm_eps=float(g["eps"]))
+    enc = build_text_encoder(st, cfg, dev)
+    out = enc({"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])})
+    for key in ("last_hidden_state", "pooler_output", "token_emb", "seq_emb"):
+        err = np.abs(out[key].cpu().numpy() - g[key]).max()
+        print(f"clap tiny {key}: max abs err {err:.2e} (|ref| max {np.abs(g[key]).max():.2f})")
+        assert err < 2e-5 * max(1.0, np.abs(g[key]).max()), key
+
+
+def test_clap_text_tower_roberta_base_shape(dev):
+    """RoBERTa-base shape (12 x 768, FFN 3072, vocab 50265, projection 512), seeded random weights, ragged phrases."""
+    st = C.init_text_state(seed=5)
+    ids, mask = C.synthetic_tokens(6, 12, seed=9)
+    enc = build_text_encoder(st, None, dev)
+    out = enc({"input_ids": ids, "attention_mask": mask})
+    st64 = {k: v.double() for k, v in st.items()}
+    ref = C.laion_clap_encoder_forward(st64, ids, mask, 12, 1e-12)
+    e_seq = (out["seq_emb"].cpu().double() - ref["seq_emb"]).abs().max().item()
+    e_tok = (out["token_emb"].cpu().double() - ref["token_emb"]).abs().max().item() / ref["token_emb"].abs().max().item()
+    print(f"clap base-shape: seq_emb err {e_seq:.2e}, token_emb rel err {e_tok:.2e}")
+    assert e_seq < 1e-5 and e_tok < 1e-5          # unit-norm 512-vector: 1e-5 per component
+
+
+def test_grounding_model_30s_clips_vs_oracle(dev):
+    """Cnn8RnnLaionClapGroundingModel.forward on 30 s clips (T' = 750), B = 3 processed in passes of 2: frame_sim within
+    1e-4 of the CPU oracle (log-mel -> Cnn8Rnn eval -> audio_proj; CLAP tower -> text_proj; DotProduct) and
+    bit-exact integer segments."""
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import Cnn8RnnLaionClapGroundingModel
+    from texttoaudiogrounding_amd.utils import eval_util
+    S = 960000
+    st_a = O.init_state(seed=31, add_proj=True, shared_dim=512, logit_gain=40.0)
+    st_t = C.init_text_state(seed=6)
+    st_a["audio_proj.weight"] = st_a["audio_proj.weight"] * 8.0        # spread the logits over several units
+    st_a["text_proj.weight"] = st_a["text_proj.weight"] * 30.0
+    batch = O.synthetic_batch(3, S, seed=41, ragged=True)
+    ids, mask = C.synthetic_tokens(3, 10, seed=2)
+    model = Cnn8RnnLaionClapGroundingModel(max_clips_per_pass=2)
+    sd = {}
+    for k, v in st_a.items():
+        if k.startswith("text_encoder."):
+            continue
+        sd["model." + k] = v
+    sd.update({"model.text_encoder." + k: v for k, v in st_t.items()})
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+    assert all("melspec" in k or k.endswith(("position_ids", "token_type_ids")) for k in missing.missing_keys), missing
+    model = model.to(dev)
+    # calibrate the running statistics (momentum 1 on one training-mode pass of the audio encoder), then eval
+    enc = model.model.audio_encoder
+    enc.train()
+    enc.dropout_p = (0.0, 0.0)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():
+        enc({"waveform": batch["waveform"][:2].to(dev), "waveform_len": batch["waveform_len"][:2], "specaug": False})
+    model.eval()
+    fs = model(batch["waveform"], batch["waveform_len"], {"input_ids": ids, "attention_mask": mask}).cpu()
+    assert fs.shape == (3, 750)
+    # ---- CPU oracle on the same (calibrated) weights ----
+    st2 = {k[len("model."):]: v.detach().cpu() for k, v in model.state_dict().items() if "melspec" not in k}
+    audio = O.cnn8rnn_forward({k: v for k, v in st2.items() if k.startswith("audio_encoder.")}, batch["waveform"],
+                              batch["waveform_len"], training=False)["embedding"]
+    a = F.linear(audio, st2["audio_proj.weight"], st2["audio_proj.bias"])
+    tx = C.laion_clap_encoder_forward({k[len("text_encoder."):]: v for k, v in st2.items() if k.startswith("text_encoder.")},
+                                      ids, mask, 12, 1e-12)
+    t = F.linear(tx["seq_emb"], st2["text_proj.weight"], st2["text_proj.bias"])
+    ref = O.match_dot_product(a, t)
+    err = (fs - ref).abs().max().item()
+    print(f"30 s clips: frame_sim err {err:.2e}; range [{ref.min():.3f}, {ref.max():.3f}]")
+    assert err < 1e-4
+    th = eval_util.eval_thresholds(50)
+    got = eval_util.segments_for_thresholds(fs.to(dev), th, 1, eval_util.n_connect_for(0.04))
+    for b in range(3):
+        for ti, tt in enumerate(th):
+            assert np.array_equal(got[b][ti], O.segments(fs[b].numpy(), tt, 1, 13))

@@ -64,9 +64,17 @@ struct Stage {
     }
 };
 
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+    if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 4) return tanhf(v);
+    return v;
+}
+
 struct Epilogue {
     const float* bias;
-    int act;          // 0 none, 1 relu, 2 sigmoid().clamp(1e-7, 1)
+    int act;          // 0 none, 1 relu, 2 sigmoid().clamp(1e-7, 1), 3 gelu (erf form), 4 tanh
     int accumulate;
     float alpha;      // scales the product before bias/act
     int scatter;      // 1: align layout: row = (b,t), col = (b2,n) -> out[b][b2][t][n]
@@ -174,8 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                     o = (size_t)m * ldc + n;
                 }
                 if (ep.accumulate) v += C[o];
-                if (ep.act == 1) v = fmaxf(v, 0.0f);
-                else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+                v = apply_act(v, ep.act);
                 C[o] = v;
             }
         }
@@ -192,8 +199,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         float v = s * ep.alpha + (ep.bias ? ep.bias[n] : 0.0f);
         const size_t o = (size_t)m * ldc + n;
         if (ep.accumulate) v += C[o];
-        if (ep.act == 1) v = fmaxf(v, 0.0f);
-        else if (ep.act == 2) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
+        v = apply_act(v, ep.act);
         C[o] = v;
     }
 }
@@ -345,7 +351,7 @@ extern "C" size_t tag_gemm_ws_bytes(int M, int N, int K) {
 extern "C" int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                         int M, int N, int K, const float* bias, int act, int accumulate, void* ws, void* stream) {
     TAG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
-    TAG_CHECK_ARG(act == 0 || act == 1);
+    TAG_CHECK_ARG(act == 0 || act == 1 || act == 3 || act == 4);
     Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
     launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();

@@ -70,6 +70,9 @@ _SIGS = {
     "tag_align_dot_dscore": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_l2norm_rows_forward": (c_int, [P, P, c_long, c_int, P]),
     "tag_l2norm_rows_backward": (c_int, [P, P, P, c_long, c_int, P]),
+    "tag_roberta_embed_ln": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
+    "tag_add_layernorm": (c_int, [P, P, P, P, c_float, P, c_long, c_int, P]),
+    "tag_mha_small": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),

@@ -1,0 +1,201 @@
+"""Inference wrapper (mirror of models/hf_modeling_grounding.py:97-352 in the reference, BASELINE config 5):
+Cnn8Rnn audio encoder + LAION-CLAP text tower + audio/text projections + DotProduct, forward only, on the HIP path.
+
+Differences forced by the environment, not by design:
+* the reference builds its text tower with ``ClapModel.from_pretrained("laion/clap-htsat-fused")`` and tokenises with
+  ``AutoTokenizer`` -- both need the network.  Here ``LaionClapEncoder`` is built from a configuration (RoBERTa-base
+  shape by default) with the SAME module / state-dict names as ``ClapModel.text_model`` + ``ClapModel.text_projection``,
+  so a downloaded checkpoint loads with ``load_state_dict``; ``forward`` takes ``input_ids`` / ``attention_mask``
+  (what the tokenizer would return).
+* no ``transformers`` import: the classes are plain ``nn.Module`` holders of the parameters; the arithmetic runs in
+  libtag_hip.so (tag_roberta_embed_ln, tag_gemm with bias/GELU/tanh/ReLU epilogues, tag_mha_small, tag_add_layernorm,
+  tag_l2norm_rows_forward).
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib import call, ptr
+from .audio_encoder import Cnn8Rnn  # noqa: F401  (same encoder as the training path; re-exported like the reference)
+from .audio_text_model import BiEncoder  # noqa: F401
+from .match import DotProduct  # noqa: F401
+
+#: ClapTextConfig defaults of "laion/clap-htsat-fused" (RoBERTa-base + 512-d projection)
+CLAP_TEXT_DEFAULTS = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                          intermediate_size=3072, max_position_embeddings=514, projection_dim=512, layer_norm_eps=1e-12,
+                          pad_token_id=1)
+
+
+class _Holder(nn.Module):
+    """Parameter container with free-form children (names mirror the Hugging Face module tree)."""
+
+
+def _text_model(cfg):
+    D, I = cfg["hidden_size"], cfg["intermediate_size"]
+    m = _Holder()
+    m.embeddings = _Holder()
+    m.embeddings.word_embeddings = nn.Embedding(cfg["vocab_size"], D, padding_idx=cfg["pad_token_id"])
+    m.embeddings.token_type_embeddings = nn.Embedding(1, D)
+    m.embeddings.position_embeddings = nn.Embedding(cfg["max_position_embeddings"], D, padding_idx=cfg["pad_token_id"])
+    m.embeddings.LayerNorm = nn.LayerNorm(D, eps=cfg["layer_norm_eps"])
+    # index buffers some transformers versions keep in the state dict (unused by the HIP path)
+    m.embeddings.register_buffer("position_ids", torch.arange(cfg["max_position_embeddings"]).unsqueeze(0))
+    m.embeddings.register_buffer("token_type_ids", torch.zeros(1, cfg["max_position_embeddings"], dtype=torch.long))
+    m.encoder = _Holder()
+    layers = []
+    for _ in range(cfg["num_hidden_layers"]):
+        lyr = _Holder()
+        lyr.attention = _Holder()
+        lyr.attention.self = _Holder()
+        lyr.attention.self.query, lyr.attention.self.key, lyr.attention.self.value = (nn.Linear(D, D) for _ in range(3))
+        lyr.attention.output = _Holder()
+        lyr.attention.output.dense = nn.Linear(D, D)
+        lyr.attention.output.LayerNorm = nn.LayerNorm(D, eps=cfg["layer_norm_eps"])
+        lyr.intermediate = _Holder()
+        lyr.intermediate.dense = nn.Linear(D, I)
+        lyr.output = _Holder()
+        lyr.output.dense = nn.Linear(I, D)
+        lyr.output.LayerNorm = nn.LayerNorm(D, eps=cfg["layer_norm_eps"])
+        layers.append(lyr)
+    m.encoder.layer = nn.ModuleList(layers)
+    m.pooler = _Holder()
+    m.pooler.dense = nn.Linear(D, D)
+    return m
+
+
+class LaionClapEncoder(nn.Module):
+    """models/hf_modeling_grounding.py:183-199.  ``forward(input_dict)`` with keys ``input_ids`` / ``attention_mask``
+    (B, L <= 64) -> ``{"seq_emb": (B, P) L2-normalised, "token_emb": (B, L, P)}``.  Inference only."""
+
+    def __init__(self, model_type: Optional[str] = None, config: Optional[dict] = None):
+        super().__init__()
+        cfg = dict(CLAP_TEXT_DEFAULTS)
+        cfg.update(config or {})
+        self.config = cfg
+        self.model_type = model_type            # kept for interface parity; weights come from load_state_dict
+        self.model = _text_model(cfg)
+        self.projection = _Holder()
+        self.projection.linear1 = nn.Linear(cfg["hidden_size"], cfg["projection_dim"])
+        self.projection.linear2 = nn.Linear(cfg["projection_dim"], cfg["projection_dim"])
+        self.embed_dim = cfg["projection_dim"]
+        self._qkv = None
+
+    def _apply(self, fn, *a, **k):              # .to(device) / .float(): drop the packed q|k|v weights
+        self._qkv = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._qkv = None
+        state_dict = dict(state_dict)
+        for name in ("model.embeddings.position_ids", "model.embeddings.token_type_ids"):   # optional in checkpoints
+            state_dict.setdefault(name, self.state_dict()[name])
+        return super().load_state_dict(state_dict, *a, **k)
+
+    def _packed_qkv(self):
+        if self._qkv is None:
+            self._qkv = []
+            for lyr in self.model.encoder.layer:
+                s = lyr.attention.self
+                self._qkv.append((torch.cat([s.query.weight, s.key.weight, s.value.weight], 0).detach().contiguous(),
+                                  torch.cat([s.query.bias, s.key.bias, s.value.bias], 0).detach().contiguous()))
+        return self._qkv
+
+    @torch.no_grad()
+    def forward(self, input_dict: Dict):
+        ids = input_dict["input_ids"].long()
+        mask = input_dict["attention_mask"].long()
+        dev = self.projection.linear1.weight.device
+        ids, mask = ids.to(dev).contiguous(), mask.to(dev).contiguous()
+        B, L = ids.shape
+        if L > 64:
+            raise ValueError("tag_mha_small handles phrases of at most 64 tokens")
+        cfg = self.config
+        D, H = cfg["hidden_size"], cfg["num_attention_heads"]
+        eps, M = float(cfg["layer_norm_eps"]), B * L
+        emb = self.model.embeddings
+        h = torch.empty(M, D, device=dev, dtype=torch.float32)
+        call("tag_roberta_embed_ln", ptr(ids), ptr(emb.word_embeddings.weight), ptr(emb.token_type_embeddings.weight),
+             ptr(emb.position_embeddings.weight), ptr(emb.LayerNorm.weight), ptr(emb.LayerNorm.bias), eps, ptr(h), B, L,
+             D, int(cfg["pad_token_id"]))
+        for lyr, (wqkv, bqkv) in zip(self.model.encoder.layer, self._packed_qkv()):
+            qkv = ops.gemm(h, wqkv, M, 3 * D, D, transB=True, bias=bqkv)
+            att = torch.empty(M, D, device=dev, dtype=torch.float32)
+            call("tag_mha_small", ptr(qkv), ptr(mask), ptr(att), B, L, H, D // H)
+            ao = lyr.attention.output
+            a = ops.gemm(att, ao.dense.weight, M, D, D, transB=True, bias=ao.dense.bias)
+            h1 = torch.empty_like(h)
+            call("tag_add_layernorm", ptr(a), ptr(h), ptr(ao.LayerNorm.weight), ptr(ao.LayerNorm.bias), eps, ptr(h1), M, D)
+            inter = lyr.intermediate.dense
+            f = ops.gemm(h1, inter.weight, M, inter.weight.shape[0], D, transB=True, bias=inter.bias, act=3)
+            od = lyr.output
+            f2 = ops.gemm(f, od.dense.weight, M, D, inter.weight.shape[0], transB=True, bias=od.dense.bias)
+            h = torch.empty_like(h1)
+            call("tag_add_layernorm", ptr(f2), ptr(h1), ptr(od.LayerNorm.weight), ptr(od.LayerNorm.bias), eps, ptr(h), M, D)
+        pd = self.model.pooler.dense
+        pooled = ops.gemm(h, pd.weight, B, D, D, transB=True, lda=L * D, bias=pd.bias, act=4)     # rows = h[:, 0]
+        p1, p2 = self.projection.linear1, self.projection.linear2
+        P = p1.weight.shape[0]
+
+        def proj(x, rows):
+            t = ops.gemm(x, p1.weight, rows, P, D, transB=True, bias=p1.bias, act=1)
+            return ops.gemm(t, p2.weight, rows, P, P, transB=True, bias=p2.bias)
+
+        token_emb = proj(h, M).view(B, L, P)
+        seq = proj(pooled, B)
+        seq_emb = torch.empty_like(seq)
+        call("tag_l2norm_rows_forward", ptr(seq), ptr(seq_emb), B, P)
+        return {"seq_emb": seq_emb, "token_emb": token_emb, "last_hidden_state": h.view(B, L, D), "pooler_output": pooled}
+
+
+class Cnn8RnnLaionClapGroundingConfig:
+    """models/hf_modeling_grounding.py:296-306 (a plain object here: no PretrainedConfig / network)."""
+
+    def __init__(self, sample_rate: int = 32000, shared_dim: int = 512, text_encoder_name: str = "laion/clap-htsat-fused",
+                 text_config: Optional[dict] = None, **kwargs):
+        self.sample_rate = sample_rate
+        self.shared_dim = shared_dim
+        self.text_encoder_name = text_encoder_name
+        self.text_config = text_config
+
+
+class Cnn8RnnLaionClapGroundingModel(nn.Module):
+    """models/hf_modeling_grounding.py:319-352.  ``forward(audio, audio_len, text)``: ``text`` is the tokenizer output
+    (dict with ``input_ids`` and ``attention_mask``) -- the reference tokenises strings itself, which needs the
+    network-fetched tokenizer.  Returns frame_sim (B, T')."""
+
+    def __init__(self, config: Optional[Cnn8RnnLaionClapGroundingConfig] = None, max_clips_per_pass: int = 64):
+        super().__init__()
+        config = config or Cnn8RnnLaionClapGroundingConfig()
+        self.config = config
+        self.model = BiEncoder(audio_encoder=Cnn8Rnn(sample_rate=config.sample_rate),
+                               text_encoder=LaionClapEncoder(config.text_encoder_name, config.text_config),
+                               match_fn=DotProduct(), shared_dim=config.shared_dim, add_proj=True)
+        self.max_clips_per_pass = max_clips_per_pass
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @torch.no_grad()
+    def forward(self, audio: torch.Tensor, audio_len, text: Dict):
+        dev = self.device
+        if isinstance(text, (list, tuple)) and text and isinstance(text[0], str):
+            raise NotImplementedError("pass the tokenizer output (input_ids, attention_mask): the tokenizer of "
+                                      "laion/clap-htsat-fused cannot be fetched without network access")
+        audio = audio.to(dev)
+        B = audio.shape[0]
+        ids, mask = text["input_ids"], text["attention_mask"]
+        audio_len = torch.as_tensor(audio_len)
+        outs = []
+        # batches are processed in passes: the conv kernels index activations with 32-bit byte offsets
+        # (B * F * 64 * 64 * 4 B < 4 GiB) and the persistent GRU holds <= 128 sequences per launch
+        frames = audio.shape[1] // self.model.audio_encoder.hop_length + 1
+        per_pass = max(1, min(self.max_clips_per_pass, (2 ** 32 - 1) // (frames * 64 * 64 * 4)))
+        for b0 in range(0, B, per_pass):
+            sl = slice(b0, min(B, b0 + per_pass))
+            d = {"waveform": audio[sl], "waveform_len": audio_len[sl], "input_ids": ids[sl], "attention_mask": mask[sl],
+                 "text_len": mask[sl].sum(-1), "specaug": False}
+            outs.append(self.model(d)["frame_sim"])
+        return torch.cat(outs, 0)

@@ -408,7 +408,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         rnn = p[28:36]
         drop = mod.dropout_p if training else (0.0, 0.0)
         seeds = [new_seed() for _ in range(5)] if training and (drop[0] > 0 or drop[1] > 0) else [0] * 5
-        saved = {}
+        need_grad = any(ctx.needs_input_grad[2:])
 
         lm = logmel(wave, mod.n_fft, mod.win_length, mod.hop_length, mod.window, mod.mel_fb)   # (B,F,64)
         B, Fr, NM = lm.shape
@@ -433,14 +433,14 @@ class Cnn8RnnFunction(torch.autograd.Function):
                           blk.bn2.momentum)
             ph, pw = CNN8_POOLS[i]
             xo = bnact_pool(y2, s2, ph, pw, act=1, pool=0, drop_p=drop[0], seed=seeds[i])
-            acts.append((x, y1, s1, y2, s2, wd1, wd2))
+            if need_grad:                      # inference: intermediates die here (30 s clips x 64 are GBs per layer)
+                acts.append((x, y1, s1, y2, s2, wd1, wd2))
             x = xo
         Bx, Tp, Wp, C = x.shape
         xm = _empty(Bx * Tp, C, like=x)
         call("tag_mean_w_forward", ptr(x), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(xm))
         M = Bx * Tp
         fc = gemm(xm, fc_w, M, fc_w.shape[0], C, transB=True, bias=fc_b, act=1)
-        need_grad = any(ctx.needs_input_grad[2:])
         y, gsave = gru_bidir_forward(fc, rnn, Bx, Tp, need_grad)
         if need_grad:
             ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gsave=gsave, p=p, drop=drop,

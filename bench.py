@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
                          "(the contract's number); x3 = opt-in 3 x bf16 split on the bf16 MFMA (conv_x3.hip)")
@@ -154,7 +155,7 @@ def main():
         ops.WGRAD_SIDE_STREAM = True
     # ---- the same K steps with the opt-in conv arithmetic (reported beside the contract's number, never as `value`)
     alt = None
-    if args.conv_math == "fp32":
+    if args.conv_math == "fp32" and not args.no_alt:
         ops.CONV_MATH = "x3"
         runner.train_step(dict(batch))
         sync()

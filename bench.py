@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
-    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3"],
+    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
                          "(the contract's number); x3 = opt-in 3 x bf16 split on the bf16 MFMA (conv_x3.hip)")
     args = ap.parse_args()
@@ -156,22 +156,27 @@ def main():
     # ---- the same K steps with the opt-in conv arithmetic (reported beside the contract's number, never as `value`)
     alt = None
     if args.conv_math == "fp32" and not args.no_alt:
-        ops.CONV_MATH = "x3"
-        runner.train_step(dict(batch))
-        sync()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
+        alt = {}
+        desc = {"x3": "fp32 operands split exactly into 3 bf16 terms, 6 partial products on v_mfma_f32_32x32x16_bf16, f32 "
+                      "accumulate (forward, dgrad and wgrad convs; same parity tolerances as fp32; opt-in TAG_CONV_MATH=x3)",
+                "bf16": "conv operands rounded to bf16, one product, f32 accumulate (BASELINE configs[2] arithmetic for the "
+                        "convs; everything else f32; TAG_CONV_MATH=bf16)"}
+        for mode in ("x3", "bf16"):
+            ops.CONV_MATH = mode
             runner.train_step(dict(batch))
-        sync()
-        dta = time.perf_counter() - ta
+            sync()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                runner.train_step(dict(batch))
+            sync()
+            dta = time.perf_counter() - ta
+            if world > 1:
+                t = torch.tensor([dta], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dta = t.item()
+            alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
+                         "ms_per_step": round(dta / args.steps * 1e3, 3)}
         ops.CONV_MATH = "fp32"
-        if world > 1:
-            t = torch.tensor([dta], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dta = t.item()
-        alt = {"conv_math": "x3: fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
-                            "v_mfma_f32_32x32x16_bf16, f32 accumulate (forward, dgrad and wgrad convs; opt-in, TAG_CONV_MATH=x3)",
-               "value": round(clips / dta, 2), "unit": "clips/s", "ms_per_step": round(dta / args.steps * 1e3, 3)}
     dom = max(fam, key=lambda k: fam[k]["flop"]) if fam else None
     roof = None
     if dom:
@@ -187,7 +192,8 @@ def main():
                 traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
                                     for v in rows) / n, 3)
         # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
-        peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / 6.0, 1)
+        nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(args.conv_math, 6.0)
+        peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / nprod, 1)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC)",
                 "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
@@ -202,7 +208,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
-               "dtype": "f32" if args.conv_math == "fp32" else "f32 (conv fwd/dgrad products as 3 x bf16 split, f32 acc)",
+               "dtype": {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
+                   args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)"),
                "data": "synthetic",
                "config": {"workload": "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "
                                       "fwd+bwd+clip+Adam, dropout on, train-mode BN", "batch_per_gpu": args.batch,

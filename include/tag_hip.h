@@ -92,17 +92,20 @@ int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const 
  *   wfwd / wdgrad: tag_conv3x3_x3_pack_bytes(Cin, Cout) bytes each (pre-split, MFMA-fragment order).
  *   Requires W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0. */
 size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout);
+/* products: partial products per fp32 multiply -- 6 (default), 9 (all), 1 (plain bf16: operands rounded to nearest
+ * bf16, one product; BASELINE configs[2] arithmetic), 0 = process default (TAG_X3_PRODUCTS, else 6).  A weight pack
+ * made with products == 1 must only be used with products == 1 (its hi plane is rounded, not truncated). */
 int tag_pack_conv_weight_x3(const float* w /*(Cout,Cin,3,3)*/, void* wfwd, void* wdgrad, int Cin, int Cout,
-                            void* stream);
+                            int products, void* stream);
 int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                            const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                           void* stream);
+                           int products, void* stream);
 /* wgrad with the same arithmetic (K = pixels; operands fetched with the transposing LDS read ds_read_b64_tr_b16).
  * Requires W in {8,16,32,64}, Cin % 64 == 0, Cout % 64 == 0; ws: tag_conv3x3_wgrad_x3_ws_bytes. */
 size_t tag_conv3x3_wgrad_x3_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* in_scale, const float* in_shift,
                          const float* dy, float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout,
-                         void* ws, void* stream);
+                         int products, void* ws, void* stream);
 /* dw (Cout,Cin,3,3) = sum over pixels of prologue(x)[shifted] * dy ; ws from *_ws_bytes */
 size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift,

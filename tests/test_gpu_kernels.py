@@ -184,6 +184,34 @@ def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert e_f < 5e-6 and (e_d is None or e_d < 5e-6) and (e_w is None or e_w < 5e-6)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 32, 64, 64), (1, 17, 16, 64, 128), (2, 250, 8, 256, 512), (2, 500, 32, 128, 128)])
+def test_conv3x3_bf16_mode(ops, dev, B, H, W, Cin, Cout):
+    """CONV_MATH = "bf16" (BASELINE configs[2] arithmetic): operands rounded to nearest bf16, ONE product per multiply on the
+    bf16 MFMA, fp32 accumulation -> must equal the convolution of the bf16-rounded operands to fp32 round-off."""
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    xb, wb, dyb = x.bfloat16().double(), w.bfloat16().double(), dy.bfloat16().double()
+    y_ref = F.conv2d(xb, wb, None, 1, 1)
+    da_ref = torch.nn.grad.conv2d_input(x.shape, wb, dyb, 1, 1)
+    dw_ref = torch.nn.grad.conv2d_weight(xb, w.shape, dyb, 1, 1)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = "bf16"
+    try:
+        wf, wdg = ops.pack_conv_weight(w.to(dev), W=W)
+        assert wf.products == 1
+        e_f = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), wf, Cout)), y_ref)
+        e_d = relerr(nchw(ops.conv3x3(nhwc(dy).to(dev), wdg, Cin)), da_ref)
+        e_w = relerr(ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev)), dw_ref)
+    finally:
+        ops.CONV_MATH = old
+    e_vs_fp32 = relerr(y_ref, F.conv2d(x.double(), w.double(), None, 1, 1))
+    print(f"bf16 conv {B}x{H}x{W} {Cin}->{Cout}: vs bf16-rounded operands fwd {e_f:.2e} dgrad {e_d:.2e} wgrad {e_w:.2e}; "
+          f"(bf16 rounding itself moves the result by {e_vs_fp32:.2e})")
+    assert e_f < 5e-6 and e_d < 5e-6 and e_w < 5e-6
+
+
 @pytest.mark.parametrize("B,H", [(2, 21), (3, 1001)])
 def test_conv3x3_c1(ops, dev, B, H):
     g = torch.Generator().manual_seed(7)

@@ -88,6 +88,26 @@ def test_golden_eval(dev, golden_dir, conv_math):
     assert logit_err < 2e-3        # logits span +-3.3
 
 
+def test_golden_eval_bf16_conv_math(dev, golden_dir):
+    """BASELINE configs[2] arithmetic for the convolutions (operands rounded to bf16, fp32 accumulate, everything else
+    fp32): the frame probabilities stay within bf16 tolerance of the fp64 golden values."""
+    from texttoaudiogrounding_amd import ops
+    gold = np.load(f"{golden_dir}/cnn8rnn_dot_eval.npz")
+    model = build_hip_model(gold_state(gold), "dot", dev).eval()
+    batch = make_batch(320)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = "bf16"
+    try:
+        with torch.no_grad():
+            out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"],
+                         "text": batch["text"], "text_len": batch["text_len"], "specaug": False})
+    finally:
+        ops.CONV_MATH = old
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    print(f"bf16 conv math: frame_sim err {fs_err:.2e}")
+    assert 1e-6 < fs_err < 3e-2         # visibly bf16 (not silently the fp32 path), yet within bf16 tolerance
+
+
 def test_golden_train_step_grads(dev, golden_dir, conv_math):
     """Train-mode BN, dropout off: loss, frame_sim, running stats and every parameter gradient
     against the reference's fp64 twin.  Gradient tolerance is per tensor, normalised by max|g|:

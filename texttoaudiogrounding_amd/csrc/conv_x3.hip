@@ -69,9 +69,17 @@ __device__ __forceinline__ float prologue1(float v, int mode, float s, float t) 
     return v;
 }
 
-// exact three-way split of two floats into packed bf16 pairs (low half = first value)
+// exact three-way split of two floats into packed bf16 pairs (low half = first value).  RNE = true (plain-bf16 mode,
+// one product): only the hi plane is used and it is rounded to nearest-even instead of truncated.
+__device__ __forceinline__ unsigned bf16_rne_bits(unsigned u) { return u + 0x7fffu + ((u >> 16) & 1u); }
+template <bool RNE = false>
 __device__ __forceinline__ void split_pack(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned ab = __float_as_uint(a), bb = __float_as_uint(b);
+    if (RNE) {
+        h = __builtin_amdgcn_perm(bf16_rne_bits(bb), bf16_rne_bits(ab), 0x07060302u);
+        m = l = 0u;
+        return;
+    }
     const float a1 = a - __uint_as_float(ab & 0xffff0000u), b1 = b - __uint_as_float(bb & 0xffff0000u);
     const unsigned a1b = __float_as_uint(a1), b1b = __float_as_uint(b1);
     const float a2 = a1 - __uint_as_float(a1b & 0xffff0000u), b2 = b1 - __uint_as_float(b1b & 0xffff0000u);
@@ -165,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
             v.w = prologue1(ra[i].w, PRO, rs.w, rt.w);
             if (!((pvalid >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack(v.x, v.y, h0_, m0_, l0_);
-            split_pack(v.z, v.w, h1_, m1_, l1_);
+            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
             unsigned char* dst = smem + (pr * G::S + pc) * PIXB + q * 8;
             *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
             if (NSPL == 3) {
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
 // (K = Cout, N = Cin, taps mirrored).  Fragment (tap, kk, nb, s) = 64 lanes x 16 B at
 // ((((tap*K/16 + kk) * N/32 + nb) * 3 + s) * 64 + lane); lane holds k = kk*16 + 8*(lane>>5) + e, n = nb*32 + (lane&31).
 __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wf,
-                                                             u32x4* __restrict__ wd, int Cin, int Cout) {
+                                                             u32x4* __restrict__ wd, int Cin, int Cout, int rne) {
     const long per_dir = (long)9 * (Cin / 16) * (Cout / 32) * 64;         // == 9 * (Cout/16) * (Cin/32) * 64
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < 2 * per_dir; idx += (long)gridDim.x * 256) {
         const bool dg = idx >= per_dir;
@@ -292,7 +300,8 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __rest
                 const int k = k0 + 2 * e + j;
                 v[j] = dg ? w[((size_t)k * Cin + nn) * 9 + (8 - tap)] : w[((size_t)nn * Cin + k) * 9 + tap];
             }
-            split_pack(v[0], v[1], h[e], m[e], l[e]);
+            if (rne) split_pack<true>(v[0], v[1], h[e], m[e], l[e]);
+            else split_pack<false>(v[0], v[1], h[e], m[e], l[e]);
         }
         u32x4* dst = (dg ? wd : wf) + ((((size_t)tap * (K / 16) + kk) * (N / 32) + nb) * 3) * 64 + lane;
         dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
@@ -408,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
             v.w = prologue1(rx[i].w, PRO, rs.w, rt.w);
             if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack(v.x, v.y, h0_, m0_, l0_);
-            split_pack(v.z, v.w, h1_, m1_, l1_);
+            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
             unsigned char* dst = Xs + qoff * G::XPL + (slot * PW + pc) * 64 + qbyte;
             *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
             if (NSPL == 3) {
@@ -438,8 +447,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
             f32x4 v = rd[i];
             if (!((dok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack(v.x, v.y, h0_, m0_, l0_);
-            split_pack(v.z, v.w, h1_, m1_, l1_);
+            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
             unsigned char* dst = Ys + buf * G::YBYTES + qoff * G::YPL + k * 64 + qbyte;
             *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
             if (NSPL == 3) {
@@ -610,7 +619,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
     }
 }
 
-static int x3_products() {
+// products per fp32 multiply: 6 (default), 9 (every partial product), 1 (plain bf16, hi plane rounded to nearest);
+// 0 = the process default (environment TAG_X3_PRODUCTS, else 6)
+static int x3_products(int requested) {
+    if (requested == 1 || requested == 6 || requested == 9) return requested;
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("TAG_X3_PRODUCTS");
@@ -695,18 +707,20 @@ void launch_wgrad_x3_w(const float* x, int pro, const float* s, const float* t, 
 
 extern "C" size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * 3 * 2; }
 
-extern "C" int tag_pack_conv_weight_x3(const float* w, void* wfwd, void* wdgrad, int Cin, int Cout, void* stream) {
+extern "C" int tag_pack_conv_weight_x3(const float* w, void* wfwd, void* wdgrad, int Cin, int Cout, int products,
+                                       void* stream) {
     TAG_CHECK_ARG(w && wfwd && wdgrad && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0);
     const long n = (long)2 * 9 * (Cin / 16) * (Cout / 32) * 64;
     hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0,
-                       as_stream(stream), w, reinterpret_cast<u32x4*>(wfwd), reinterpret_cast<u32x4*>(wdgrad), Cin, Cout);
+                       as_stream(stream), w, reinterpret_cast<u32x4*>(wfwd), reinterpret_cast<u32x4*>(wdgrad), Cin, Cout,
+                       x3_products(products) == 1 ? 1 : 0);
     TAG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                                       const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                                      void* stream) {
+                                      int products, void* stream) {
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
@@ -715,7 +729,7 @@ extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int pro
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
     const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
-    const int np = x3_products();
+    const int np = x3_products(products);
 #define BY_NP(MB)                                                                                        \
     if (np == 6) launch_x3_w<MB, 6>(x, wp, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);     \
     else if (np == 9) launch_x3_w<MB, 9>(x, wp, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
@@ -732,8 +746,8 @@ extern "C" size_t tag_conv3x3_wgrad_x3_ws_bytes(int B, int H, int W, int Cin, in
 }
 
 extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* in_scale, const float* in_shift,
-                                    const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
-                                    void* stream) {
+                                    const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int products,
+                                    void* ws, void* stream) {
     TAG_CHECK_ARG(x && dy && dw && ws && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && prologue >= 0 && prologue <= 3);
@@ -744,7 +758,7 @@ extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* i
     hipStream_t st = as_stream(stream);
     int cps;
     const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps);
-    const int np = x3_products();
+    const int np = x3_products(products);
     if (np == 6) launch_wgrad_x3_w<6>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else if (np == 9) launch_wgrad_x3_w<9>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else launch_wgrad_x3_w<1>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);

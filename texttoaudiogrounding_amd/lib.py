@@ -30,10 +30,10 @@ _SIGS = {
     "tag_pack_conv_weight": (c_int, [P, P, P, c_int, c_int, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_x3_pack_bytes": (c_size_t, [c_int, c_int]),
-    "tag_pack_conv_weight_x3": (c_int, [P, P, P, c_int, c_int, P]),
-    "tag_conv3x3_forward_x3": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_pack_conv_weight_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "tag_conv3x3_forward_x3": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_wgrad_x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "tag_conv3x3_wgrad_x3": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_wgrad_x3": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "tag_conv3x3_wgrad": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_c1_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

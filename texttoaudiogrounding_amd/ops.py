@@ -105,13 +105,23 @@ def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     return st
 
 
-# Arithmetic of the 3x3 convolutions (forward + dgrad): "fp32" = exact fp32 MFMA (default); "x3" = fp32 operands split
-# exactly into 3 bf16 terms, 6 partial products on the bf16 MFMA, fp32 accumulate (conv_x3.hip; opt-in).
+# Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "fp32" = exact fp32 MFMA (default); opt-in, on the bf16
+# MFMA with fp32 accumulation (conv_x3.hip): "x3" = fp32 operands split exactly into 3 bf16 terms, 6 partial products;
+# "x9" = all 9 partial products; "bf16" = operands rounded to bf16, one product (BASELINE configs[2] arithmetic).
 CONV_MATH = os.environ.get("TAG_CONV_MATH", "fp32")
+_X3_PRODUCTS = {"x3": 6, "x9": 9, "bf16": 1}
 
 
 def _x3_ok(W, K, N):
-    return CONV_MATH == "x3" and W in (8, 16, 32, 64) and K % 32 == 0 and N % 64 == 0
+    return CONV_MATH in _X3_PRODUCTS and W in (8, 16, 32, 64) and K % 32 == 0 and N % 64 == 0
+
+
+class _X3Pack:
+    """Weight pack of the bf16-MFMA kernels: the byte blob + the product count it was made for."""
+    dtype = torch.uint8
+
+    def __init__(self, blob, products):
+        self.blob, self.products = blob, products
 
 
 def pack_conv_weight(w, want_dgrad=True, W=None):
@@ -124,8 +134,9 @@ def pack_conv_weight(w, want_dgrad=True, W=None):
         nbytes = query("tag_conv3x3_x3_pack_bytes", Cin, Cout)
         xf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         xd = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        call("tag_pack_conv_weight_x3", ptr(w), ptr(xf), ptr(xd), Cin, Cout)
-        wf, wd = (xf if fx3 else None), (xd if dx3 else None)
+        npr = _X3_PRODUCTS[CONV_MATH]
+        call("tag_pack_conv_weight_x3", ptr(w), ptr(xf), ptr(xd), Cin, Cout, npr)
+        wf, wd = (_X3Pack(xf, npr) if fx3 else None), (_X3Pack(xd, npr) if dx3 else None)
     if wf is None or (want_dgrad and wd is None):
         pf = _empty(9, Cin, Cout, like=w)
         pd = _empty(9, Cout, Cin, like=w) if want_dgrad else None
@@ -140,8 +151,8 @@ def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
     y = _empty(B, H, W, Cout, like=x)
     if wpack.dtype == torch.uint8:
         with _timed(("conv3x3_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
-            call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W, Cin,
-                 Cout)
+            call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W,
+                 Cin, Cout, wpack.products)
         return y
     kname = "conv3x3_halo_kernel" if W in (8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
     with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
@@ -153,11 +164,11 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     dw = _empty(Cout, Cin, 3, 3, like=x)
-    if CONV_MATH == "x3" and W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0:
+    if CONV_MATH in _X3_PRODUCTS and W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0:
         ws = _ws(query("tag_conv3x3_wgrad_x3_ws_bytes", B, H, W, Cin, Cout), x)
         with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
             call("tag_conv3x3_wgrad_x3", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
-                 ptr(ws))
+                 _X3_PRODUCTS[CONV_MATH], ptr(ws))
         return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     kname = "conv3x3_wgrad_alltaps_kernel" if W in (8, 16, 32, 64) else "conv3x3_wgrad_kernel"

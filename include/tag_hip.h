@@ -174,7 +174,7 @@ int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p
  *   op(A): transA ? A^T : A, A stored (M,K) ld=lda or (K,M) when transA; same for B (K,N)/(N,K).
  * Serves nn.Linear fc1 / audio_proj / text_proj (models/audio_encoder.py:140,216;
  * models/audio_text_model.py:45-46,78-87), the GRU input projections and all their backward GEMMs.
- * act: 0 none, 1 relu, 3 gelu (erf form), 4 tanh.  bias (N) nullable.
+ * act: 0 none, 1 relu, 3 gelu (erf form), 4 tanh, 5 sigmoid.  bias (N) nullable.
  * ------------------------------------------------------------------------------------------- */
 /* ws (nullable): scratch of tag_gemm_ws_bytes(M,N,K) bytes enabling a deterministic split-K for problems whose
  * MxN tile count cannot fill the chip (weight gradients: K = B*T); 0 bytes = not needed. */
@@ -292,6 +292,34 @@ int tag_add_layernorm(const float* x, const float* res, const float* gamma, cons
  * dh in {16,32,64}; mask (B,L) int64 (0 = padded key) */
 int tag_mha_small(const float* qkv, const long* mask, float* out /*(B*L, heads*dh)*/, int B, int L, int heads,
                   int dh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BASELINE configs[3]: cross-encoder (models/cross_encoder.py:5-79) + token-level DotProduct (models/match.py:43-60).
+ * Seq2SeqAttention's Linear over the concatenation [query ; kv] is applied as two tag_gemm calls
+ * (aq = query Wq^T (B,T,Da), ak = kv Wk^T + b (B,L,Da)); these entries do the rest.  L <= 32 tokens.
+ * ------------------------------------------------------------------------------------------- */
+/* score = v . tanh(aq[b,q] + ak[b,k]); rows q >= qlen[b] and columns k >= klen[b] filled with -1e10; attn = softmax_k;
+ * ctx = attn @ kv (B,T,Dk) */
+int tag_addattn_forward(const float* aq, const float* ak, const float* v, const float* kv /*(B,L,Dk)*/,
+                        const long* qlen, const long* klen, float* attn /*(B,T,L)*/, float* ctx, int B, int T, int L,
+                        int Da, int Dk, void* stream);
+size_t tag_addattn_backward_ws_bytes(int B, int T, int L, int Da, int Dk);
+/* given dctx: daq (B,T,Da), dak (B,L,Da), dkv (B,L,Dk) (the attn @ kv term only), dv (Da); deterministic */
+int tag_addattn_backward(const float* aq, const float* ak, const float* v, const float* kv, const float* attn,
+                         const float* dctx, const long* qlen, const long* klen, float* daq, float* dak, float* dkv,
+                         float* dv, int B, int T, int L, int Da, int Dk, void* ws, void* stream);
+/* CrossGating pieces (models/cross_encoder.py:51-57): out = a * b; backward of out = x * g, g = sigmoid(z):
+ * dx (+)= dout * g, dz = dout * x * g * (1 - g).  n % 4 == 0 */
+int tag_mul(const float* a, const float* b, float* out, long n, void* stream);
+int tag_gate_backward(const float* dout, const float* x, const float* g, float* dx, int accumulate, float* dz, long n,
+                      void* stream);
+/* DotProduct with text_level="token" after a cross-encoder: sim[r] = sigmoid(a[r].b[r] [/sqrt(D)]).clamp(1e-7, 1) */
+int tag_rowdot_sigmoid_forward(const float* a, const float* b, float* sim, long rows, int D, int scale, void* stream);
+int tag_rowdot_sigmoid_backward(const float* a, const float* b, const float* dsim, float* da, float* db, long rows,
+                                int D, int scale, void* stream);
+/* dtable[text[b,l]] += dtok[b,l,:] (token_emb gradient of EmbeddingLayer, models/text_encoder.py:37-43) */
+int tag_embed_tokens_backward(const float* dtok, const long* text, float* dtable, int B, int L, int D, int V,
+                              void* stream);
 
 #ifdef __cplusplus
 }

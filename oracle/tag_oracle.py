@@ -581,3 +581,53 @@ def segments(frame_sim_row: np.ndarray, threshold, window_size: int, n_connect: 
 def eval_thresholds(n_thresholds: int = 50) -> np.ndarray:
     """run_strong.py:203-205."""
     return np.arange(1 / (n_thresholds * 2), 1, 1 / n_thresholds)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: cross-encoder (models/cross_encoder.py:5-79) plugged into BiEncoder (models/audio_text_model.py:
+# 74-77) with match.DotProduct(text_level="token") (models/match.py:43-60)
+# ---------------------------------------------------------------------------------------------------------------
+def seq2seq_attention(st, query, kv, query_len, kv_len, prefix="cross_encoder.attn."):
+    """Seq2SeqAttention.forward (models/cross_encoder.py:12-42): additive attention of every audio frame over the phrase
+    tokens.  score[b,q,k] = v . tanh(W [query[b,q] ; kv[b,k]] + bias), rows q >= query_len and columns k >= kv_len filled
+    with -1e10, softmax over k, out = attn @ kv.  W = h2attn.weight (D_attn, D_q + D_kv) is applied as two products."""
+    W, b, v = st[prefix + "h2attn.weight"], st[prefix + "h2attn.bias"], st[prefix + "v"]
+    dq = query.shape[-1]
+    aq = F.linear(query, W[:, :dq])                                   # (B,Tq,Da)
+    ak = F.linear(kv, W[:, dq:], b)                                   # (B,Lk,Da)
+    score = (torch.tanh(aq.unsqueeze(2) + ak.unsqueeze(1)) * v).sum(-1)          # (B,Tq,Lk)
+    Tq, Lk = query.shape[1], kv.shape[1]
+    qm = torch.arange(Tq)[None, :] < torch.as_tensor(query_len).view(-1, 1)
+    km = torch.arange(Lk)[None, :] < torch.as_tensor(kv_len).view(-1, 1)
+    score = score.masked_fill(~qm.unsqueeze(-1), -1e10).masked_fill(~km.unsqueeze(1), -1e10)
+    attn = torch.softmax(score, dim=-1)
+    return torch.bmm(attn, kv)
+
+
+def cross_attention_gating(st, audio_emb, token_emb, audio_len, text_len, prefix="cross_encoder."):
+    """CrossAttentionGating.forward (models/cross_encoder.py:67-79): text <- attention(audio -> tokens); then CrossGating
+    (:51-57): s_out = s * sigmoid(fc_u(u)), u_out = u * sigmoid(fc_s(s)) with u = audio, s = attended text."""
+    s = seq2seq_attention(st, audio_emb, token_emb, audio_len, text_len, prefix + "attn.")
+    g_u = torch.sigmoid(F.linear(audio_emb, st[prefix + "gating.fc_u.weight"], st[prefix + "gating.fc_u.bias"]))
+    g_s = torch.sigmoid(F.linear(s, st[prefix + "gating.fc_s.weight"], st[prefix + "gating.fc_s.bias"]))
+    return audio_emb * g_s, s * g_u
+
+
+def match_dot_product_token(audio, text, scale=True):
+    """match.DotProduct with text_level='token' after a cross-encoder: text is (B,T,D), one vector per frame."""
+    score = (audio * text).sum(-1)
+    if scale:
+        score = score / math.sqrt(audio.size(-1))
+    return torch.sigmoid(score).clamp(1e-7, 1.0)
+
+
+def init_cross_state(seed, dim=512, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / math.sqrt(2 * dim)
+    u = lambda *s, a=1.0: (torch.rand(*s, generator=g) * 2 - 1) * a
+    return {"cross_encoder.attn.h2attn.weight": u(dim, 2 * dim, a=k * scale), "cross_encoder.attn.h2attn.bias": u(dim, a=k),
+            "cross_encoder.attn.v": torch.randn(dim, generator=g),
+            "cross_encoder.gating.fc_u.weight": u(dim, dim, a=scale / math.sqrt(dim)),
+            "cross_encoder.gating.fc_u.bias": u(dim, a=1 / math.sqrt(dim)),
+            "cross_encoder.gating.fc_s.weight": u(dim, dim, a=scale / math.sqrt(dim)),
+            "cross_encoder.gating.fc_s.bias": u(dim, a=1 / math.sqrt(dim))}

@@ -69,12 +69,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 2) return fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
     if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (act == 4) return tanhf(v);
+    if (act == 5) return 1.0f / (1.0f + expf(-v));
     return v;
 }
 
 struct Epilogue {
     const float* bias;
-    int act;          // 0 none, 1 relu, 2 sigmoid().clamp(1e-7, 1), 3 gelu (erf form), 4 tanh
+    int act;          // 0 none, 1 relu, 2 sigmoid().clamp(1e-7, 1), 3 gelu (erf form), 4 tanh, 5 sigmoid
     int accumulate;
     float alpha;      // scales the product before bias/act
     int scatter;      // 1: align layout: row = (b,t), col = (b2,n) -> out[b][b2][t][n]
@@ -351,7 +352,7 @@ extern "C" size_t tag_gemm_ws_bytes(int M, int N, int K) {
 extern "C" int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                         int M, int N, int K, const float* bias, int act, int accumulate, void* ws, void* stream) {
     TAG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
-    TAG_CHECK_ARG(act == 0 || act == 1 || act == 3 || act == 4);
+    TAG_CHECK_ARG(act == 0 || act == 1 || act == 3 || act == 4 || act == 5);
     Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
     launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();

@@ -73,6 +73,14 @@ _SIGS = {
     "tag_roberta_embed_ln": (c_int, [P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
     "tag_add_layernorm": (c_int, [P, P, P, P, c_float, P, c_long, c_int, P]),
     "tag_mha_small": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_addattn_forward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_addattn_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "tag_addattn_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "tag_mul": (c_int, [P, P, P, c_long, P]),
+    "tag_gate_backward": (c_int, [P, P, P, P, c_int, P, c_long, P]),
+    "tag_rowdot_sigmoid_forward": (c_int, [P, P, P, c_long, c_int, c_int, P]),
+    "tag_rowdot_sigmoid_backward": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
+    "tag_embed_tokens_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),

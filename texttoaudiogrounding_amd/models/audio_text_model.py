@@ -13,14 +13,12 @@ class BiEncoder(nn.Module):
                  freeze_audio_encoder: bool = False, freeze_text_encoder: bool = False,
                  pretrained: Optional[str] = None):
         super().__init__()
-        if cross_encoder is not None:
-            raise NotImplementedError("cross_encoder (BASELINE config 4) is outside the round-1 hot path")
         if upsample:
             raise NotImplementedError("upsample=True is off in every strong eg_config and not on the HIP path")
         self.audio_encoder = audio_encoder
         self.text_encoder = text_encoder
         self.match_fn = match_fn
-        self.cross_encoder = None
+        self.cross_encoder = cross_encoder
         if audio_encoder.embed_dim != text_encoder.embed_dim or add_proj:
             self.audio_proj = nn.Linear(audio_encoder.embed_dim, shared_dim)
             self.text_proj = nn.Linear(text_encoder.embed_dim, shared_dim)
@@ -51,11 +49,18 @@ class BiEncoder(nn.Module):
         forward_dict = {"audio_emb": audio_emb, "text_emb": text_emb, "audio_len": audio_output["length"]}
         if "text_len" in input_dict:
             forward_dict["text_len"] = input_dict["text_len"]
+        if self.cross_encoder is not None:
+            forward_dict.update(self.cross_encoder(forward_dict))
+            text_emb = forward_dict["text_emb"]
         if hasattr(self, "audio_proj"):
             forward_dict["audio_emb"] = ops.LinearFunction.apply(forward_dict["audio_emb"], self.audio_proj.weight,
                                                                  self.audio_proj.bias)
-            text_emb["seq_emb"] = ops.LinearFunction.apply(text_emb["seq_emb"], self.text_proj.weight,
-                                                           self.text_proj.bias)
-            # token_emb is not projected: no HIP head consumes it on this path (text_level='seq')
+            if "seq_emb" in text_emb:
+                text_emb["seq_emb"] = ops.LinearFunction.apply(text_emb["seq_emb"], self.text_proj.weight,
+                                                               self.text_proj.bias)
+            if self.cross_encoder is not None and "token_emb" in text_emb:
+                text_emb["token_emb"] = ops.LinearFunction.apply(text_emb["token_emb"], self.text_proj.weight,
+                                                                 self.text_proj.bias)
+            # without a cross-encoder token_emb is not projected: no head consumes it (text_level='seq')
         frame_sim = self.match_fn(forward_dict)
         return {"frame_sim": frame_sim, "length": audio_output["length"]}

@@ -29,5 +29,12 @@ class DotProduct(nn.Module):
         self.text_level = text_level
 
     def forward(self, input_dict):
+        if self.text_level == "token":
+            # after a cross-encoder the text is one vector per frame (B,T,D): (audio * text).sum(-1)  (models/match.py:53-59)
+            text = input_dict["text_emb"]["token_emb"]
+            if self.l2norm or text.shape != input_dict["audio_emb"].shape:
+                raise NotImplementedError("token-level DotProduct is implemented for the cross-encoder output "
+                                          "(text (B,T,D), l2norm=False)")
+            return ops.RowDotFunction.apply(input_dict["audio_emb"], text, self.scale)
         return ops.MatchFunction.apply(input_dict["audio_emb"], _seq_text(input_dict, self.text_level), 0,
                                        self.l2norm, self.scale)

@@ -661,7 +661,8 @@ class LinearFunction(torch.autograd.Function):
 
 
 class EmbedMeanFunction(torch.autograd.Function):
-    """nn.Embedding gather + mean over valid tokens (rows T1/T2)."""
+    """nn.Embedding gather + mean over valid tokens (rows T1/T2).  token_emb is differentiable too (the cross-encoder
+    consumes it): its gradient is a scatter-add into the table (tag_embed_tokens_backward)."""
 
     @staticmethod
     def forward(ctx, table, text, text_len, want_tokens):
@@ -673,17 +674,18 @@ class EmbedMeanFunction(torch.autograd.Function):
         call("tag_embed_mean_forward", ptr(text), ptr(text_len), ptr(tab), ptr(tok), ptr(seq), B, L, D, V)
         ctx.save_for_backward(text, text_len)
         ctx.shape = (B, L, D, V)
-        if want_tokens:
-            ctx.mark_non_differentiable(tok)
-            return seq, tok
-        return seq, None
+        ctx.set_materialize_grads(False)
+        return seq, tok
 
     @staticmethod
-    def backward(ctx, dseq, _dtok):
+    def backward(ctx, dseq, dtok):
         text, text_len = ctx.saved_tensors
         B, L, D, V = ctx.shape
-        dtab = torch.zeros(V, D, device=dseq.device, dtype=F32)
-        call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
+        dtab = torch.zeros(V, D, device=text.device, dtype=F32)
+        if dseq is not None:
+            call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
+        if dtok is not None:
+            call("tag_embed_tokens_backward", ptr(_chk(dtok, "grad")), ptr(text), ptr(dtab), B, L, D, V)
         return dtab, None, None, None
 
 
@@ -786,3 +788,87 @@ def grad_sumsq(flat_grad):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
     call("tag_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, ptr(gnorm_sq),
          float(max_norm), float(grad_scale))
+
+
+class CrossEncoderFunction(torch.autograd.Function):
+    """CrossAttentionGating (models/cross_encoder.py:60-79): additive attention of every frame over the phrase tokens,
+    then sigmoid cross-gating.  inputs audio (B,T,D), token (B,L,D); outputs (u_out, s_out) both (B,T,D).
+    params: h2attn.weight (Da, 2D), h2attn.bias (Da), v (Da), fc_u.{weight,bias}, fc_s.{weight,bias}."""
+
+    @staticmethod
+    def forward(ctx, audio, token, audio_len, text_len, w_h, b_h, v, w_u, b_u, w_s, b_s):
+        a, t = _chk(audio, "audio_emb"), _chk(token, "token_emb")
+        B, T, D = a.shape
+        L, Dk = t.shape[1], t.shape[2]
+        Da = w_h.shape[0]
+        w_h, b_h, v, w_u, b_u, w_s, b_s = (_chk(x.detach(), "parameter") for x in (w_h, b_h, v, w_u, b_u, w_s, b_s))
+        if w_h.shape[1] != D + Dk or w_u.shape != (D, D) or w_s.shape != (Dk, Dk) or D != Dk:
+            raise RuntimeError("CrossAttentionGating: inconsistent dimensions")
+        dev = a.device
+        ql = torch.as_tensor(audio_len).long().to(dev).contiguous()
+        kl = torch.as_tensor(text_len).long().to(dev).contiguous()
+        M = B * T
+        aq = gemm(a, w_h, M, Da, D, transB=True, ldb=D + Dk)
+        ak = gemm(t, w_h[:, D:], B * L, Da, Dk, transB=True, ldb=D + Dk, bias=b_h)
+        attn = _empty(B, T, L, like=a)
+        cx = _empty(B, T, Dk, like=a)
+        call("tag_addattn_forward", ptr(aq), ptr(ak), ptr(v), ptr(t), ptr(ql), ptr(kl), ptr(attn), ptr(cx), B, T, L, Da, Dk)
+        g_u = gemm(a, w_u, M, D, D, transB=True, bias=b_u, act=5)
+        g_s = gemm(cx, w_s, M, Dk, Dk, transB=True, bias=b_s, act=5)
+        u_out, s_out = torch.empty_like(a), torch.empty_like(cx)
+        call("tag_mul", ptr(a), ptr(g_s), ptr(u_out), a.numel())
+        call("tag_mul", ptr(cx), ptr(g_u), ptr(s_out), cx.numel())
+        ctx.save_for_backward(a, t, aq, ak, attn, cx, g_u, g_s, ql, kl, w_h, v, w_u, w_s)
+        return u_out, s_out
+
+    @staticmethod
+    def backward(ctx, du_out, ds_out):
+        a, t, aq, ak, attn, cx, g_u, g_s, ql, kl, w_h, v, w_u, w_s = ctx.saved_tensors
+        B, T, D = a.shape
+        L, Dk = t.shape[1], t.shape[2]
+        Da, M = w_h.shape[0], B * T
+        du_out, ds_out = _chk(du_out, "grad"), _chk(ds_out, "grad")
+        da, dz_s = torch.empty_like(a), torch.empty_like(a)
+        call("tag_gate_backward", ptr(du_out), ptr(a), ptr(g_s), ptr(da), 0, ptr(dz_s), a.numel())       # u_out = a * g_s
+        dcx, dz_u = torch.empty_like(cx), torch.empty_like(cx)
+        call("tag_gate_backward", ptr(ds_out), ptr(cx), ptr(g_u), ptr(dcx), 0, ptr(dz_u), cx.numel())    # s_out = cx * g_u
+        dw_s = gemm(dz_s, cx, Dk, Dk, M, transA=True, lda=Dk)
+        db_s = colsum(dz_s, M, Dk)
+        gemm(dz_s, w_s, M, Dk, Dk, out=dcx, accumulate=True)
+        dw_u = gemm(dz_u, a, D, D, M, transA=True, lda=D)
+        db_u = colsum(dz_u, M, D)
+        gemm(dz_u, w_u, M, D, D, out=da, accumulate=True)
+        daq, dak = _empty(B, T, Da, like=a), _empty(B, L, Da, like=a)
+        dkv, dv = _empty(B, L, Dk, like=a), _empty(Da, like=a)
+        ws = _ws(query("tag_addattn_backward_ws_bytes", B, T, L, Da, Dk), a)
+        call("tag_addattn_backward", ptr(aq), ptr(ak), ptr(v), ptr(t), ptr(attn), ptr(dcx), ptr(ql), ptr(kl), ptr(daq),
+             ptr(dak), ptr(dkv), ptr(dv), B, T, L, Da, Dk, ptr(ws))
+        dw_h = _empty(Da, D + Dk, like=a)
+        gemm(daq, a, Da, D, M, transA=True, lda=Da, out=dw_h, ldc=D + Dk)
+        gemm(dak, t, Da, Dk, B * L, transA=True, lda=Da, out=dw_h[:, D:], ldc=D + Dk)
+        db_h = colsum(dak, B * L, Da)
+        gemm(daq, w_h, M, D, Da, ldb=D + Dk, out=da, accumulate=True)
+        gemm(dak, w_h[:, D:], B * L, Dk, Da, ldb=D + Dk, out=dkv, accumulate=True)
+        return da, dkv, None, None, dw_h, db_h, dv, dw_u, db_u, dw_s, db_s
+
+
+class RowDotFunction(torch.autograd.Function):
+    """match.DotProduct with text_level='token' after a cross-encoder: one text vector per frame (models/match.py:43-60)."""
+
+    @staticmethod
+    def forward(ctx, audio, text, scale):
+        a, t = _chk(audio, "audio_emb"), _chk(text, "token_emb")
+        B, T, D = a.shape
+        sim = _empty(B, T, like=a)
+        call("tag_rowdot_sigmoid_forward", ptr(a), ptr(t), ptr(sim), B * T, D, int(scale))
+        ctx.save_for_backward(a, t)
+        ctx.scale = int(scale)
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t = ctx.saved_tensors
+        B, T, D = a.shape
+        da, dt = torch.empty_like(a), torch.empty_like(t)
+        call("tag_rowdot_sigmoid_backward", ptr(a), ptr(t), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), B * T, D, ctx.scale)
+        return da, dt, None

@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cross-encoder", action="store_true",
+                    help="time BASELINE configs[3] instead: the same biencoder with CrossAttentionGating(512) and the "
+                         "token-level DotProduct (NOT the contract's workload; for DESIGN.md section 10)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
@@ -93,8 +96,14 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     torch.manual_seed(0)
-    model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
-                                       match.DotProduct(), 512)
+    if args.cross_encoder:
+        from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
+        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                           match.DotProduct(text_level="token"), 512,
+                                           cross_encoder=CrossAttentionGating(512))
+    else:
+        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                           match.DotProduct(), 512)
     runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(device))
     batch = synthetic_batch(args.batch, 320000, 1234 + rank, device)
 
@@ -211,8 +220,11 @@ def main():
                "dtype": {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
                    args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)"),
                "data": "synthetic",
-               "config": {"workload": "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "
-                                      "fwd+bwd+clip+Adam, dropout on, train-mode BN", "batch_per_gpu": args.batch,
+               "config": {"workload": ("configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + "
+                                       "match.DotProduct(token), fwd+bwd+clip+Adam, dropout on, train-mode BN"
+                                       if args.cross_encoder else
+                                       "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "
+                                       "fwd+bwd+clip+Adam, dropout on, train-mode BN"), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math},
                "loss": round(float(loss.item()), 6),

@@ -12,10 +12,11 @@
 namespace {
 
 constexpr int MAXL = 32;      // tokens per phrase
-constexpr int QT = 16;        // frames per backward tile
+constexpr int QT = 8;         // frames per backward tile
 constexpr float FILL = -1e10f;
 
-// attn (B,T,L) softmax weights, ctx (B,T,Dk) = attn @ kv
+// attn (B,T,L) softmax weights, ctx (B,T,Dk) = attn @ kv.  LM = compile-time bound on L (scores stay in registers)
+template <int LM>
 __global__ __launch_bounds__(256) void addattn_fwd_kernel(const float* __restrict__ aq, const float* __restrict__ ak,
                                                           const float* __restrict__ v, const float* __restrict__ kv,
                                                           const long* __restrict__ qlen, const long* __restrict__ klen,
@@ -27,10 +28,10 @@ __global__ __launch_bounds__(256) void addattn_fwd_kernel(const float* __restric
     const int b = (int)(row / T), q = (int)(row % T);
     const bool qok = q < qlen[b];
     const int kl = (int)klen[b];
-    float sc[MAXL];                             // fully unrolled below: stays in registers
+    float sc[LM];                               // fully unrolled below: stays in registers
     float mx = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < MAXL; ++k) {
+    for (int k = 0; k < LM; ++k) {
         sc[k] = 0.0f;
         if (k < L) {
             float s = 0.0f;
@@ -43,11 +44,11 @@ __global__ __launch_bounds__(256) void addattn_fwd_kernel(const float* __restric
     }
     float den = 0.0f;
 #pragma unroll
-    for (int k = 0; k < MAXL; ++k)
+    for (int k = 0; k < LM; ++k)
         if (k < L) { sc[k] = expf(sc[k] - mx); den += sc[k]; }
     const float inv = 1.0f / den;
 #pragma unroll
-    for (int k = 0; k < MAXL; ++k)
+    for (int k = 0; k < LM; ++k)
         if (k < L) {
             sc[k] *= inv;
             if (lane == 0) attn[row * L + k] = sc[k];
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void addattn_fwd_kernel(const float* __restric
     for (int d = lane; d < Dk; d += 64) {
         float o = 0.0f;
 #pragma unroll
-        for (int k = 0; k < MAXL; ++k)
+        for (int k = 0; k < LM; ++k)
             if (k < L) o = fmaf(sc[k], kv[((long)b * L + k) * Dk + d], o);
         ctx[row * Dk + d] = o;
     }
@@ -152,11 +153,19 @@ __global__ __launch_bounds__(256) void fold_tiles_kernel(const float* __restrict
 }
 // dv[d] = sum over all (b, tile) of dv_p, fp64, fixed order
 __global__ __launch_bounds__(256) void fold_dv_kernel(const float* __restrict__ part, float* __restrict__ dv, long n, int Da) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= Da) return;
+    // block = 16 columns x 16 row groups; rows folded in fp64 in a fixed order
+    __shared__ double sh[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4, d = blockIdx.x * 16 + c;
     double s = 0.0;
-    for (long r = 0; r < n; ++r) s += (double)part[r * Da + d];
-    dv[d] = (float)s;
+    if (d < Da)
+        for (long r = g; r < n; r += 16) s += (double)part[r * Da + d];
+    sh[g][c] = s;
+    __syncthreads();
+    if (g == 0 && d < Da) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += sh[q][c];
+        dv[d] = (float)t;
+    }
 }
 
 // ---- gating and token-level dot product: rows of D spread over a wave ----
@@ -227,8 +236,11 @@ extern "C" int tag_addattn_forward(const float* aq, const float* ak, const float
                                    void* stream) {
     TAG_CHECK_ARG(aq && ak && v && kv && qlen && klen && attn && ctx && B > 0 && T > 0 && L > 0 && L <= MAXL);
     TAG_CHECK_ARG(Da > 0 && Dk > 0);
-    hipLaunchKernelGGL(addattn_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, as_stream(stream), aq, ak, v, kv, qlen,
-                       klen, attn, ctx, B, T, L, Da, Dk);
+#define LAUNCH(LM)                                                                                                    \
+    hipLaunchKernelGGL(addattn_fwd_kernel<LM>, dim3(cdiv((long)B * T, 4)), dim3(256), 0, as_stream(stream), aq, ak, v, kv, \
+                       qlen, klen, attn, ctx, B, T, L, Da, Dk);
+    if (L <= 4) { LAUNCH(4) } else if (L <= 8) { LAUNCH(8) } else if (L <= 16) { LAUNCH(16) } else { LAUNCH(32) }
+#undef LAUNCH
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -262,7 +274,7 @@ extern "C" int tag_addattn_backward(const float* aq, const float* ak, const floa
                        (long)L * Da);
     hipLaunchKernelGGL(fold_tiles_kernel, dim3(cdiv((long)B * L * Dk, 256)), dim3(256), 0, st, dkv_p, dkv, (long)B, NT,
                        (long)L * Dk);
-    hipLaunchKernelGGL(fold_dv_kernel, dim3(cdiv(Da, 256)), dim3(256), 0, st, dv_p, dv, (long)B * NT, Da);
+    hipLaunchKernelGGL(fold_dv_kernel, dim3(cdiv(Da, 16)), dim3(256), 0, st, dv_p, dv, (long)B * NT, Da);
     TAG_LAUNCH_CHECK();
     return 0;
 }

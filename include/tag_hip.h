@@ -59,6 +59,12 @@ size_t tag_bn_stats_ws_bytes(long rows, int C);
 int tag_bn_stats(const float* x, long rows, int C, int pre_op, const float* gamma, const float* beta,
                  float eps, float momentum, float* running_mean, float* running_var, float* mean,
                  float* invstd, float* scale, float* shift, void* ws, void* stream);
+/* the same outputs from the partial statistics a conv kernel wrote in its epilogue (P rows; layout: see
+ * tag_conv3x3_forward) */
+size_t tag_bn_stats_from_partials_ws_bytes(int P, int C);
+int tag_bn_stats_from_partials(const float* partials, int P, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean,
+                               float* invstd, float* scale, float* shift, void* ws, void* stream);
 /* eval mode: scale/shift from running statistics */
 int tag_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* scale, float* shift,
@@ -81,8 +87,13 @@ int tag_bn_param_grad(const float* x, const float* dy, long rows, int C, const f
  * ------------------------------------------------------------------------------------------- */
 int tag_pack_conv_weight(const float* w /*(Cout,Cin,3,3)*/, float* wfwd /*(9,Cin,Cout)*/,
                          float* wdgrad /*(9,Cout,Cin), nullable*/, int Cin, int Cout, void* stream);
+/* stats (nullable): when given, the kernel also writes BatchNorm partial statistics of y in its epilogue --
+ * tag_conv3x3_stats_rows(B,H,W,Cout) rows of (3*Cout) floats {tile pivot mu, sum(y-mu), sum((y-mu)^2)} followed
+ * by one pixel count per row, i.e. rows*(3*Cout+1) floats; tag_bn_stats_from_partials turns them into
+ * the batch statistics (saves the separate pass over y).  rows == 0: not available for this shape. */
+int tag_conv3x3_stats_rows(int B, int H, int W, int Cout);
 int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
-                        const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                        const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
                         void* stream);
 
 /* Alternative arithmetic for the same convolution (forward and dgrad): every fp32 operand is split exactly into
@@ -97,8 +108,9 @@ size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout);
  * made with products == 1 must only be used with products == 1 (its hi plane is rounded, not truncated). */
 int tag_pack_conv_weight_x3(const float* w /*(Cout,Cin,3,3)*/, void* wfwd, void* wdgrad, int Cin, int Cout,
                             int products, void* stream);
+int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout);      /* same contract as tag_conv3x3_stats_rows */
 int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
-                           const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
+                           const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
                            int products, void* stream);
 /* wgrad with the same arithmetic (K = pixels; operands fetched with the transposing LDS read ds_read_b64_tr_b16).
  * Requires W in {8,16,32,64}, Cin % 64 == 0, Cout % 64 == 0; ws: tag_conv3x3_wgrad_x3_ws_bytes. */

@@ -212,6 +212,38 @@ def test_conv3x3_bf16_mode(ops, dev, B, H, W, Cin, Cout):
     assert e_f < 5e-6 and e_d < 5e-6 and e_w < 5e-6
 
 
+@pytest.mark.parametrize("math_", ["fp32", "x3"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 8, 64, 128), (1, 17, 16, 64, 64), (2, 1001, 64, 64, 64), (3, 250, 8, 256, 512),
+                                            (2, 501, 32, 64, 128)])
+def test_conv3x3_fused_bn_stats(ops, dev, math_, B, H, W, Cin, Cout):
+    """Batch statistics from the conv kernel's epilogue (per-tile sum / squared deviations merged in fp64) == the
+    statistics of the conv output (fp64), incl. ragged last tiles (H not a multiple of the tile height) and a large mean."""
+    g = torch.Generator().manual_seed(H + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g) + 2.0                   # non-zero mean -> cancellation matters
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin) + 0.02
+    w[:3] = w[:3] * 1e-4 + 0.05                                        # channels whose |mean| is ~1e3 x their std
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    rm, rv = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    old = ops.CONV_MATH
+    ops.CONV_MATH = math_
+    try:
+        wf, _ = ops.pack_conv_weight(w.to(dev), W=W)
+        y, part = ops.conv3x3_stats(nhwc(x).to(dev), wf, Cout)
+    finally:
+        ops.CONV_MATH = old
+    assert part is not None
+    rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
+    st = ops.bn_stats(y.view(-1, Cout), gamma.to(dev), beta.to(dev), rmd, rvd, True, partials=part)
+    yd = y.cpu().double().view(-1, Cout)                               # statistics OF THE KERNEL'S OUTPUT
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    n = yd.shape[0]
+    assert relerr(st.mean, mean) < 1e-6
+    assert ((st.invstd.cpu().double() - 1.0 / torch.sqrt(var + 1e-5)).abs() * torch.sqrt(var + 1e-5)).max() < 2e-6   # per channel
+    assert relerr(st.scale, gamma.double() / torch.sqrt(var + 1e-5)) < 2e-6
+    assert relerr(rmd, 0.9 * rm.double() + 0.1 * mean) < 1e-6
+    assert relerr(rvd, 0.9 * rv.double() + 0.1 * var * n / (n - 1)) < 2e-6
+
+
 @pytest.mark.parametrize("B,H", [(2, 21), (3, 1001)])
 def test_conv3x3_c1(ops, dev, B, H):
     g = torch.Generator().manual_seed(7)

@@ -140,6 +140,82 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
     }
 }
 
+// Batch statistics from the per-tile partials the conv kernels write in their epilogue: row p holds, per channel, a
+// pivot mu_p (the tile mean as rounded in fp32), r_p = sum(y - mu_p) and q_p = sum((y - mu_p)^2); cnt[p] = pixels of
+// the tile.  Tile sum s_p = n_p mu_p + r_p, tile M2 = q_p - r_p^2 / n_p; merged in fp64 (Chan et al.) about the pivot
+// K = mu_0:  N var = sum M2_p + sum s_p^2 / n_p - S^2 / N.  Two stages: NCH row chunks -> 4 doubles per (chunk,
+// channel), then one block per 16 channels folds the chunks and writes the BatchNorm outputs.
+constexpr int STAT_MAX_CHUNKS = 256;
+__device__ __forceinline__ void fold16(double (&v)[4], double (*sh)[16][17], int g, int cl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[k][g][cl] = v[k];
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t = 0;
+            for (int q = 0; q < 16; ++q) t += sh[k][q][cl];
+            v[k] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void bn_stats_partials_reduce_kernel(const float* __restrict__ part,
+                                                                      const float* __restrict__ cnt, int P, int C,
+                                                                      int rows_per_chunk, double* __restrict__ out) {
+    __shared__ double sh[4][16][17];
+    const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
+    const int p0 = blockIdx.y * rows_per_chunk, p1 = min(P, p0 + rows_per_chunk);
+    const double K = c < C ? (double)part[c] : 0.0;
+    double v[4] = {0, 0, 0, 0};                       // sum about K, sum s^2/n, sum M2, n
+    if (c < C)
+        for (int p = p0 + g; p < p1; p += 16) {
+            const double np = (double)cnt[p];
+            if (np > 0) {
+                const double rp = (double)part[(size_t)p * 3 * C + C + c];
+                const double sp = np * ((double)part[(size_t)p * 3 * C + c] - K) + rp;
+                v[0] += sp; v[1] += sp * sp / np; v[2] += (double)part[(size_t)p * 3 * C + 2 * C + c] - rp * rp / np; v[3] += np;
+            }
+        }
+    fold16(v, sh, g, cl);
+    if (g == 0 && c < C) {
+        double* o = out + ((size_t)blockIdx.y * C + c) * 4;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+}
+__global__ __launch_bounds__(256) void bn_stats_partials_finalize_kernel(const double* __restrict__ chunks, int nch,
+                                                                        const float* __restrict__ part, int C,
+                                                                        const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, float eps,
+                                                                        float momentum, float* running_mean,
+                                                                        float* running_var, float* mean, float* invstd,
+                                                                        float* scale, float* shift) {
+    __shared__ double sh[4][16][17];
+    const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
+    double v[4] = {0, 0, 0, 0};
+    if (c < C)
+        for (int ch = g; ch < nch; ch += 16) {
+            const double* o = chunks + ((size_t)ch * C + c) * 4;
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+    fold16(v, sh, g, cl);
+    if (g != 0 || c >= C) return;
+    const double a = v[0], bq = v[1], cq = v[2], n = v[3];
+    const double m = (double)part[c] + a / n;
+    double var = (cq + bq - a * a / n) / n;
+    if (var < 0) var = 0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (mean) mean[c] = (float)m;
+    if (invstd) invstd[c] = (float)is;
+    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    if (scale) scale[c] = (float)(gm * is);
+    if (shift) shift[c] = (float)((double)bt - m * (double)gm * is);
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) {
+        const double unb = n > 1 ? var * n / (n - 1) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
 // dgamma / dbeta finalize: partial slot 0 = sum dz, slot 1 = sum dz*xhat
 __global__ __launch_bounds__(256) void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
                                                               float* dgamma, float* dbeta) {
@@ -631,6 +707,33 @@ extern "C" int tag_bn_stats(const float* x, long rows, int C, int pre_op, const 
     TAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk,
                        rows, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int stat_chunks(int P, int* rows_per_chunk) {
+    int r = (P + STAT_MAX_CHUNKS - 1) / STAT_MAX_CHUNKS;
+    if (r < 64) r = 64;
+    *rows_per_chunk = r;
+    return (P + r - 1) / r;
+}
+extern "C" size_t tag_bn_stats_from_partials_ws_bytes(int P, int C) {
+    int r;
+    return (size_t)stat_chunks(P, &r) * C * 4 * sizeof(double);
+}
+extern "C" int tag_bn_stats_from_partials(const float* partials, int P, int C, const float* gamma, const float* beta,
+                                          float eps, float momentum, float* running_mean, float* running_var,
+                                          float* mean, float* invstd, float* scale, float* shift, void* ws,
+                                          void* stream) {
+    TAG_CHECK_ARG(partials && ws && P > 0 && C > 0);
+    int rpc;
+    const int nch = stat_chunks(P, &rpc);
+    double* chunks = static_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_stats_partials_reduce_kernel, dim3(cdiv(C, 16), nch), dim3(256), 0, as_stream(stream), partials,
+                       partials + (size_t)P * 3 * C, P, C, rpc, chunks);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_partials_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), chunks, nch,
+                       partials, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -264,7 +264,8 @@ template <int BN_, int PRO, int TW>
 __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
-                                                              int B, int H, int W, int Cin, int Cout) {
+                                                              float* __restrict__ stats, int B, int H, int W, int Cin,
+                                                              int Cout) {
     using G = HaloGeom<TW>;
     constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = TAG_HALO_NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -440,6 +441,50 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
                 if (h < H && n < Cout) y[(((size_t)img * H + h) * W + w) * Cout + n] = acc[i][j][r];
             }
         }
+    // ---- fused BatchNorm statistics of the output (training): per (64-pixel wave tile, channel) a pivot mu (the tile
+    // mean as rounded in fp32), r = sum(y - mu) and q = sum((y - mu)^2): the tile's sum is n*mu + r EXACTLY up to the
+    // rounding of the small deviations, so channels whose |mean| >> std keep their variance;
+    // tag_bn_stats_from_partials merges the tiles in fp64 ----
+    if (stats) {
+        const int prow = mt * 2 + (wid >> 1);                        // partial row of this wave
+        float* ps = stats + (size_t)prow * 3 * Cout;
+        float cnt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cnt += (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H ? 1.0f : 0.0f;
+        cnt += __shfl_xor(cnt, 32, 64);
+        const float rc = 1.0f / fmaxf(cnt, 1.0f);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H;
+                    s1 += ok ? acc[i][j][r] : 0.0f;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = s1 * rc;
+            float r1 = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H;
+                    const float d = ok ? acc[i][j][r] - mu : 0.0f;
+                    r1 += d;
+                    q = fmaf(d, d, q);
+                }
+            r1 += __shfl_xor(r1, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            const int n = n0 + wn0 + j * 32 + ml;
+            if (kl == 0 && n < Cout) { ps[n] = mu; ps[Cout + n] = r1; ps[2 * Cout + n] = q; }
+        }
+        if (n0 == 0 && wn0 == 0 && lane == 0) stats[(size_t)m_tiles * 2 * 3 * Cout + prow] = cnt;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1257,8 +1302,8 @@ static int launch_fwd(const float* x, const float* wp, int pro, const float* s, 
 }
 
 template <int BN_, int TW>
-static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, int B, int H,
-                        int W, int Cin, int Cout, hipStream_t st) {
+static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, float* stats,
+                        int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = HaloGeom<TW>;
     const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
     const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + TAG_HALO_NB * BK * BN_ + 2 * 512) * sizeof(float);
@@ -1270,8 +1315,8 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, B, H, \
-                           W, Cin, Cout);                                                                         \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
+                           B, H, W, Cin, Cout);                                                                   \
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;
@@ -1282,9 +1327,18 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 #undef LAUNCH_PRO
 }
 
+// rows of BatchNorm partial statistics the forward kernel writes when asked to (one per 64-pixel wave tile);
+// 0 = this shape is served by a kernel without the fused statistics
+extern "C" int tag_conv3x3_stats_rows(int B, int H, int W, int Cout) {
+    (void)Cout;
+    if (!(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64))) return 0;
+    const int th = 128 / W;
+    return B * ((H + th - 1) / th) * 2;
+}
+
 extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
-                                   const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                                   void* stream) {
+                                   const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin,
+                                   int Cout, void* stream) {
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0 && W > 0);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
     TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside the kernel
@@ -1292,11 +1346,12 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
     const bool halo = conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64);
-#define HALO_BY_W(BN_)                                                                                   \
-    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);        \
-    else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
-    else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
-    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
+    TAG_CHECK_ARG(stats == nullptr || halo);
+#define HALO_BY_W(BN_)                                                                                          \
+    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);        \
+    else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st); \
+    else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st); \
+    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);
     if (halo) {
         if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
     } else if (Cout >= 128) {

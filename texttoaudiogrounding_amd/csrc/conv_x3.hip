@@ -98,7 +98,8 @@ template <int MB, int PRO, int TW, int NP>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, float* __restrict__ y,
-                                                            int B, int H, int W, int Cin, int Cout) {
+                                                            float* __restrict__ stats, int B, int H, int W, int Cin,
+                                                            int Cout) {
     using G = X3Geom<TW>;
     constexpr int BN_ = MB == 4 ? 128 : 64;
     constexpr int NSPL = NP == 1 ? 1 : 3;                         // planes actually read
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
 
     // ---- epilogue: D col = lane&31 (cout), D row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel via row_to_pix ----
     const int n = n0 + wn * 32 + ml;
+    bool okrow[MB][16];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -272,8 +274,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
             int ty, tx;
             pix_to_yx<TW>((wm * MB + i) * 32 + row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl), ty, tx);
             const int h = h0 + ty;
+            okrow[i][r] = h < H;
             if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
         }
+    // ---- fused BatchNorm statistics (see conv.hip): one partial row per wave M-group (MB * 32 pixels) ----
+    if (stats) {
+        constexpr int MG = MB == 4 ? 1 : 2;
+        const int prow = mt * MG + wm;
+        float* ps = stats + (size_t)prow * 3 * Cout;
+        float cnt = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cnt += okrow[i][r] ? 1.0f : 0.0f; s1 += okrow[i][r] ? acc[i][r] : 0.0f; }
+        cnt += __shfl_xor(cnt, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mu = s1 / fmaxf(cnt, 1.0f);
+        float r1 = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = okrow[i][r] ? acc[i][r] - mu : 0.0f;
+                r1 += d;
+                q = fmaf(d, d, q);
+            }
+        r1 += __shfl_xor(r1, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (kl == 0) { ps[n] = mu; ps[Cout + n] = r1; ps[2 * Cout + n] = q; }
+        if (n0 == 0 && wn == 0 && lane == 0) stats[(size_t)m_tiles * MG * 3 * Cout + prow] = cnt;
+    }
 }
 
 // (Cout,Cin,3,3) fp32 -> split bf16 planes in B-fragment order, for forward (K = Cin, N = Cout) and dgrad
@@ -633,8 +663,8 @@ static int x3_products(int requested) {
 }
 
 template <int MB, int TW, int NP>
-void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, int B, int H, int W,
-               int Cin, int Cout, hipStream_t st) {
+void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, float* stats, int B,
+               int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = X3Geom<TW>;
     constexpr int BN_ = MB == 4 ? 128 : 64;
     const int grid = B * ((H + G::TH - 1) / G::TH) * (Cout / BN_);
@@ -647,8 +677,8 @@ void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const f
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, B, H, \
-                           W, Cin, Cout);                                                                           \
+        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
+                           B, H, W, Cin, Cout);                                                                     \
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;
@@ -660,12 +690,12 @@ void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const f
 }
 
 template <int MB, int NP>
-void launch_x3_w(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, int B, int H, int W,
-                 int Cin, int Cout, hipStream_t st) {
-    if (W == 8) launch_x3<MB, 8, NP>(x, wp, pro, s, t, y, B, H, W, Cin, Cout, st);
-    else if (W == 16) launch_x3<MB, 16, NP>(x, wp, pro, s, t, y, B, H, W, Cin, Cout, st);
-    else if (W == 32) launch_x3<MB, 32, NP>(x, wp, pro, s, t, y, B, H, W, Cin, Cout, st);
-    else launch_x3<MB, 64, NP>(x, wp, pro, s, t, y, B, H, W, Cin, Cout, st);
+void launch_x3_w(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, float* stats, int B,
+                 int H, int W, int Cin, int Cout, hipStream_t st) {
+    if (W == 8) launch_x3<MB, 8, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else if (W == 16) launch_x3<MB, 16, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else if (W == 32) launch_x3<MB, 32, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else launch_x3<MB, 64, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
 }
 
 template <int TW, int NP>
@@ -718,9 +748,15 @@ extern "C" int tag_pack_conv_weight_x3(const float* w, void* wfwd, void* wdgrad,
     return 0;
 }
 
+extern "C" int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout) {
+    if (!(W == 8 || W == 16 || W == 32 || W == 64)) return 0;
+    const int th = 128 / W;
+    return B * ((H + th - 1) / th) * (Cout % 128 == 0 ? 1 : 2);
+}
+
 extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
-                                      const float* in_shift, float* y, int B, int H, int W, int Cin, int Cout,
-                                      int products, void* stream) {
+                                      const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin,
+                                      int Cout, int products, void* stream) {
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
@@ -731,9 +767,9 @@ extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int pro
     const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
     const int np = x3_products(products);
 #define BY_NP(MB)                                                                                        \
-    if (np == 6) launch_x3_w<MB, 6>(x, wp, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);     \
-    else if (np == 9) launch_x3_w<MB, 9>(x, wp, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st); \
-    else launch_x3_w<MB, 1>(x, wp, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
+    if (np == 6) launch_x3_w<MB, 6>(x, wp, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);     \
+    else if (np == 9) launch_x3_w<MB, 9>(x, wp, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st); \
+    else launch_x3_w<MB, 1>(x, wp, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);
     if (Cout % 128 == 0) { BY_NP(4) } else { BY_NP(2) }
 #undef BY_NP
     TAG_LAUNCH_CHECK();

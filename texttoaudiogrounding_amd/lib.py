@@ -28,10 +28,14 @@ _SIGS = {
     "tag_affine_forward": (c_int, [P, c_long, c_int, P, P, P, P]),
     "tag_bn_param_grad": (c_int, [P, P, c_long, c_int, P, P, P, P, P, P]),
     "tag_pack_conv_weight": (c_int, [P, P, P, c_int, c_int, P]),
-    "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "tag_bn_stats_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
+    "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
+    "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_x3_pack_bytes": (c_size_t, [c_int, c_int]),
     "tag_pack_conv_weight_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-    "tag_conv3x3_forward_x3": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_forward_x3": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_wgrad_x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "tag_conv3x3_wgrad_x3": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -82,8 +82,10 @@ class BNStat:
     __slots__ = ("mean", "invstd", "scale", "shift", "train")
 
 
-def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, pre_op=0) -> BNStat:
-    """x2d: (rows, C) view of a channels-last tensor."""
+def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, pre_op=0,
+             partials=None) -> BNStat:
+    """x2d: (rows, C) view of a channels-last tensor.  partials = (P, buffer) from conv3x3(..., want_stats=True): the batch
+    statistics come from the conv kernel's epilogue instead of another pass over x2d."""
     rows, C = x2d.shape
     st = BNStat()
     st.train = bool(training)
@@ -92,9 +94,14 @@ def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     if training:
         st.mean = _empty(C, like=x2d)
         st.invstd = _empty(C, like=x2d)
-        ws = _ws(query("tag_bn_stats_ws_bytes", rows, C), x2d)
-        call("tag_bn_stats", ptr(x2d), rows, C, pre_op, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
-             ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
+        if partials is not None and pre_op == 0:
+            ws = _ws(query("tag_bn_stats_from_partials_ws_bytes", partials[0], C), x2d)
+            call("tag_bn_stats_from_partials", ptr(partials[1]), partials[0], C, ptr(gamma), ptr(beta), eps, momentum,
+                 ptr(running_mean), ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
+        else:
+            ws = _ws(query("tag_bn_stats_ws_bytes", rows, C), x2d)
+            call("tag_bn_stats", ptr(x2d), rows, C, pre_op, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+                 ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws))
     else:
         call("tag_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, C, ptr(st.scale),
              ptr(st.shift))
@@ -146,18 +153,36 @@ def pack_conv_weight(w, want_dgrad=True, W=None):
     return wf, (wd if want_dgrad else None)
 
 
+FUSE_BN_STATS = os.environ.get("TAG_FUSE_BN_STATS", "1") != "0"
+
+
 def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
+    """y = conv(prologue(x))."""
+    return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False)[0]
+
+
+def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats=True):
+    """(y, partials): y = conv(prologue(x)) and, when want_stats, the BatchNorm partial statistics of y that the kernel
+    writes in its epilogue ((P, buffer), or None when this shape has no fused statistics) -> bn_stats(..., partials=...)."""
     B, H, W, Cin = x.shape
     y = _empty(B, H, W, Cout, like=x)
-    if wpack.dtype == torch.uint8:
+    x3 = wpack.dtype == torch.uint8
+    part = None
+    if want_stats and FUSE_BN_STATS:
+        P = query("tag_conv3x3_x3_stats_rows" if x3 else "tag_conv3x3_stats_rows", B, H, W, Cout)
+        if P > 0:
+            part = (P, _empty(P * (3 * Cout + 1), like=x))
+    sp = ptr(part[1]) if part else None
+    if x3:
         with _timed(("conv3x3_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
-            call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W,
+            call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H, W,
                  Cin, Cout, wpack.products)
-        return y
-    kname = "conv3x3_halo_kernel" if W in (8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
-    with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
-        call("tag_conv3x3_forward", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout)
-    return y
+    else:
+        kname = "conv3x3_halo_kernel" if W in (8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
+        with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_forward", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H, W, Cin,
+                 Cout)
+    return y, part
 
 
 def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None):
@@ -431,17 +456,17 @@ class Cnn8RnnFunction(torch.autograd.Function):
             blk = getattr(mod, f"conv_block{i + 1}")
             if i == 0:
                 y1 = conv3x3_c1(lm, c1w, st0.scale, st0.shift)
-                wf1 = wd1 = None
+                wf1 = wd1 = part1 = None
             else:
                 wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
-                y1 = conv3x3(x, wf1, c1w.shape[0])
+                y1, part1 = conv3x3_stats(x, wf1, c1w.shape[0], want_stats=bn_train)
             Bx, H, W, C = y1.shape
             s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
-                          blk.bn1.momentum)
+                          blk.bn1.momentum, partials=part1)
             wf2, wd2 = pack_conv_weight(c2w, W=y1.shape[2])
-            y2 = conv3x3(y1, wf2, C, prologue=1, scale=s1.scale, shift=s1.shift)
+            y2, part2 = conv3x3_stats(y1, wf2, C, prologue=1, scale=s1.scale, shift=s1.shift, want_stats=bn_train)
             s2 = bn_stats(y2.view(-1, C), g2, b2, blk.bn2.running_mean, blk.bn2.running_var, bn_train, blk.bn2.eps,
-                          blk.bn2.momentum)
+                          blk.bn2.momentum, partials=part2)
             ph, pw = CNN8_POOLS[i]
             xo = bnact_pool(y2, s2, ph, pw, act=1, pool=0, drop_p=drop[0], seed=seeds[i])
             if need_grad:                      # inference: intermediates die here (30 s clips x 64 are GBs per layer)

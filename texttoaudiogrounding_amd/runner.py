@@ -64,7 +64,15 @@ class StrongRunner:
     # Runner.forward (run_strong.py:92-120)
     def forward(self, batch: Dict, training: bool = True):
         for k, v in batch.items():
-            if isinstance(v, torch.Tensor):
+            if k in ("waveform_len", "text_len"):
+                # small integer arrays: staged through pinned memory so that no copy blocks the host mid-step (a
+                # pageable host->device copy waits for the stream to drain); everything downstream (frame lengths,
+                # masks) then stays on the device
+                if not (isinstance(v, torch.Tensor) and v.is_cuda):
+                    v = torch.as_tensor(v).long()
+                    v = (v.pin_memory() if self.device.type == "cuda" else v).to(self.device, non_blocking=True)
+                batch[k] = v.long()
+            elif isinstance(v, torch.Tensor):
                 batch[k] = v.long().to(self.device) if k == "text" else v.float().to(self.device)
         input_dict = {"specaug": False}
         input_dict.update(batch)

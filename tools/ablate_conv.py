@@ -22,7 +22,7 @@ for n, label in VARIANTS.items():
                            os.path.join(CSRC, "tag_lib.hip"), "-o", so], stderr=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     P, I = ctypes.c_void_p, ctypes.c_int
-    lib.tag_conv3x3_forward.argtypes = [P, P, I, P, P, P, I, I, I, I, I, P]
+    lib.tag_conv3x3_forward.argtypes = [P, P, I, P, P, P, P, I, I, I, I, I, P]
     lib.tag_pack_conv_weight.argtypes = [P, P, P, I, I, P]
     line = f"{label:34s}"
     for (B, H, W, Cin, Cout) in shapes:
@@ -32,7 +32,7 @@ for n, label in VARIANTS.items():
         y = torch.empty(B, H, W, Cout, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         lib.tag_pack_conv_weight(w.data_ptr(), wf.data_ptr(), None, Cin, Cout, st)
-        run = lambda: lib.tag_conv3x3_forward(x.data_ptr(), wf.data_ptr(), 0, None, None, y.data_ptr(), B, H, W, Cin, Cout, st)
+        run = lambda: lib.tag_conv3x3_forward(x.data_ptr(), wf.data_ptr(), 0, None, None, y.data_ptr(), None, B, H, W, Cin, Cout, st)
         for _ in range(5):
             run()
         torch.cuda.synchronize()

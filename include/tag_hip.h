@@ -333,6 +333,22 @@ int tag_rowdot_sigmoid_backward(const float* a, const float* b, const float* dsi
 int tag_embed_tokens_backward(const float* dtok, const long* text, float* dtable, int B, int L, int D, int V,
                               void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Weak supervision (next row of the scope table): MultiTextBiEncoder (models/audio_text_model.py:101-229) -- N phrases
+ * per clip scored against the SAME audio embedding (no (B*N,T,D) expansion), pooled by linear_softmax_with_lens
+ * (models/utils.py:75-76); ClipBceLoss (losses.py:38-43) is tag_frame_bce_* over the (B,N) clip matrix.
+ * ------------------------------------------------------------------------------------------- */
+/* sim[(b*N+n), t] = sigmoid(audio[b,t] . text[b*N+n] [/sqrt(D)]).clamp(1e-7,1);  N <= 16 in backward */
+int tag_match_group_forward(const float* audio /*(B,T,D)*/, const float* text /*(B*N,D)*/, float* sim /*(B*N,T)*/,
+                            int scale, int B, int N, int T, int D, void* stream);
+int tag_match_group_backward(const float* audio, const float* text, const float* dsim, float* daudio /*(B,T,D)*/,
+                             float* dtext /*(B*N,D)*/, int scale, int B, int N, int T, int D, void* stream);
+/* clip[r] = sum_{t<len} f^2 / sum_{t<len} f over rows of frame probabilities (rows, T); len = length[r / group] */
+int tag_linear_softmax_pool_forward(const float* fs, const long* length, float* clip, long rows, int T, int group,
+                                    void* stream);
+int tag_linear_softmax_pool_backward(const float* fs, const long* length, const float* dclip, float* dfs, long rows,
+                                     int T, int group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -631,3 +631,29 @@ def init_cross_state(seed, dim=512, scale=1.0):
             "cross_encoder.gating.fc_u.bias": u(dim, a=1 / math.sqrt(dim)),
             "cross_encoder.gating.fc_s.weight": u(dim, dim, a=scale / math.sqrt(dim)),
             "cross_encoder.gating.fc_s.bias": u(dim, a=1 / math.sqrt(dim))}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Weak supervision: MultiTextBiEncoder head (models/audio_text_model.py:150-215),
+# linear_softmax_with_lens (models/utils.py:22-40,75-76) and ClipBceLoss (losses.py:38-43)
+# ---------------------------------------------------------------------------------------------------------------
+def linear_softmax_with_lens(features, lens):
+    """features (B,T,...) -> sum_{t<len} f^2 / sum_{t<len} f."""
+    lens = torch.as_tensor(lens)
+    mask = (torch.arange(features.shape[1])[None, :] < lens.view(-1, 1)).to(features.dtype)
+    while mask.ndim < features.ndim:
+        mask = mask.unsqueeze(-1)
+    return (features * features * mask).sum(1) / (features * mask).sum(1)
+
+
+def multitext_head(audio_emb, seq_emb, length, n_text, scale=True):
+    """audio (B,T,D), seq_emb (B*N,D): expand the audio per phrase, DotProduct(seq), reshape to (B,T,N), pool."""
+    B, T, D = audio_emb.shape
+    a = audio_emb.unsqueeze(1).expand(-1, n_text, -1, -1).reshape(B * n_text, T, D)
+    fs = match_dot_product(a, seq_emb, scale=scale)                       # (B*N, T)
+    frame_sim = fs.reshape(B, n_text, T).transpose(1, 2)                 # (B, T, N)
+    return frame_sim, linear_softmax_with_lens(frame_sim, length)
+
+
+def clip_bce_loss(clip_sim, label):
+    return F.binary_cross_entropy(clip_sim, label)

@@ -1,0 +1,96 @@
+"""Weak-supervision callers of the hot-path kernels: MultiTextBiEncoder head chain --
+grouped DotProduct, linear_softmax pooling, ClipBceLoss -- against the imported reference's outputs
+(tests/golden/weak_heads.npz) and, at B=64 x 8 phrases x T'=250, against the fp64 oracle; plus the whole model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def head_chain(audio, text, length, label, N, dev):
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.losses import ClipBceLoss
+    a = audio.to(dev).requires_grad_(True)
+    t = text.to(dev).requires_grad_(True)
+    B = a.shape[0]
+    sim = ops.MatchGroupFunction.apply(a, t, N, True)
+    clip = ops.LinearSoftmaxPoolFunction.apply(sim, length.long().to(dev), N).view(B, N)
+    loss = ClipBceLoss()({"clip_sim": clip, "label": label.to(dev)})
+    loss.backward()
+    return sim.view(B, N, -1).transpose(1, 2), clip, loss, a.grad, t.grad
+
+
+def rel(got, want):
+    want = torch.as_tensor(want).double()
+    return (got.detach().cpu().double() - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+
+
+def test_weak_heads_golden(dev, golden_dir):
+    g = np.load(f"{golden_dir}/weak_heads.npz")
+    fs, clip, loss, da, dt = head_chain(torch.from_numpy(g["audio"]), torch.from_numpy(g["text"]), torch.from_numpy(g["length"]),
+                                        torch.from_numpy(g["label"]), int(g["n_text"]), dev)
+    errs = {"frame_sim": rel(fs, g["frame_sim_f64"]), "clip_sim": rel(clip, g["clip_sim_f64"]),
+            "loss": abs(loss.item() - float(g["loss_f64"])), "daudio": rel(da, g["daudio_f64"]), "dtext": rel(dt, g["dtext_f64"])}
+    print("weak heads golden:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 5e-6 for v in errs.values()), errs
+
+
+def test_weak_heads_baseline_shape(dev):
+    B, N, T, D = 64, 8, 250, 512
+    g = torch.Generator().manual_seed(2)
+    audio, text = torch.randn(B, T, D, generator=g), torch.randn(B * N, D, generator=g)
+    length = torch.randint(100, T + 1, (B,), generator=g)
+    label = (torch.rand(B, N, generator=g) < 0.3).float()
+    fs, clip, loss, da, dt = head_chain(audio, text, length, label, N, dev)
+    a64, t64 = audio.double().requires_grad_(True), text.double().requires_grad_(True)
+    fo, co = O.multitext_head(a64, t64, length, N)
+    lo = O.clip_bce_loss(co, label.double())
+    lo.backward()
+    errs = {"frame_sim": rel(fs, fo.detach()), "clip_sim": rel(clip, co.detach()), "loss": abs(loss.item() - lo.item()),
+            "daudio": rel(da, a64.grad), "dtext": rel(dt, t64.grad)}
+    print("weak heads B=64 N=8:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 2e-5 for v in errs.values()), errs
+
+
+def test_multitext_biencoder_whole_model(dev):
+    """MultiTextBiEncoder(Cnn8Rnn, EmbeddingAgg(512), DotProduct) + ClipBceLoss: forward and the text-side / top-of-audio
+    gradients vs the fp64 oracle (eval-mode BN so that the comparison is well conditioned at B=2)."""
+    from texttoaudiogrounding_amd.losses import ClipBceLoss
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
+    st = O.init_state(seed=19, logit_gain=60.0)
+    batch = O.synthetic_batch(2, 48000, seed=5, ragged=True)
+    N, L = 3, 4
+    g = torch.Generator().manual_seed(1)
+    text = torch.randint(2, 5221, (2, N, L), generator=g)
+    text_len = torch.randint(1, L + 1, (2, N), generator=g)
+    for b in range(2):
+        for n in range(N):
+            text[b, n, text_len[b, n]:] = 0
+    label = (torch.rand(2, N, generator=g) < 0.5).float()
+    model = audio_text_model.MultiTextBiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                                match.DotProduct(), 512, text_forward_keys=["text"])
+    missing = model.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys and all("melspec" in k for k in missing.missing_keys)
+    model = model.to(dev).eval()
+    out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"], "text": text,
+                 "text_len": text_len, "specaug": False})
+    loss = ClipBceLoss()({"clip_sim": out["clip_sim"], "label": label})
+    loss.backward()
+    s64 = O.state_to(st, torch.float64, requires_grad=True)
+    ao = O.cnn8rnn_forward(s64, batch["waveform"].double(), batch["waveform_len"], training=False)
+    seq = O.embedding_agg_mean(s64, text.reshape(2 * N, L), text_len.reshape(-1))["seq_emb"]
+    fo, co = O.multitext_head(ao["embedding"], seq, ao["length"], N)
+    lo = O.clip_bce_loss(co, label.double())
+    lo.backward()
+    assert out["frame_sim"].shape == fo.shape == (2, 37, N)
+    e_fs = (out["frame_sim"].cpu().double() - fo.detach()).abs().max().item()
+    e_cs = (out["clip_sim"].cpu().double() - co.detach()).abs().max().item()
+    print(f"MultiTextBiEncoder: frame_sim err {e_fs:.1e}, clip_sim err {e_cs:.1e}, loss {loss.item():.6f} vs {lo.item():.6f}; "
+          f"clip range [{co.min().item():.3f}, {co.max().item():.3f}]")
+    assert e_fs < 1e-4 and e_cs < 1e-4 and abs(loss.item() - lo.item()) < 2e-5
+    for name in ("text_encoder.embedding.core.weight", "audio_encoder.fc1.weight", "audio_encoder.rnn.weight_ih_l0"):
+        p = dict(model.named_parameters())[name]
+        assert rel(p.grad, s64[name].grad) < 1e-4, name

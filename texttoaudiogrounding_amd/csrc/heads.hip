@@ -65,10 +65,12 @@ __device__ __forceinline__ float dot_rows(const Row& a, const Row& b) {
 }
 
 // grid = B, block = 256: wave w handles t = w, w+4, ...
+// group = phrases per clip (MultiTextBiEncoder): text row b pairs with audio clip b / group
 __global__ __launch_bounds__(256) void match_fwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
                                                         float* __restrict__ sim, int kind, int l2norm, int scale,
-                                                        int T, int D) {
+                                                        int T, int D, int group) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    audio += (size_t)(b / group) * T * D - (size_t)b * T * D;
     Row tx;
     load_row(tx, text + (size_t)b * D, D, lane);
     float tinv = 1.0f;
@@ -326,6 +328,104 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[i] -= step_size * (mi / denom);
     }
 }
+// ---- weak supervision (MultiTextBiEncoder, models/audio_text_model.py:101-229): N phrases per clip ----
+// backward of the grouped DotProduct head: one block per CLIP; daudio[b,t] = sum_n ds[n,t] text_n, dtext_n = sum_t ds a_t
+constexpr int MAXG = 16;
+template <int NG, int ND>      // N <= NG phrases per clip, D <= 64 * ND
+__global__ __launch_bounds__(256) void match_group_bwd_kernel(const float* __restrict__ audio,
+                                                              const float* __restrict__ text,
+                                                              const float* __restrict__ dsim, float* __restrict__ daudio,
+                                                              float* __restrict__ dtext, int scale, int T, int D, int N) {
+    extern __shared__ float gsm[];                 // text rows [N][D], then the per-wave dtext partials [4][N][D]
+    float* txs = gsm;
+    float* red = gsm + (size_t)N * D;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < N * D; e += 256) txs[e] = text[(size_t)b * N * D + e];
+    __syncthreads();
+    const float rs = scale ? 1.0f / sqrtf((float)D) : 1.0f;
+    float dt[NG][ND];
+#pragma unroll
+    for (int n = 0; n < NG; ++n)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dt[n][i] = 0.0f;
+    for (int t = wid; t < T; t += 4) {
+        float a[ND], da[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d = lane + 64 * i;
+            a[i] = d < D ? audio[((size_t)b * T + t) * D + d] : 0.0f;
+            da[i] = 0.0f;
+        }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            if (n < N) {
+                float tx[ND], sc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    const int d = lane + 64 * i;
+                    tx[i] = d < D ? txs[(size_t)n * D + d] : 0.0f;
+                    sc = fmaf(a[i], tx[i], sc);
+                }
+                sc = wave_sum(sc) * rs;
+                const float p = 1.0f / (1.0f + expf(-sc));
+                const float pass = (p >= 1e-7f && p <= 1.0f) ? 1.0f : 0.0f;
+                const float ds = dsim[((size_t)b * N + n) * T + t] * pass * p * (1.0f - p) * rs;
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    da[i] = fmaf(ds, tx[i], da[i]);
+                    dt[n][i] = fmaf(ds, a[i], dt[n][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) daudio[((size_t)b * T + t) * D + d] = da[i];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NG; ++n)
+        if (n < N)
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) red[((size_t)wid * N + n) * D + d] = dt[n][i];
+            }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * D; e += 256)
+        dtext[(size_t)b * N * D + e] = (red[e] + red[(size_t)N * D + e]) + (red[(size_t)2 * N * D + e] + red[(size_t)3 * N * D + e]);
+}
+
+// linear_softmax_with_lens (models/utils.py:75-76) over rows of frame probabilities: clip[r] = sum_{t<len} f^2 / sum f;
+// len of row r = length[r / group]
+__global__ __launch_bounds__(256) void linsoftmax_pool_fwd_kernel(const float* __restrict__ fs, const long* __restrict__ length,
+                                                                  float* __restrict__ clip, long rows, int T, int group) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int len = (int)min((long)T, length[r / group]);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = lane; t < len; t += 64) { const float f = fs[r * T + t]; s1 += f; s2 = fmaf(f, f, s2); }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) clip[r] = s2 / s1;
+}
+__global__ __launch_bounds__(256) void linsoftmax_pool_bwd_kernel(const float* __restrict__ fs, const long* __restrict__ length,
+                                                                  const float* __restrict__ dclip, float* __restrict__ dfs,
+                                                                  long rows, int T, int group) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int len = (int)min((long)T, length[r / group]);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = lane; t < len; t += 64) { const float f = fs[r * T + t]; s1 += f; s2 = fmaf(f, f, s2); }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float g = dclip[r], inv = 1.0f / s1;
+    for (int t = lane; t < T; t += 64) {
+        const float f = fs[r * T + t];
+        dfs[r * T + t] = t < len ? g * (2.0f * f * inv - s2 * inv * inv) : 0.0f;
+    }
+}
+
 int sumsq_blocks(long n) {
     long nb = (n + 256 * 16 - 1) / (256 * 16);
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
@@ -355,7 +455,7 @@ extern "C" int tag_match_forward(const float* audio, const float* text, float* s
     TAG_CHECK_ARG(audio && text && sim && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
     TAG_CHECK_ARG(kind == 0 || kind == 1);
     hipLaunchKernelGGL(match_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), audio, text, sim, kind, l2norm,
-                       scale, T, D);
+                       scale, T, D, 1);
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -420,6 +520,57 @@ extern "C" int tag_adam_step(float* p, const float* g, float* m, float* v, long 
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
                        eps, bc1, bc2_sqrt, gnorm_sq, max_norm, grad_scale);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- weak supervision: grouped heads ---- */
+extern "C" int tag_match_group_forward(const float* audio, const float* text, float* sim, int scale, int B, int N, int T,
+                                       int D, void* stream) {
+    TAG_CHECK_ARG(audio && text && sim && B > 0 && N > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
+    hipLaunchKernelGGL(match_fwd_kernel, dim3(B * N), dim3(256), 0, as_stream(stream), audio, text, sim, 0, 0, scale, T, D,
+                       N);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_match_group_backward(const float* audio, const float* text, const float* dsim, float* daudio,
+                                        float* dtext, int scale, int B, int N, int T, int D, void* stream) {
+    TAG_CHECK_ARG(audio && text && dsim && daudio && dtext && B > 0 && N > 0 && N <= MAXG && T > 0 && D > 0);
+    TAG_CHECK_ARG(D <= 64 * MAXD_PER_LANE);
+    const size_t lds = (size_t)5 * N * D * sizeof(float);
+    TAG_CHECK_ARG(lds <= 160 * 1024);
+#define LAUNCH(NG, ND)                                                                                               \
+    {                                                                                                                \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_group_bwd_kernel<NG, ND>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((match_group_bwd_kernel<NG, ND>), dim3(B), dim3(256), lds, as_stream(stream), audio, text, \
+                           dsim, daudio, dtext, scale, T, D, N);                                                     \
+    }
+    const bool small_d = D <= 512;
+    if (N <= 4) { if (small_d) LAUNCH(4, 8) else LAUNCH(4, 16) }
+    else if (N <= 8) { if (small_d) LAUNCH(8, 8) else LAUNCH(8, 16) }
+    else { if (small_d) LAUNCH(16, 8) else LAUNCH(16, 16) }
+#undef LAUNCH
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_linear_softmax_pool_forward(const float* fs, const long* length, float* clip, long rows, int T,
+                                               int group, void* stream) {
+    TAG_CHECK_ARG(fs && length && clip && rows > 0 && T > 0 && group > 0);
+    hipLaunchKernelGGL(linsoftmax_pool_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), fs, length, clip,
+                       rows, T, group);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_linear_softmax_pool_backward(const float* fs, const long* length, const float* dclip, float* dfs,
+                                                long rows, int T, int group, void* stream) {
+    TAG_CHECK_ARG(fs && length && dclip && dfs && rows > 0 && T > 0 && group > 0);
+    hipLaunchKernelGGL(linsoftmax_pool_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), fs, length, dclip,
+                       dfs, rows, T, group);
     TAG_LAUNCH_CHECK();
     return 0;
 }

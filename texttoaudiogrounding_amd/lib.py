@@ -85,6 +85,10 @@ _SIGS = {
     "tag_rowdot_sigmoid_forward": (c_int, [P, P, P, c_long, c_int, c_int, P]),
     "tag_rowdot_sigmoid_backward": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
     "tag_embed_tokens_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_match_group_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_match_group_backward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_linear_softmax_pool_forward": (c_int, [P, P, P, c_long, c_int, c_int, P]),
+    "tag_linear_softmax_pool_backward": (c_int, [P, P, P, P, c_long, c_int, c_int, P]),
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),

@@ -20,3 +20,16 @@ class FrameBceLoss(nn.Module):
             raise RuntimeError("frame_sim and label must be aligned first (Runner.forward does it)")
         length = torch.as_tensor(length).long().to(frame_sim.device).contiguous()
         return ops.FrameBceFunction.apply(frame_sim, label.to(frame_sim.device).float(), length, Tt)
+
+
+class ClipBceLoss(nn.Module):
+    """losses.py:38-43 in the reference: F.binary_cross_entropy(clip_sim, label) -- the mean over the (B,N) clip matrix,
+    evaluated by the frame-BCE kernels with every row of full length."""
+
+    def forward(self, output: Dict):
+        return self.forward_tensor(output["clip_sim"], output["label"])
+
+    def forward_tensor(self, prob, label):
+        B, N = prob.shape
+        length = torch.full((B,), N, dtype=torch.long, device=prob.device)
+        return ops.FrameBceFunction.apply(prob.contiguous(), label.to(prob.device).float().contiguous(), length, N)

@@ -64,3 +64,54 @@ class BiEncoder(nn.Module):
             # without a cross-encoder token_emb is not projected: no head consumes it (text_level='seq')
         frame_sim = self.match_fn(forward_dict)
         return {"frame_sim": frame_sim, "length": audio_output["length"]}
+
+
+class MultiTextBiEncoder(BiEncoder):
+    """Weakly supervised variant (mirror of models/audio_text_model.py:101-229 in the reference): every clip comes with N
+    phrases; frame_sim (B,T',N) is pooled over time into clip_sim (B,N).  The audio embedding is NOT expanded to
+    (B*N,T',D): the grouped head (ops.MatchGroupFunction) scores the N phrases of a clip against the same rows."""
+
+    def __init__(self, audio_encoder: nn.Module, text_encoder: nn.Module, match_fn: nn.Module, shared_dim: int,
+                 text_forward_keys: "list[str]", cross_encoder: Optional[nn.Module] = None, pooling: str = "linear_softmax",
+                 add_proj: bool = False, upsample: bool = False, freeze_audio_encoder: bool = False,
+                 freeze_text_encoder: bool = False, safe_size: Optional[int] = None, pretrained: Optional[str] = None,
+                 output_fn=print):
+        if cross_encoder is not None:
+            raise NotImplementedError("MultiTextBiEncoder with a cross-encoder is not on the HIP path yet")
+        super().__init__(audio_encoder=audio_encoder, text_encoder=text_encoder, match_fn=match_fn, shared_dim=shared_dim,
+                         cross_encoder=None, add_proj=add_proj, upsample=upsample,
+                         freeze_audio_encoder=freeze_audio_encoder, freeze_text_encoder=freeze_text_encoder)
+        self.text_forward_keys = list(text_forward_keys)
+        if "text_len" not in self.text_forward_keys:
+            self.text_forward_keys.append("text_len")
+        if pooling != "linear_softmax":
+            raise NotImplementedError("the HIP path implements pooling='linear_softmax' (the reference's default)")
+        self.pooling = pooling
+        self.safe_size = safe_size          # chunking knob of the reference: unnecessary here (no expansion)
+        if pretrained is not None and type(self) is MultiTextBiEncoder:
+            self.load_pretrained(pretrained, output_fn)
+
+    def forward(self, input_dict):
+        from .match import DotProduct
+        if not isinstance(self.match_fn, DotProduct) or self.match_fn.l2norm or self.match_fn.text_level != "seq":
+            raise NotImplementedError("MultiTextBiEncoder on the HIP path: match.DotProduct(l2norm=False, text_level='seq')")
+        audio_output = self.audio_encoder(input_dict)
+        audio_emb = audio_output["embedding"]
+        if hasattr(self, "audio_proj"):
+            audio_emb = ops.LinearFunction.apply(audio_emb, self.audio_proj.weight, self.audio_proj.bias)
+        B = audio_emb.size(0)
+        N = input_dict[self.text_forward_keys[0]].shape[1]
+        text_forward_dict = {}
+        for key in self.text_forward_keys:
+            x = torch.as_tensor(input_dict[key])
+            text_forward_dict[key] = x.reshape(x.shape[0] * x.shape[1], *x.shape[2:])
+        text_emb = self.text_encoder(text_forward_dict)
+        seq = text_emb["seq_emb"]
+        if hasattr(self, "text_proj"):
+            seq = ops.LinearFunction.apply(seq, self.text_proj.weight, self.text_proj.bias)
+        sim = ops.MatchGroupFunction.apply(audio_emb, seq, N, self.match_fn.scale)            # (B*N, T')
+        length = audio_output["length"]
+        len_dev = torch.as_tensor(length).long().to(sim.device).contiguous()
+        clip_sim = ops.LinearSoftmaxPoolFunction.apply(sim, len_dev, N).view(B, N)
+        frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
+        return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}

@@ -897,3 +897,52 @@ class RowDotFunction(torch.autograd.Function):
         da, dt = torch.empty_like(a), torch.empty_like(t)
         call("tag_rowdot_sigmoid_backward", ptr(a), ptr(t), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), B * T, D, ctx.scale)
         return da, dt, None
+
+
+class MatchGroupFunction(torch.autograd.Function):
+    """DotProduct head of MultiTextBiEncoder (models/audio_text_model.py:150-190): N phrases per clip scored against the
+    same audio embedding.  audio (B,T,D), text (B*N,D) -> sim (B*N,T)."""
+
+    @staticmethod
+    def forward(ctx, audio, text, N, scale):
+        a, t = _chk(audio, "audio_emb"), _chk(text, "text_emb")
+        B, T, D = a.shape
+        if t.shape != (B * N, D):
+            raise RuntimeError(f"text_emb must be (B*N, D) = ({B * N}, {D}), got {tuple(t.shape)}")
+        sim = _empty(B * N, T, like=a)
+        call("tag_match_group_forward", ptr(a), ptr(t), ptr(sim), int(scale), B, N, T, D)
+        ctx.save_for_backward(a, t)
+        ctx.cfg = (N, int(scale))
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t = ctx.saved_tensors
+        N, scale = ctx.cfg
+        B, T, D = a.shape
+        da, dt = torch.empty_like(a), torch.empty_like(t)
+        call("tag_match_group_backward", ptr(a), ptr(t), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), scale, B, N, T, D)
+        return da, dt, None, None
+
+
+class LinearSoftmaxPoolFunction(torch.autograd.Function):
+    """linear_softmax_with_lens (models/utils.py:75-76): rows (R,T) of frame probabilities -> (R,), row r uses
+    length[r // group]."""
+
+    @staticmethod
+    def forward(ctx, fs, length, group):
+        f = _chk(fs, "frame_sim")
+        R, T = f.shape
+        clip = _empty(R, like=f)
+        call("tag_linear_softmax_pool_forward", ptr(f), ptr(length), ptr(clip), R, T, group)
+        ctx.save_for_backward(f, length)
+        ctx.group = group
+        return clip
+
+    @staticmethod
+    def backward(ctx, dclip):
+        f, length = ctx.saved_tensors
+        R, T = f.shape
+        dfs = torch.empty_like(f)
+        call("tag_linear_softmax_pool_backward", ptr(f), ptr(length), ptr(_chk(dclip, "grad")), ptr(dfs), R, T, ctx.group)
+        return dfs, None, None

@@ -349,6 +349,16 @@ int tag_linear_softmax_pool_forward(const float* fs, const long* length, float* 
 int tag_linear_softmax_pool_backward(const float* fs, const long* length, const float* dclip, float* dfs, long rows,
                                      int T, int group, void* stream);
 
+/* align-by-phrase (models/audio_text_model.py:907-976): sim_pooling.AudioMeanTextMean over the (B,B,T,N) matrix of
+ * tag_align_dot_forward (models/sim_pooling.py:6-22) and MaxMarginRankingLoss(fix_norm=True) (losses.py:226-264) */
+int tag_meanmean_pool_forward(const float* sim, const long* audio_len, const long* text_len, float* out /*(B,B)*/, int B,
+                              int T, int N, void* stream);
+int tag_meanmean_pool_backward(const float* dout, const long* audio_len, const long* text_len, float* dsim, int B, int T,
+                               int N, void* stream);
+int tag_maxmargin_forward(const float* x /*(n,n)*/, int n, float margin, float lamda1, float* loss, void* stream);
+int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, const float* dloss, float* dx,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

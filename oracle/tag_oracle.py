@@ -657,3 +657,23 @@ def multitext_head(audio_emb, seq_emb, length, n_text, scale=True):
 
 def clip_bce_loss(clip_sim, label):
     return F.binary_cross_entropy(clip_sim, label)
+
+
+def audio_mean_text_mean(sim, audio_len, text_len):
+    """sim_pooling.AudioMeanTextMean (models/sim_pooling.py:6-22): (B,B,T,N) -> (B,B); row a uses audio_len[a], column b
+    text_len[b]."""
+    B, _, T, N = sim.shape
+    am = (torch.arange(T)[None, :] < torch.as_tensor(audio_len).view(-1, 1)).to(sim.dtype)        # (B,T)
+    tm = (torch.arange(N)[None, :] < torch.as_tensor(text_len).view(-1, 1)).to(sim.dtype)         # (B,N)
+    s = (sim * am[:, None, :, None]).sum(2) / torch.as_tensor(audio_len).to(sim.dtype).view(-1, 1, 1)     # (B,B,N)
+    return (s * tm[None, :, :]).sum(2) / torch.as_tensor(text_len).to(sim.dtype).view(1, -1)
+
+
+def max_margin_ranking_loss(x, margin=1.0, lamda1=1.0):
+    """MaxMarginRankingLoss(fix_norm=True) (losses.py:226-264)."""
+    n = x.shape[0]
+    d = torch.diag(x).view(-1, 1)
+    off = ~torch.eye(n, dtype=torch.bool)
+    t1 = F.relu(margin - (d - x))[off]
+    t2 = F.relu(margin - (d - lamda1 * x.t()))[off]
+    return torch.cat([t1, t2]).mean()

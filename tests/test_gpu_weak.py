@@ -94,3 +94,43 @@ def test_multitext_biencoder_whole_model(dev):
     for name in ("text_encoder.embedding.core.weight", "audio_encoder.fc1.weight", "audio_encoder.rnn.weight_ih_l0"):
         p = dict(model.named_parameters())[name]
         assert rel(p.grad, s64[name].grad) < 1e-4, name
+
+
+def align_chain(audio, text, audio_len, text_len, margin, dev):
+    from texttoaudiogrounding_amd.losses import MaxMarginRankingLoss
+    from texttoaudiogrounding_amd.models import align, sim_pooling
+    a = audio.to(dev).requires_grad_(True)
+    t = text.to(dev).requires_grad_(True)
+    m = align.DotProduct(scaled=True)(a, t)
+    sim = sim_pooling.AudioMeanTextMean()({"sim": m, "audio_len": audio_len, "text_len": text_len})
+    loss = MaxMarginRankingLoss(margin=margin)({"sim": sim})
+    loss.backward()
+    return m, sim, loss, a.grad, t.grad
+
+
+def test_align_heads_golden(dev, golden_dir):
+    """align.DotProduct -> sim_pooling.AudioMeanTextMean -> MaxMarginRankingLoss vs the imported reference (fp64 twin)."""
+    g = np.load(f"{golden_dir}/align_heads.npz")
+    m, sim, loss, da, dt = align_chain(torch.from_numpy(g["audio"]), torch.from_numpy(g["text"]), torch.from_numpy(g["audio_len"]),
+                                       [int(v) for v in g["text_len"]], 0.1, dev)
+    errs = {"matrix": rel(m, g["matrix_f64"]), "sim": rel(sim, g["sim_f64"]), "loss": abs(loss.item() - float(g["loss_f64"])),
+            "daudio": rel(da, g["daudio_f64"]), "dtext": rel(dt, g["dtext_f64"])}
+    print("align heads golden:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 5e-6 for v in errs.values()), errs
+
+
+def test_align_heads_baseline_shape(dev):
+    B, T, N, D = 64, 250, 6, 512
+    g = torch.Generator().manual_seed(4)
+    audio, text = torch.randn(B, T, D, generator=g) * 0.5, torch.randn(B, N, D, generator=g) * 0.5
+    audio_len = torch.randint(100, T + 1, (B,), generator=g)
+    text_len = torch.randint(1, N + 1, (B,), generator=g)
+    m, sim, loss, da, dt = align_chain(audio, text, audio_len, [int(v) for v in text_len], 0.05, dev)
+    a64, t64 = audio.double().requires_grad_(True), text.double().requires_grad_(True)
+    mo = O.align_dot_product(a64, t64, scaled=True)
+    so = O.audio_mean_text_mean(mo, audio_len, text_len)
+    lo = O.max_margin_ranking_loss(so, 0.05, 1.0)
+    lo.backward()
+    errs = {"sim": rel(sim, so.detach()), "loss": abs(loss.item() - lo.item()), "daudio": rel(da, a64.grad), "dtext": rel(dt, t64.grad)}
+    print("align heads B=64:", {k: f"{v:.1e}" for k, v in errs.items()}, f"loss {lo.item():.5f}")
+    assert all(v < 2e-5 for v in errs.values()), errs

@@ -426,6 +426,73 @@ __global__ __launch_bounds__(256) void linsoftmax_pool_bwd_kernel(const float* _
     }
 }
 
+// ---- weak supervision, align-by-phrase (models/audio_text_model.py:907-976): sim_pooling.AudioMeanTextMean
+// (models/sim_pooling.py:6-22) over the (B,B,T,N) matrix of align.DotProduct, and MaxMarginRankingLoss (losses.py:226-264)
+// out[a,b] = mean_{n < tlen[b]} mean_{t < alen[a]} sim[a,b,t,n];  one wave per (a,b)
+__global__ __launch_bounds__(256) void meanmean_pool_fwd_kernel(const float* __restrict__ sim, const long* __restrict__ alen,
+                                                                const long* __restrict__ tlen, float* __restrict__ out, int B,
+                                                                int T, int N) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * B) return;
+    const int a = (int)(r / B), b = (int)(r % B);
+    const int al = (int)min((long)T, alen[a]), tl = (int)min((long)N, tlen[b]);
+    float s = 0.0f;
+    for (int e = lane; e < al * N; e += 64) { const int n = e % N; if (n < tl) s += sim[r * T * N + e]; }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s / ((float)al * (float)tl);
+}
+__global__ __launch_bounds__(256) void meanmean_pool_bwd_kernel(const float* __restrict__ dout, const long* __restrict__ alen,
+                                                                const long* __restrict__ tlen, float* __restrict__ dsim, int B,
+                                                                int T, int N) {
+    const long total = (long)B * B * T * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % N);
+        const int t = (int)((i / N) % T);
+        const long r = i / ((long)N * T);
+        const int a = (int)(r / B), b = (int)(r % B);
+        const int al = (int)min((long)T, alen[a]), tl = (int)min((long)N, tlen[b]);
+        dsim[i] = (t < al && n < tl) ? dout[r] / ((float)al * (float)tl) : 0.0f;
+    }
+}
+// loss = mean over i != j of relu(m - (x_ii - x_ij)) and relu(m - (x_ii - lam x_ji))   (fix_norm = True)
+__global__ __launch_bounds__(256) void maxmargin_fwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
+                                                            float* __restrict__ loss) {
+    __shared__ double sred[4];
+    double s = 0.0;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        if (i == j) continue;
+        const float d = x[i * n + i];
+        s += (double)fmaxf(margin - (d - x[i * n + j]), 0.0f) + (double)fmaxf(margin - (d - lam * x[j * n + i]), 0.0f);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((sred[0] + sred[1]) + (sred[2] + sred[3])) / (2.0 * n * (n - 1)));
+}
+// one wave per row i: off-diagonal dx_ij written by the owner of element (i,j); the diagonal collects its row's terms
+__global__ __launch_bounds__(256) void maxmargin_bwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
+                                                            const float* __restrict__ dloss, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float c = dloss[0] / (2.0f * n * (n - 1));
+    const float di = x[i * n + i];
+    float dd = 0.0f;
+    for (int j = lane; j < n; j += 64) {
+        if (j == i) continue;
+        const float xij = x[i * n + j], xji = x[j * n + i], dj = x[j * n + j];
+        const float a1 = (margin - (di - xij)) > 0.0f ? 1.0f : 0.0f;          // term 1 of pair (i,j): depends on x_ii, x_ij
+        const float a2 = (margin - (di - lam * xji)) > 0.0f ? 1.0f : 0.0f;    // term 2 of pair (i,j): depends on x_ii, x_ji
+        const float b2 = (margin - (dj - lam * xij)) > 0.0f ? 1.0f : 0.0f;    // term 2 of pair (j,i): depends on x_jj, x_ij
+        dx[i * n + j] = c * (a1 + lam * b2);
+        dd -= c * (a1 + a2);
+    }
+    dd = wave_sum(dd);
+    if (lane == 0) dx[i * n + i] = dd;
+}
+
 int sumsq_blocks(long n) {
     long nb = (n + 256 * 16 - 1) / (256 * 16);
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
@@ -571,6 +638,38 @@ extern "C" int tag_linear_softmax_pool_backward(const float* fs, const long* len
     TAG_CHECK_ARG(fs && length && dclip && dfs && rows > 0 && T > 0 && group > 0);
     hipLaunchKernelGGL(linsoftmax_pool_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), fs, length, dclip,
                        dfs, rows, T, group);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_meanmean_pool_forward(const float* sim, const long* alen, const long* tlen, float* out, int B, int T,
+                                         int N, void* stream) {
+    TAG_CHECK_ARG(sim && alen && tlen && out && B > 0 && T > 0 && N > 0);
+    hipLaunchKernelGGL(meanmean_pool_fwd_kernel, dim3(cdiv((long)B * B, 4)), dim3(256), 0, as_stream(stream), sim, alen, tlen,
+                       out, B, T, N);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_meanmean_pool_backward(const float* dout, const long* alen, const long* tlen, float* dsim, int B, int T,
+                                          int N, void* stream) {
+    TAG_CHECK_ARG(dout && alen && tlen && dsim && B > 0 && T > 0 && N > 0);
+    const long total = (long)B * B * T * N;
+    hipLaunchKernelGGL(meanmean_pool_bwd_kernel, dim3(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256)), dim3(256), 0,
+                       as_stream(stream), dout, alen, tlen, dsim, B, T, N);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_maxmargin_forward(const float* x, int n, float margin, float lamda1, float* loss, void* stream) {
+    TAG_CHECK_ARG(x && loss && n > 1);
+    hipLaunchKernelGGL(maxmargin_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, loss);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, const float* dloss, float* dx,
+                                      void* stream) {
+    TAG_CHECK_ARG(x && dloss && dx && n > 1);
+    hipLaunchKernelGGL(maxmargin_bwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, dloss,
+                       dx);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -89,6 +89,10 @@ _SIGS = {
     "tag_match_group_backward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_linear_softmax_pool_forward": (c_int, [P, P, P, c_long, c_int, c_int, P]),
     "tag_linear_softmax_pool_backward": (c_int, [P, P, P, P, c_long, c_int, c_int, P]),
+    "tag_meanmean_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_meanmean_pool_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_maxmargin_forward": (c_int, [P, c_int, c_float, c_float, P, P]),
+    "tag_maxmargin_backward": (c_int, [P, c_int, c_float, c_float, P, P, P]),
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),

@@ -33,3 +33,16 @@ class ClipBceLoss(nn.Module):
         B, N = prob.shape
         length = torch.full((B,), N, dtype=torch.long, device=prob.device)
         return ops.FrameBceFunction.apply(prob.contiguous(), label.to(prob.device).float().contiguous(), length, N)
+
+
+class MaxMarginRankingLoss(nn.Module):
+    """losses.py:226-264 in the reference (triplet ranking over the (B,B) clip-vs-caption matrix)."""
+
+    def __init__(self, margin=1, fix_norm=True, lamda1=1, sim_key="sim"):
+        super().__init__()
+        if not fix_norm:
+            raise NotImplementedError("the HIP path implements fix_norm=True (the reference's default)")
+        self.fix_norm, self.margin, self.lamda1, self.sim_key = fix_norm, margin, lamda1, sim_key
+
+    def forward(self, x):
+        return ops.MaxMarginFunction.apply(x[self.sim_key], self.margin, self.lamda1)

@@ -115,3 +115,42 @@ class MultiTextBiEncoder(BiEncoder):
         clip_sim = ops.LinearSoftmaxPoolFunction.apply(sim, len_dev, N).view(B, N)
         frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
         return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}
+
+
+class AudioTextAlignByPhrase(nn.Module):
+    """Weakly supervised alignment (mirror of models/audio_text_model.py:907-976 in the reference): every clip against
+    every clip's phrases -- align.DotProduct (B,B,T',N) -> sim_pooling -> (B,B) for MaxMarginRankingLoss."""
+
+    def __init__(self, audio_encoder, text_encoder, match_fn, sim_pooling, shared_dim, cross_encoder=None, add_proj=False,
+                 freeze_audio_encoder=False, freeze_text_encoder=False):
+        super().__init__()
+        if cross_encoder is not None:
+            raise NotImplementedError("AudioTextAlignByPhrase with a cross-encoder is not on the HIP path")
+        self.audio_encoder, self.text_encoder, self.match_fn = audio_encoder, text_encoder, match_fn
+        self.cross_encoder, self.sim_pooling = None, sim_pooling
+        if audio_encoder.embed_dim != text_encoder.embed_dim or add_proj:
+            self.audio_proj = nn.Linear(audio_encoder.embed_dim, shared_dim)
+            self.text_proj = nn.Linear(text_encoder.embed_dim, shared_dim)
+        if freeze_audio_encoder:
+            for p in self.audio_encoder.parameters():
+                p.requires_grad = False
+        if freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad = False
+
+    def forward(self, input_dict):
+        audio_output = self.audio_encoder(input_dict)
+        audio_emb = audio_output["embedding"]
+        text_key = input_dict["text_key"]
+        phrases_emb = self.text_encoder({"text": input_dict[text_key], "text_len": input_dict[f"{text_key}_len"]})
+        phrases_num = [int(v) for v in input_dict[f"{text_key}_num"]]
+        seq_emb = torch.split(phrases_emb["seq_emb"], phrases_num, dim=0)
+        seq_emb = nn.utils.rnn.pad_sequence(seq_emb, batch_first=True)          # (B, max_num, D)
+        if hasattr(self, "audio_proj"):                                         # the reference declares but never applies them
+            pass
+        sim_matrix = self.match_fn(audio_emb, seq_emb.contiguous())
+        sim = self.sim_pooling({"sim": sim_matrix, "audio_len": audio_output["length"], "text_len": phrases_num})
+        output = {"sim": sim}
+        if input_dict.get("output_matrix", False):
+            output["sim_matrix"] = sim_matrix
+        return output

@@ -946,3 +946,46 @@ class LinearSoftmaxPoolFunction(torch.autograd.Function):
         dfs = torch.empty_like(f)
         call("tag_linear_softmax_pool_backward", ptr(f), ptr(length), ptr(_chk(dclip, "grad")), ptr(dfs), R, T, ctx.group)
         return dfs, None, None
+
+
+class MeanMeanPoolFunction(torch.autograd.Function):
+    """sim_pooling.AudioMeanTextMean (models/sim_pooling.py:6-22): (B,B,T,N) -> (B,B)."""
+
+    @staticmethod
+    def forward(ctx, sim, audio_len, text_len):
+        s = _chk(sim, "sim")
+        B, _, T, N = s.shape
+        out = _empty(B, B, like=s)
+        call("tag_meanmean_pool_forward", ptr(s), ptr(audio_len), ptr(text_len), ptr(out), B, T, N)
+        ctx.save_for_backward(audio_len, text_len)
+        ctx.shape = (B, T, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        audio_len, text_len = ctx.saved_tensors
+        B, T, N = ctx.shape
+        dsim = torch.empty(B, B, T, N, device=dout.device, dtype=F32)
+        call("tag_meanmean_pool_backward", ptr(_chk(dout, "grad")), ptr(audio_len), ptr(text_len), ptr(dsim), B, T, N)
+        return dsim, None, None
+
+
+class MaxMarginFunction(torch.autograd.Function):
+    """MaxMarginRankingLoss(fix_norm=True) (losses.py:226-264) on an (n,n) similarity matrix."""
+
+    @staticmethod
+    def forward(ctx, x, margin, lamda1):
+        xs = _chk(x, "sim")
+        n = xs.shape[0]
+        loss = _empty(1, like=xs)
+        call("tag_maxmargin_forward", ptr(xs), n, float(margin), float(lamda1), ptr(loss))
+        ctx.save_for_backward(xs)
+        ctx.cfg = (float(margin), float(lamda1))
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (xs,) = ctx.saved_tensors
+        dx = torch.empty_like(xs)
+        call("tag_maxmargin_backward", ptr(xs), xs.shape[0], ctx.cfg[0], ctx.cfg[1], ptr(_chk(dloss.reshape(1), "grad")), ptr(dx))
+        return dx, None, None

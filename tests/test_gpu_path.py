@@ -351,3 +351,27 @@ def test_full_length_train_step_vs_oracle(dev):
     runner.optimizer_step()
     for (name, p), q in zip(model.named_parameters(), params):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name
+
+
+@pytest.mark.parametrize("B,S", [(1, 4000), (3, 9999), (2, 32000)])
+def test_edge_shapes_train_step(dev, B, S):
+    """Edge cases of the path: a single clip, clips of a few frames (T' = 3), odd sample counts, one-token phrases:
+    one training step (dropout off) against the fp64 oracle."""
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=B + S, logit_gain=40.0)
+    batch = O.synthetic_batch(B, S, seed=S, ragged=(B > 1))
+    model = build_hip_model(st, "dot", dev).train()
+    model.audio_encoder.dropout_p = (0.0, 0.0)
+    runner = StrongRunner(model, device=str(dev))
+    loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    s64 = O.state_to(st, torch.float64, requires_grad=True)
+    b64 = dict(batch)
+    b64["waveform"], b64["label"] = batch["waveform"].double(), batch["label"].double()
+    oloss, oout = O.train_step_loss(s64, b64, "dot", "cnn8rnn", True, (0.0, 0.0))
+    oloss.backward()
+    print(f"edge B={B} S={S}: T'={oout['frame_sim'].shape[1]}, loss {loss.item():.6f} vs {oloss.item():.6f}")
+    assert abs(loss.item() - oloss.item()) < 5e-5 * max(1.0, abs(oloss.item()))
+    for name in ("text_encoder.embedding.core.weight", "audio_encoder.rnn.weight_hh_l0", "audio_encoder.fc1.bias"):
+        p = dict(model.named_parameters())[name]
+        g = s64[name].grad
+        assert (p.grad.cpu().double() - g).abs().max().item() / (g.abs().max().item() + 1e-30) < 1e-3, name

@@ -375,3 +375,43 @@ def test_edge_shapes_train_step(dev, B, S):
         p = dict(model.named_parameters())[name]
         g = s64[name].grad
         assert (p.grad.cpu().double() - g).abs().max().item() / (g.abs().max().item() + 1e-30) < 1e-3, name
+
+
+@pytest.mark.parametrize("math_", ["fp32", "x3"])
+def test_training_trajectory_matches_oracle(dev, math_):
+    """Ten optimiser steps (forward, backward, clip_grad_norm_(1.0), Adam) on a fixed batch, dropout off: the loss
+    trajectory of the HIP path follows the fp64 oracle's (torch.optim.Adam on the oracle's parameters)."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=23, logit_gain=20.0)
+    batch = O.synthetic_batch(4, 32000, seed=9, ragged=True)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = math_
+    try:
+        model = build_hip_model(st, "dot", dev).train()
+        model.audio_encoder.dropout_p = (0.0, 0.0)
+        runner = StrongRunner(model, lr=2e-4, max_grad_norm=1.0, device=str(dev))
+        hip = []
+        for _ in range(10):
+            hip.append(runner.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}).item())
+    finally:
+        ops.CONV_MATH = old
+    s64 = O.state_to(st, torch.float64, requires_grad=True)
+    b64 = dict(batch)
+    b64["waveform"], b64["label"] = batch["waveform"].double(), batch["label"].double()
+    names = [n for n, _ in model.named_parameters()]
+    params = [s64[n] for n in names]
+    opt = torch.optim.Adam(params, lr=2e-4)
+    ref = []
+    for _ in range(10):
+        opt.zero_grad()
+        loss, _ = O.train_step_loss(s64, b64, "dot", "cnn8rnn", True, (0.0, 0.0))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        ref.append(loss.item())
+    print(f"trajectory [{math_}]: hip {['%.5f' % v for v in hip]}")
+    print(f"                 oracle {['%.5f' % v for v in ref]}")
+    assert ref[-1] < ref[0] - 0.005                                  # the oracle actually learns on this batch
+    assert max(abs(a - b) for a, b in zip(hip, ref)) < 3e-3           # Adam's sign-like first steps amplify fp32 noise
+    assert abs(hip[0] - ref[0]) < 2e-5

@@ -276,12 +276,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         partials[(size_t)blockIdx.x * N + col] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
                                                  sred[3][threadIdx.x];
 }
-__global__ void colsum_final_kernel(const double* __restrict__ partials, int nblk, int N, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// 16 columns x 16 row groups per block, folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partials, int nblk, int N,
+                                                           float* __restrict__ out) {
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * N + c];
-    out[c] = (float)s;
+    if (c < N)
+        for (int b = g; b < nblk; b += 16) s += partials[(size_t)b * N + c];
+    sh[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        double t = 0;
+        for (int q = 0; q < 16; ++q) t += sh[q][cl];
+        out[c] = (float)t;
+    }
 }
 int colsum_blocks(long M) {
     long nb = (M + 63) / 64;
@@ -368,7 +377,7 @@ extern "C" int tag_colsum(const float* x, int ld, long M, int N, float* out, voi
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(N, 64)), dim3(256), 0, as_stream(stream), x, ld, M, N,
                        partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64), 0, as_stream(stream), partials, nblk, N, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 16)), dim3(256), 0, as_stream(stream), partials, nblk, N, out);
     TAG_LAUNCH_CHECK();
     return 0;
 }

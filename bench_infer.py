@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=8)
-    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3"])
+    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"])
     args = ap.parse_args()
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.models.hf_modeling_grounding import Cnn8RnnLaionClapGroundingModel

@@ -25,6 +25,9 @@ def install_aliases(force: bool = False):
         "models.match": "texttoaudiogrounding_amd.models.match",
         "models.align": "texttoaudiogrounding_amd.models.align",
         "models.audio_text_model": "texttoaudiogrounding_amd.models.audio_text_model",
+        "models.cross_encoder": "texttoaudiogrounding_amd.models.cross_encoder",
+        "models.sim_pooling": "texttoaudiogrounding_amd.models.sim_pooling",
+        "models.hf_modeling_grounding": "texttoaudiogrounding_amd.models.hf_modeling_grounding",
         "losses": "texttoaudiogrounding_amd.losses",
     }
     for alias, target in names.items():

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __
             const float r = sigmoidf_(gir + gh[0]);
             const float z = sigmoidf_(giz + gh[1]);
             const float n = tanhf(gin + r * gh[2]);
-            const float h = (1.0f - z) * n + z * hprev;
+            float h = (1.0f - z) * n + z * hprev;
+            if (dead) h = __int_as_float(0x7fc00000);   // a timed-out exchange must not pass silently: NaN reaches the loss
             hprev = h;
             __hip_atomic_store(hxd + (size_t)(s & 1) * Bpad * H + (size_t)b * H + j, granule((unsigned)(s + 1), h),
                                TAG_RLX_AGENT);
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
         if (valid) {
             float dh = dyv;
             if (s > 0) dh += msum + dh_carry * z_next;
+            if (dead) dh = __int_as_float(0x7fc00000);  // timed-out exchange: poison the gradients (loud, not silent)
             dh_carry = dh;
             z_next = g_z;
             const float dn = dh * (1.0f - g_z);

@@ -406,7 +406,13 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
     }
 }
 
-bool gru_persistent_ok(int B, int H) { return (H == 256 || H == 128) && (H / 16) * ((B + 15) / 16) * 2 <= 256; }
+// the persistent kernels need every workgroup resident at once (one per CU): grid <= CUs of THIS device (256 on a
+// whole MI355X, fewer in a partitioned mode); otherwise the per-step kernels are used
+bool gru_persistent_ok(int B, int H) {
+    static int cus = 0;
+    if (cus == 0) { cus = tag_device_cu_count(); if (cus <= 0) cus = 1; }
+    return (H == 256 || H == 128) && (H / 16) * ((B + 15) / 16) * 2 <= cus;
+}
 
 }  // namespace
 

@@ -1103,6 +1103,64 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
     }
 }
 
+constexpr int C1B_GW = 66, C1B_GT = 10;        // LDS ring rows: 64 + 2 halo pixels; G rows: 9 taps + 1 pad
+// Forward of the Cin = 1 convolution for W = 64, Cout = 64: a workgroup walks down a strip of rows of one image; the
+// three input rows of the current output row live in an LDS ring (bn0 affine and zero padding applied once per value),
+// every thread produces 4 pixels x 4 couts per row (weights in registers) and stores 16 B per pixel -> the kernel is a
+// pure 1 GB write stream.
+__global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ cs,
+                                                               const float* __restrict__ ct, const float* __restrict__ wgt,
+                                                               float* __restrict__ y, int H, int strips,
+                                                               int rows_per_strip) {
+    constexpr int W = 64, Cout = 64;
+    __shared__ float Xs[4][C1B_GW];
+    const int img = blockIdx.x / strips, strip = blockIdx.x % strips;
+    const int r0 = strip * rows_per_strip;
+    int r1 = r0 + rows_per_strip;
+    if (r1 > H) r1 = H;
+    const int tid = threadIdx.x, c = (tid & 15) << 2, grp = tid >> 4;      // 16 pixel groups of 4 pixels
+    float wr[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[j][t] = wgt[(c + j) * 9 + t];
+    const float* ximg = x + (size_t)img * H * W;
+    auto stage_x = [&](int row) {
+        if (tid < C1B_GW) {
+            const int w = tid - 1;
+            float v = 0.0f;
+            if ((unsigned)row < (unsigned)H && (unsigned)w < (unsigned)W) {
+                v = ximg[(size_t)row * W + w];
+                if (cs) v = fmaf(v, cs[w], ct[w]);
+            }
+            Xs[(row + 8) & 3][tid] = v;
+        }
+    };
+    stage_x(r0 - 1);
+    stage_x(r0);
+    stage_x(r0 + 1);
+    __syncthreads();
+    for (int h = r0; h < r1; ++h) {
+        if (h + 2 <= r1) stage_x(h + 2);                                    // slot (h+2)&3 is not read by row h
+        float xin[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) xin[r][k] = Xs[(h + r - 1 + 8) & 3][grp * 4 + k];
+        float* yrow = y + (((size_t)img * H + h) * W + grp * 4) * Cout + c;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(xin[tap / 3][px + tap % 3], wr[j][tap], o[j]);
+            *reinterpret_cast<float4*>(yrow + (size_t)px * Cout) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+    }
+}
+
 // Fused backward of the Cin = 1 convolution for W = 64 mel bins, Cout = 64: ONE pass over dy (the 1 GB tensor at
 // batch 64) produces both dw (64 x 9) and dx (the gradient of the bn0 output, needed for bn0's weight / bias).
 // A workgroup walks down a strip of rows of one image; per row (64 pixels x 64 couts = 16 KB, one float4 per thread
@@ -1111,7 +1169,6 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
 //   dgrad:  G[h][w][tap] = sum_co dy[h][w][co] * wgt[co][tap]  (16-lane butterfly), kept in an LDS ring of 4 rows;
 //           dx[h-1][w] = sum_tap G[h-1-(ky-1)][w-(kx-1)][tap] once row h is in.
 // The next row's dy is in flight while the current one is processed; one barrier per row.
-constexpr int C1B_GW = 66, C1B_GT = 10;        // G ring row: 64 + 2 halo pixels, 9 taps + 1 pad
 // sum over each aligned group of 16 lanes, result in all 16 (DPP: quad swaps, then half-row and row mirrors)
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -1492,13 +1549,19 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     return 0;
 }
 
+static void c1_bwd_geom(int B, int H, int* strips, int* rows);
 extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, const float* col_shift, const float* w,
                                       float* y, int B, int H, int W, int Cout, void* stream) {
     TAG_CHECK_ARG(x && w && y && Cout % 4 == 0 && (col_scale == nullptr) == (col_shift == nullptr));
     const long M = (long)B * H * W;
     long nb = (M * (Cout / 4) + 255) / 256;
     if (nb > 8192) nb = 8192;
-    if (W % 4 == 0 && 256 % (Cout / 4) == 0) {
+    if (W == 64 && Cout == 64) {
+        int strips, rows;
+        c1_bwd_geom(B, H, &strips, &rows);
+        hipLaunchKernelGGL(conv_c1_fwd_rows_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
+                           col_shift, w, y, H, strips, rows);
+    } else if (W % 4 == 0 && 256 % (Cout / 4) == 0) {
         nb = ((M / 4) * (Cout / 4) + 255) / 256;
         if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(conv_c1_fwd4_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale,

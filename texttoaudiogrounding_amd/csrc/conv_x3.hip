@@ -522,9 +522,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
     const unsigned lq = (unsigned)(half * 32 + (li & 3) * 8);
     const unsigned va = (unsigned)(wi * G::XPL) + lq + (unsigned)((CW == 8 ? (li >> 2) : (kl * 8 + (li >> 2))) * 64);
     const unsigned vb = (unsigned)(wj * G::YPL) + lq + (unsigned)((kl * 8 + (li >> 2)) * 64);
-    constexpr int PA[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
-    constexpr int PB[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0};
-    constexpr int P0 = NP == 1 ? 8 : 9 - NP;
 
     // MFMA phase of one chunk as 18 plane-steps q = ((s*3 + ky)*3 + o): the A fragments (3 taps kx) of ONE split plane
     // (o = 0 lo, 1 mid, 2 hi) are live at a time and feed every product that uses that plane (lo: a_l*b_h; mid:

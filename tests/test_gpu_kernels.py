@@ -184,6 +184,34 @@ def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert e_f < 5e-6 and (e_d is None or e_d < 5e-6) and (e_w is None or e_w < 5e-6)
 
 
+def test_conv3x3_x3_extreme_dynamic_range(ops, dev):
+    """x3 arithmetic with operands spanning 16 orders of magnitude across channels (1e-8 ... 1e+8): the exact 3-way bf16
+    split keeps fp32 accuracy wherever fp32 itself does (bf16 has fp32's exponent range)."""
+    B, H, W, Cin, Cout = 2, 33, 16, 128, 128
+    g = torch.Generator().manual_seed(99)
+    sc = torch.exp(6.0 * torch.randn(1, Cin, 1, 1, generator=g)).clamp(1e-8, 1e8)
+    x = torch.randn(B, Cin, H, W, generator=g) * sc
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin) / sc.view(1, Cin, 1, 1)     # products are O(1)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    y_ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = "x3"
+    try:
+        wf, _ = ops.pack_conv_weight(w.to(dev), W=W)
+        e_f = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), wf, Cout)), y_ref)
+        dw = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev))
+    finally:
+        ops.CONV_MATH = old
+    pf, _ = ops.pack_conv_weight(w.to(dev))
+    e_32 = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), pf, Cout)), y_ref)
+    # weight gradients span the same 16 decades: compare per input channel
+    e_w = ((dw.cpu().double() - dw_ref).abs().amax(dim=(0, 2, 3)) / dw_ref.abs().amax(dim=(0, 2, 3))).max().item()
+    print(f"x3 extreme range: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e}), wgrad per-channel err {e_w:.2e}; "
+          f"operand scales {sc.min().item():.1e} .. {sc.max().item():.1e}")
+    assert e_f < 5e-6 and e_w < 5e-6
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 32, 64, 64), (1, 17, 16, 64, 128), (2, 250, 8, 256, 512), (2, 500, 32, 128, 128)])
 def test_conv3x3_bf16_mode(ops, dev, B, H, W, Cin, Cout):
     """CONV_MATH = "bf16" (BASELINE configs[2] arithmetic): operands rounded to nearest bf16, ONE product per multiply on the

@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--cross-encoder", action="store_true",
                     help="time BASELINE configs[3] instead: the same biencoder with CrossAttentionGating(512) and the "
                          "token-level DotProduct (NOT the contract's workload; for DESIGN.md section 10)")
+    ap.add_argument("--crnn", action="store_true",
+                    help="time the variant the strong eg_config literally instantiates instead (cdur_w2vmean.yaml: CrnnEncoder "
+                         "(256) + EmbeddingAgg(256) + match.ExpNegL2); NOT the contract's workload")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
@@ -96,7 +99,10 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     torch.manual_seed(0)
-    if args.cross_encoder:
+    if args.crnn:
+        model = audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(32000, 256), text_encoder.EmbeddingAgg(5221, 256),
+                                           match.ExpNegL2(), 256)
+    elif args.cross_encoder:
         from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
         model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
                                            match.DotProduct(text_level="token"), 512,
@@ -220,7 +226,8 @@ def main():
                "dtype": {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
                    args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)"),
                "data": "synthetic",
-               "config": {"workload": ("configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + "
+               "config": {"workload": "strong eg_config as written (cdur_w2vmean.yaml): CrnnEncoder(256) + EmbeddingAgg(256) + "
+                                      "match.ExpNegL2, fwd+bwd+clip+Adam" if args.crnn else ("configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + "
                                        "match.DotProduct(token), fwd+bwd+clip+Adam, dropout on, train-mode BN"
                                        if args.cross_encoder else
                                        "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "

@@ -134,3 +134,31 @@ def test_align_heads_baseline_shape(dev):
     errs = {"sim": rel(sim, so.detach()), "loss": abs(loss.item() - lo.item()), "daudio": rel(da, a64.grad), "dtext": rel(dt, t64.grad)}
     print("align heads B=64:", {k: f"{v:.1e}" for k, v in errs.items()}, f"loss {lo.item():.5f}")
     assert all(v < 2e-5 for v in errs.values()), errs
+
+
+def test_clip_frame_bce_loss(dev):
+    """ClipFrameBceLoss (losses.py:186-210) on MultiTextBiEncoder-shaped outputs vs torch's binary_cross_entropy (fp64)."""
+    import torch.nn.functional as F
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.losses import ClipFrameBceLoss
+    B, N, T, D = 5, 3, 40, 64
+    g = torch.Generator().manual_seed(6)
+    audio, text = torch.randn(B, T, D, generator=g), torch.randn(B * N, D, generator=g)
+    length = torch.tensor([40, 31, 17, 40, 5])
+    weak = (torch.rand(B, N, generator=g) < 0.5).float()
+    strong = (torch.rand(B, T, N, generator=g) < 0.3).float()
+    a, t = audio.to(dev).requires_grad_(True), text.to(dev).requires_grad_(True)
+    sim = ops.MatchGroupFunction.apply(a, t, N, True)
+    clip = ops.LinearSoftmaxPoolFunction.apply(sim, length.to(dev), N).view(B, N)
+    out = {"frame_sim": sim.view(B, N, T).transpose(1, 2), "clip_sim": clip, "length": length, "weak_label": weak,
+           "strong_label": strong}
+    loss = ClipFrameBceLoss(frame_weight=0.3)(out)
+    loss.backward()
+    a64, t64 = audio.double().requires_grad_(True), text.double().requires_grad_(True)
+    fo, co = O.multitext_head(a64, t64, length, N)
+    mask = (torch.arange(T)[None, :] < length[:, None]).double().unsqueeze(-1).expand(B, T, N)
+    frame = (F.binary_cross_entropy(fo, strong.double(), reduction="none") * mask).sum() / mask.sum()
+    ref = 0.7 * F.binary_cross_entropy(co, weak.double()) + 0.3 * frame
+    ref.backward()
+    print(f"ClipFrameBceLoss {loss.item():.7f} vs {ref.item():.7f}; daudio err {rel(a.grad, a64.grad):.1e}")
+    assert abs(loss.item() - ref.item()) < 1e-6 and rel(a.grad, a64.grad) < 1e-5 and rel(t.grad, t64.grad) < 1e-5

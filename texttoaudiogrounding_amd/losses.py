@@ -46,3 +46,27 @@ class MaxMarginRankingLoss(nn.Module):
 
     def forward(self, x):
         return ops.MaxMarginFunction.apply(x[self.sim_key], self.margin, self.lamda1)
+
+
+class ClipFrameBceLoss(nn.Module):
+    """losses.py:186-210 in the reference: (1 - w) * ClipBceLoss(clip_sim, weak_label) + w * FrameBceLoss(frame_sim (B,T,N),
+    strong_label (B,T,N), length).  The 3-D frame term equals the 2-D kernel over rows (b, n) of length[b] (the mask count
+    is sum_b len_b * N either way), so the (B,T,N) view of MultiTextBiEncoder's (B*N,T) scores is used as it lies."""
+
+    def __init__(self, frame_weight, clip_label_key="weak_label", clip_prob_key="clip_sim", frame_label_key="strong_label",
+                 frame_prob_key="frame_sim"):
+        super().__init__()
+        self.clip_loss_fn, self.frame_loss_fn = ClipBceLoss(), FrameBceLoss()
+        self.frame_weight = frame_weight
+        self.clip_label_key, self.clip_prob_key = clip_label_key, clip_prob_key
+        self.frame_label_key, self.frame_prob_key = frame_label_key, frame_prob_key
+
+    def forward(self, output: Dict):
+        fs, lab = output[self.frame_prob_key], output[self.frame_label_key]
+        B, T, N = fs.shape
+        fs2 = fs.transpose(1, 2).reshape(B * N, T)                      # a view for MultiTextBiEncoder's output
+        lab2 = lab.to(fs.device).float().transpose(1, 2).reshape(B * N, T).contiguous()
+        length = torch.as_tensor(output["length"]).long().to(fs.device).repeat_interleave(N).contiguous()
+        frame = ops.FrameBceFunction.apply(fs2.contiguous(), lab2, length, T)
+        clip = self.clip_loss_fn.forward_tensor(output[self.clip_prob_key], output[self.clip_label_key])
+        return (1 - self.frame_weight) * clip + self.frame_weight * frame

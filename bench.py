@@ -242,9 +242,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line on stdout: RCCL / HIP print banners through C stdio, whose buffer would
+        # otherwise be flushed at exit, after Python's own output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

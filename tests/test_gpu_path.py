@@ -415,3 +415,33 @@ def test_training_trajectory_matches_oracle(dev, math_):
     assert ref[-1] < ref[0] - 0.005                                  # the oracle actually learns on this batch
     assert max(abs(a - b) for a, b in zip(hip, ref)) < 3e-3           # Adam's sign-like first steps amplify fp32 noise
     assert abs(hip[0] - ref[0]) < 2e-5
+
+
+@pytest.mark.parametrize("math_", ["fp32", "x3"])
+def test_training_step_is_bitwise_deterministic(dev, math_):
+    """Every reduction of the path folds its partials in a fixed order (no atomics except the embedding scatter-add, whose
+    addends per row are few): two runs of the same step from the same state give bit-identical losses and gradients --
+    with the weight-gradient convs on the side stream."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=3, logit_gain=40.0)
+    batch = O.synthetic_batch(3, 64000, seed=8, ragged=True)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = math_
+    try:
+        res = []
+        for _ in range(2):
+            torch.manual_seed(123)                       # same dropout seeds
+            model = build_hip_model(st, "dot", dev).train()
+            runner = StrongRunner(model, device=str(dev))
+            loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            res.append((loss.item(), runner.flat.grad.clone()))
+    finally:
+        ops.CONV_MATH = old
+    assert res[0][0] == res[1][0]
+    emb = [n for n, _ in model.named_parameters()].index("text_encoder.embedding.core.weight")
+    off = sum(p.numel() for i, (_, p) in enumerate(model.named_parameters()) if i < emb)
+    n_emb = dict(model.named_parameters())["text_encoder.embedding.core.weight"].numel()
+    same = res[0][1] == res[1][1]
+    same[off:off + n_emb] = True                         # scatter-add rows use atomics (order-dependent rounding)
+    assert bool(same.all()), f"{int((~same).sum())} gradient elements differ between two identical runs"

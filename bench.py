@@ -49,14 +49,23 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(batch=8, iters=2):
-    """The oracle (plain PyTorch eager CPU restatement) timed on the host cores: fwd+bwd, dropout on."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _time_oracle(batch, iters, threads):
     from oracle import tag_oracle as O
-    torch.set_num_threads(usable_cores())
+    torch.set_num_threads(threads)
     st = O.state_to(O.init_state(seed=0), torch.float32, requires_grad=True)
     b = O.synthetic_batch(batch, 320000, seed=1234)
     times = []
-    for i in range(iters + 1):
+    for i in range(iters + 1):                 # 1 warm-up + iters timed
         for v in st.values():
             if v.is_floating_point() and v.grad is not None:
                 v.grad = None
@@ -64,9 +73,39 @@ def cpu_baseline(batch=8, iters=2):
         loss, _ = O.train_step_loss(st, b, "dot", "cnn8rnn", True)
         loss.backward()
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": batch / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fwd+bwd, B={batch} x 10 s clips, median of {iters} after 1 warm-up"}
+    return sorted(times[1:])[len(times[1:]) // 2]
+
+
+def cpu_baseline(batch=16, iters=5):
+    """the oracle (plain PyTorch eager CPU restatement of the reference) timed on the host cores of
+    this box: one training step's fwd+bwd, dropout on, B = 16 (configs[0]), 1 warm-up + 5 timed, median; all usable cores
+    and -- on a smaller sample of the same workload, to bound the run -- one thread."""
+    cores = usable_cores()
+    t_all = _time_oracle(batch, iters, cores)
+    t_one = _time_oracle(2, iters, 1)
+    return {"value": round(batch / t_all, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"oracle fwd+bwd (Cnn8Rnn + EmbeddingAgg(512) + DotProduct, dropout on), B={batch} x 10 s clips, "
+                      f"median of {iters} after 1 warm-up",
+            "single_thread": {"value": round(2 / t_one, 3), "unit": "clips/s", "cores": 1,
+                              "sample": f"same step, B=2, median of {iters} after 1 warm-up"}}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks on this node
+    (one process per GPU, rendezvous on 127.0.0.1); the child rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -87,6 +126,8 @@ def main():
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
                          "(the contract's number); x3 = opt-in 3 x bf16 split on the bf16 MFMA (conv_x3.hip)")
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        sys.exit(self_launch(args))
 
     import torch.distributed as dist
     from texttoaudiogrounding_amd import ops
@@ -95,7 +136,8 @@ def main():
 
     ops.CONV_MATH = args.conv_math
     rank, world, local = init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     torch.manual_seed(0)
@@ -234,11 +276,17 @@ def main():
                                        "fwd+bwd+clip+Adam, dropout on, train-mode BN"), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math},
-               "loss": round(float(loss.item()), 6),
+               "loss": round(runner.loss_value(loss), 6),
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 / PEAK_FP32_MFMA, 4),
                "roofline": roof}
         if alt:
             out["alt_conv_math"] = alt
+        out["ranks_observed"] = dist.get_world_size() if world > 1 else 1
+        out["backend"] = dist.get_backend() if world > 1 else None
+        if world > 1:
+            out["comm"] = {"collective": "all-reduce(sum) of the flat fp32 gradient in buckets, launched from inside backward",
+                           "buckets_MB": [round((e - s0) * 4 / 2 ** 20, 2) for (s0, e, _, _) in runner.buckets.bounds],
+                           "overlap": runner.overlap_comm}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             out["cpu_baseline"] = cpu_baseline()

@@ -119,6 +119,24 @@ int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* in_scale, co
                          const float* dy, float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout,
                          int products, void* ws, void* stream);
 /* dw (Cout,Cin,3,3) = sum over pixels of prologue(x)[shifted] * dy ; ws from *_ws_bytes */
+/* dgrad convolution fused with the REDUCTION half of the BatchNorm+ReLU backward its result flows into
+ * (models/panns.py:49-50 backward: relu_(bn(conv(x)))).  da = conv(dy, wpack_dgrad) is written as by
+ * tag_conv3x3_forward; in the epilogue every 64-pixel wave tile also reads yref (the raw conv output the forward
+ * pass saved = the BatchNorm input at the same pixels/channels) and writes the partial sums over the tile of
+ *   g = da * [yref*bn_scale + bn_shift > 0]    and    g * (yref - bn_mean) * bn_invstd
+ * to bnpart [P][2][Cout] (P = tag_conv3x3_stats_rows(B,H,W,Cout) > 0: halo-tile shapes only).  The MFMA-bound conv
+ * hides that read; the separate two-tensor reduction pass of tag_bnrelu_backward disappears.
+ * tag_bn_grad_from_partials folds the rows (fp64, fixed order) into dgamma / dbeta; tag_bnrelu_backward_apply is the
+ * apply half: dy = gamma*invstd*(g - dbeta/N - xhat*dgamma/N) (bn_train) or gamma*invstd*g. */
+int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, float* da, const float* yref,
+                             const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                             const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
+                             void* stream);
+size_t tag_bn_grad_from_partials_ws_bytes(int P, int C);
+int tag_bn_grad_from_partials(const float* bnpart, int P, int C, float* dgamma, float* dbeta, void* ws, void* stream);
+int tag_bnrelu_backward_apply(const float* y, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const float* gamma, const float* da, float* dy,
+                              const float* dgamma, const float* dbeta, long rows, int C, int bn_train, void* stream);
 size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift,
                       const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
@@ -209,11 +227,16 @@ int tag_relu_backward(const float* y, const float* dy, float* dx, long n, void* 
  *   gates(B,T,2,4H) saved r,z,n and (W_hn h + b_hn) for the backward pass (nullable in inference)
  * backward: dy (B,T,2H) -> dgi (B,T,2,3H), dgh (B,T,2,3H); hprev (B,T,2,H) is also written
  * (h_{t-1} per direction) so that dW_hh = dgh^T hprev is a plain GEMM for the caller.
- * When (H/16)*ceil(B/16)*2 <= 256 the whole sequence is ONE persistent launch (weights in registers,
- * state exchanged between workgroups through tagged 8-byte granules); otherwise one launch per step.
+ * When the grid (H/16)*ceil(B/16)*2 fits the device (occupancy query x CUs) the whole sequence is ONE persistent
+ * launch (weights in registers, state exchanged between workgroups through tagged 8-byte granules), issued with
+ * hipLaunchCooperativeKernel so that co-residency of the spinning workgroups is guaranteed by the runtime; if the
+ * grid does not fit or the cooperative launch is refused, one launch per step (same arithmetic).
  * ------------------------------------------------------------------------------------------- */
 /* scratch for both directions of either pass: transposed weights + the exchange granules of the persistent
- * kernels + an error word (last 256 bytes; non-zero after a sync = a bounded spin timed out) */
+ * kernels + a STICKY error word (last 256 bytes): the CALLER zero-fills the scratch once when it allocates it; a
+ * persistent kernel whose bounded spin ran out sets the word (and poisons its outputs with NaN, which makes
+ * tag_adam_step skip the step); the library never clears it.  Copy the last 256 bytes to the host after a
+ * synchronisation and pass them to tag_gru_timed_out. */
 size_t tag_gru_ws_bytes(int B, int T, int H);
 int tag_gru_forward(const float* gi, const float* w_hh, const float* b_hh, float* y, float* gates,
                     void* ws /* tag_gru_ws_bytes */, int B, int T, int H, void* stream);
@@ -226,8 +249,13 @@ int tag_gru_timed_out(const void* host_copy_of_err_word);
  * T1 + T2: nn.Embedding gather + mean over valid tokens
  * models/text_encoder.py:39-43,79-88; models/utils.py:33-58.
  * text (B,L) int64, text_len (B) int64, table (V,D); token_emb (B,L,D) nullable; seq_emb (B,D).
- * backward accumulates into dtable (V,D), which the caller zero-fills.
+ * backward accumulates into dtable (V,D), which the caller zero-fills; it is DETERMINISTIC (no atomics: the
+ * first occurrence of a token id owns its table row and sums all occurrences in a fixed order).
+ * nn.Embedding raises on ids outside [0,V): tag_embed_check_ids sets *err_flag (device int, sticky, caller-zeroed)
+ * to 1 when any id is out of range -- the host reads it at its next synchronisation; the gather/scatter kernels
+ * clamp (forward) or skip (backward) such ids so that nothing is read or written out of bounds.
  * ------------------------------------------------------------------------------------------- */
+int tag_embed_check_ids(const int64_t* text, long n, int V, int* err_flag, void* stream);
 int tag_embed_mean_forward(const int64_t* text, const int64_t* text_len, const float* table,
                            float* token_emb, float* seq_emb, int B, int L, int D, int V, void* stream);
 int tag_embed_mean_backward(const float* dseq, const int64_t* text, const int64_t* text_len,
@@ -280,7 +308,8 @@ int tag_segments(const float* sim, int ld, int B, int T, const double* threshold
  * O1: clip_grad_norm_ + Adam on a flat fp32 buffer (run_strong.py:143-145; torch.optim.Adam).
  * tag_sumsq: out[0] (double) = sum g^2 (zero-filled by the call).  tag_adam_step reads the squared
  * norm from device memory: coef = min(1, max_norm / (sqrt(gnorm_sq) + 1e-6)); max_norm <= 0 disables.
- * grad_scale multiplies g first (1/world_size for DP averaging).
+ * grad_scale multiplies g first (1/world_size for DP averaging).  A non-finite squared norm makes tag_adam_step a
+ * no-op (parameters and moments untouched): one poisoned step cannot destroy the optimiser state.
  * ------------------------------------------------------------------------------------------- */
 size_t tag_sumsq_ws_bytes(long n);
 int tag_sumsq(const float* g, long n, double* out, void* ws, void* stream);

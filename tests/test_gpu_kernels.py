@@ -352,6 +352,38 @@ def test_bnrelu_backward(ops, dev):
     assert relerr(dg, gd.grad) < 5e-6 and relerr(db, bd.grad) < 5e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cin,C", [(2, 9, 8, 64, 128), (1, 17, 16, 128, 64), (2, 21, 32, 64, 64), (2, 33, 64, 64, 64),
+                                         (3, 250, 8, 512, 512)])
+def test_conv_dgrad_fused_bnrelu_backward(ops, dev, B, H, W, Cin, C):
+    """tag_conv3x3_dgrad_bnsums + tag_bn_grad_from_partials + tag_bnrelu_backward_apply (BatchNorm-backward sums in the
+    dgrad conv epilogue) against the fp64 chain  a = relu(bn(y)); u = conv(a, w); backward(du)."""
+    g = torch.Generator().manual_seed(H * W + C)
+    y = torch.randn(B, C, H, W, generator=g) * (1.0 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.3
+    w = torch.randn(Cin, C, 3, 3, generator=g) / math.sqrt(9 * C)       # the conv that CONSUMES relu(bn(y)): C -> Cin
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    du = torch.randn(B, Cin, H, W, generator=g)
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5))
+    F.conv2d(a, w.double(), padding=1).backward(du.double())
+    yh = nhwc(y).to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gamma.to(dev), beta.to(dev), None, None, True)
+    _, wd = ops.pack_conv_weight(w.to(dev), W=W)                          # dgrad pack: Cin -> C
+    assert ops.FUSE_BN_BWD_SUMS and ops.query("tag_conv3x3_stats_rows", B, H, W, C) > 0
+    dy, dg, db = ops.conv3x3_dgrad_bnrelu_backward(nhwc(du).to(dev), wd, yh, st, gamma.to(dev))
+    e = (relerr(nchw(dy), yd.grad), relerr(dg, gd.grad), relerr(db, bd.grad))
+    print(f"fused dgrad+BN backward: dy {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
+    assert max(e) < 1e-5
+    # and equal (to rounding) to the unfused kernels
+    old = ops.FUSE_BN_BWD_SUMS
+    ops.FUSE_BN_BWD_SUMS = False
+    try:
+        dy2, dg2, db2 = ops.conv3x3_dgrad_bnrelu_backward(nhwc(du).to(dev), wd, yh, st, gamma.to(dev))
+    finally:
+        ops.FUSE_BN_BWD_SUMS = old
+    assert relerr(dy, dy2) < 2e-6 and relerr(dg, dg2) < 2e-6 and relerr(db, db2) < 2e-6
+
+
 @pytest.mark.parametrize("pre", [0, 1])
 def test_bn_act_backward(ops, dev, pre):
     """BatchNorm in front of a conv (CrnnEncoder cdur_block): u = bn(pre(x)), pre = identity | leaky_relu(0.1)."""
@@ -507,6 +539,51 @@ def test_embed_mean(ops, dev):
     ref["seq_emb"].backward(dseq.double())
     seq.backward(dseq.to(dev))
     assert relerr(tab.grad, td.grad) < 1e-6
+
+
+def test_embed_backward_repeated_ids_is_deterministic_and_flags_bad_ids(ops, dev):
+    """Many (clip, position) pairs share table rows; seq_emb AND token_emb gradients flow; the table gradient equals the
+    fp64 oracle and is bit-identical run to run (no atomics).  An id outside [0,V) raises at the next host check, as
+    nn.Embedding would (models/text_encoder.py:39)."""
+    g = torch.Generator().manual_seed(11)
+    V, D, B, L = 7, 512, 64, 4                                   # 256 pairs over 7 rows
+    table = torch.randn(V, D, generator=g)
+    text = torch.randint(0, V, (B, L), generator=g)
+    lens = 1 + torch.arange(B) % 4
+    td = table.double().requires_grad_(True)
+    ref = O.embedding_agg_mean({"text_encoder.embedding.core.weight": td}, text, lens)
+    dseq, dtok = torch.randn(B, D, generator=g), torch.randn(B, L, D, generator=g)
+    (ref["seq_emb"] * dseq.double()).sum().add((ref["token_emb"] * dtok.double()).sum()).backward()
+    outs = []
+    for _ in range(2):
+        tab = table.to(dev).requires_grad_(True)
+        seq, tok = ops.EmbedMeanFunction.apply(tab, text.to(dev), lens.to(dev), True)
+        torch.autograd.backward([seq, tok], [dseq.to(dev), dtok.to(dev)])
+        outs.append(tab.grad.clone())
+    assert relerr(outs[0], td.grad) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+    ops.check_async_errors()                                     # all ids valid: nothing raised
+    bad = text.clone()
+    bad[3, 0] = V + 5
+    ops.EmbedMeanFunction.apply(table.to(dev), bad.to(dev), lens.to(dev), False)
+    with pytest.raises(IndexError):
+        ops.check_async_errors()
+    ops.check_async_errors()                                     # the flag was cleared by the raise
+
+
+def test_adam_skips_non_finite_gradient_norm(ops, dev):
+    """One poisoned step (NaN from a timed-out GRU exchange) must not destroy parameters or moments."""
+    n = 4099
+    p = torch.randn(n, device=dev)
+    m, v = torch.rand(n, device=dev), torch.rand(n, device=dev)
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    gr = torch.randn(n, device=dev)
+    gr[17] = float("nan")
+    gsq = ops.grad_sumsq(gr)
+    assert not torch.isfinite(gsq).item()
+    ops.adam_step(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1, gsq, 1.0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0)
 
 
 @pytest.mark.parametrize("kind,l2norm,scale", [(0, False, True), (0, True, False), (1, True, False), (1, False, False)])

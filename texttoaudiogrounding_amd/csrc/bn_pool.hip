@@ -94,26 +94,38 @@ struct StatsFn1 {
     }
 };
 
-// sum the per-block partials: 256 threads = 16 channels x 16 interleaved parts, folded through LDS in a
-// fixed order (deterministic)
+// sum the per-block partials: FOLD_T threads = 16 channels x FOLD_P interleaved parts (4 independent loads in flight per
+// thread and quantity), folded through LDS in a fixed order (deterministic).  One block per 16 channels used to walk up
+// to 1024 partial rows with 16 threads per channel (64 dependent-latency loads each: 95 us per call, 617 us at C = 512);
+// 64 parts x 4-way unrolled loads bring that to a few microseconds.
+constexpr int FOLD_P = 64, FOLD_T = 16 * FOLD_P;
 __device__ __forceinline__ void fold_partials(const double* __restrict__ partials, int nblk, int C, int c, int part,
                                               double& s1, double& s2) {
-    __shared__ double sh[2][16][17];
-    double a = 0, b = 0;
-    if (c < C)
-        for (int blk = part; blk < nblk; blk += 16) {
-            a += partials[(size_t)blk * 2 * C + c];
-            b += partials[(size_t)blk * 2 * C + C + c];
+    __shared__ double sh[2][FOLD_P][17];
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (c < C) {
+        int blk = part;
+        for (; blk + 3 * FOLD_P < nblk; blk += 4 * FOLD_P) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] += partials[(size_t)(blk + u * FOLD_P) * 2 * C + c];
+                b[u] += partials[(size_t)(blk + u * FOLD_P) * 2 * C + C + c];
+            }
         }
-    sh[0][part][threadIdx.x & 15] = a;
-    sh[1][part][threadIdx.x & 15] = b;
+        for (; blk < nblk; blk += FOLD_P) {
+            a[0] += partials[(size_t)blk * 2 * C + c];
+            b[0] += partials[(size_t)blk * 2 * C + C + c];
+        }
+    }
+    sh[0][part][threadIdx.x & 15] = (a[0] + a[1]) + (a[2] + a[3]);
+    sh[1][part][threadIdx.x & 15] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
     s1 = 0; s2 = 0;
     if (part == 0)
-        for (int q = 0; q < 16; ++q) { s1 += sh[0][q][threadIdx.x & 15]; s2 += sh[1][q][threadIdx.x & 15]; }
+        for (int q = 0; q < FOLD_P; ++q) { s1 += sh[0][q][threadIdx.x & 15]; s2 += sh[1][q][threadIdx.x & 15]; }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk,
+__global__ __launch_bounds__(FOLD_T) void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                                long rows, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps,
                                                                float momentum, float* running_mean,
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_stats_partials_finalize_kernel(const d
 }
 
 // dgamma / dbeta finalize: partial slot 0 = sum dz, slot 1 = sum dz*xhat
-__global__ __launch_bounds__(256) void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
+__global__ __launch_bounds__(FOLD_T) void bn_grad_finalize_kernel(const double* __restrict__ partials, int nblk, int C,
                                                               float* dgamma, float* dbeta) {
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     double s1, s2;
@@ -225,6 +237,30 @@ __global__ __launch_bounds__(256) void bn_grad_finalize_kernel(const double* __r
     if (part != 0 || c >= C) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
+}
+
+// dgamma / dbeta from the fp32 partial rows the dgrad conv epilogue writes (conv3x3_halo_kernel<.., EPI = 1>): row p =
+// [sum g | sum g*xhat] over one 64-pixel wave tile.  Stage 1: (16 channels) x (row chunk) blocks fold their rows in fp64;
+// stage 2: one block per 16 channels folds the chunks.  Fixed order throughout.
+__global__ __launch_bounds__(256) void bn_grad_partials_reduce_kernel(const float* __restrict__ part, int P, int C,
+                                                                     int rows_per_chunk, double* __restrict__ out) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
+    const int p0 = blockIdx.y * rows_per_chunk, p1 = min(P, p0 + rows_per_chunk);
+    double a = 0, b = 0;
+    if (c < C)
+        for (int p = p0 + g; p < p1; p += 16) {
+            a += (double)part[(size_t)p * 2 * C + c];
+            b += (double)part[(size_t)p * 2 * C + C + c];
+        }
+    sh[0][g][cl] = a; sh[1][g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double t1 = 0, t2 = 0;
+        for (int q = 0; q < 16; ++q) { t1 += sh[0][q][cl]; t2 += sh[1][q][cl]; }
+        out[((size_t)blockIdx.y * 2) * C + c] = t1;           // same [blk][2][C] layout as the reduce2 partials
+        out[((size_t)blockIdx.y * 2 + 1) * C + c] = t2;
+    }
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -705,7 +741,7 @@ extern "C" int tag_bn_stats(const float* x, long rows, int C, int pre_op, const 
                            StatsFn1{x, C, pre_op}, rows, C, partials);
     }
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk,
                        rows, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -765,7 +801,7 @@ extern "C" int tag_bn_param_grad(const float* x, const float* dy, long rows, int
     hipLaunchKernelGGL(reduce2_kernel<ParamGradFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
                        as_stream(stream), ParamGradFn{x, dy, mean, invstd, C}, rows, C, partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -813,7 +849,7 @@ extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, cons
     PoolBwdCtx<PH, PW> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                         \
     hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),          \
                        as_stream(stream), ctx, partials);                                                          \
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, \
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, \
                        C, dgamma, dbeta);                                                                          \
     hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma,     \
                        dgamma, dbeta, bn_train, dy);
@@ -837,10 +873,41 @@ extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const flo
     hipLaunchKernelGGL(reduce2_kernel<BnReluBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
                        as_stream(stream), fn, rows, C, partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn,
                        gamma, dgamma, dbeta, bn_train, rows, dy);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_bn_grad_from_partials_ws_bytes(int P, int C) {
+    int r;
+    return (size_t)stat_chunks(P, &r) * 2 * C * sizeof(double);
+}
+extern "C" int tag_bn_grad_from_partials(const float* bnpart, int P, int C, float* dgamma, float* dbeta, void* ws,
+                                         void* stream) {
+    TAG_CHECK_ARG(bnpart && dgamma && dbeta && ws && P > 0 && C > 0);
+    int rpc;
+    const int nch = stat_chunks(P, &rpc);
+    double* chunks = static_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_grad_partials_reduce_kernel, dim3(cdiv(C, 16), nch), dim3(256), 0, as_stream(stream), bnpart, P, C,
+                       rpc, chunks);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), chunks, nch, C, dgamma,
+                       dbeta);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+// the APPLY half of tag_bnrelu_backward alone: dgamma / dbeta already hold sum(g*xhat) / sum(g)
+extern "C" int tag_bnrelu_backward_apply(const float* y, const float* scale, const float* shift, const float* mean,
+                                         const float* invstd, const float* gamma, const float* da, float* dy,
+                                         const float* dgamma, const float* dbeta, long rows, int C, int bn_train,
+                                         void* stream) {
+    TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && da && dy && dgamma && dbeta && vec_ok(C));
+    BnReluBwdFn fn{y, scale, shift, mean, invstd, da, C};
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn, gamma,
+                       dgamma, dbeta, bn_train, rows, dy);
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -879,7 +946,7 @@ extern "C" int tag_bn_act_backward(const float* x, int pre_op, const float* mean
     hipLaunchKernelGGL(reduce2_kernel<BnActBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double), as_stream(stream),
                        fn, rows, C, partials);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, as_stream(stream), partials, nblk, C,
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn, gamma,
                        dgamma, dbeta, bn_train, rows, dx);

@@ -260,12 +260,21 @@ struct HaloGeom {
     static constexpr int ITEMS = (PP * 8 + 255) / 256;            // float4 per thread per patch chunk
 };
 
-template <int BN_, int PRO, int TW>
+// Epilogue operands of the dgrad launches (EPI == 1): the tensor whose BatchNorm+ReLU the gradient flows into next.
+struct BnBwdEpi {
+    const float* yref;      // (B,H,W,Cout) raw conv output saved by the forward pass (= BatchNorm input)
+    const float* scale;     // gamma * invstd
+    const float* shift;     // beta - mean * gamma * invstd
+    const float* mean;
+    const float* invstd;
+};
+
+template <int BN_, int PRO, int TW, int EPI = 0>
 __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
-                                                              float* __restrict__ stats, int B, int H, int W, int Cin,
-                                                              int Cout) {
+                                                              float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
+                                                              int Cin, int Cout) {
     using G = HaloGeom<TW>;
     constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = TAG_HALO_NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -445,7 +454,46 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
     // mean as rounded in fp32), r = sum(y - mu) and q = sum((y - mu)^2): the tile's sum is n*mu + r EXACTLY up to the
     // rounding of the small deviations, so channels whose |mean| >> std keep their variance;
     // tag_bn_stats_from_partials merges the tiles in fp64 ----
-    if (stats) {
+    // ---- EPI == 1 (dgrad launches): the reduction half of the BatchNorm+ReLU backward this gradient flows into.  The
+    // accumulators hold da = dL/d relu(bn(yref)); with g = da * [bn(yref) > 0] and xhat = (yref - mean) * invstd the
+    // BatchNorm backward needs sum(g) (= dbeta) and sum(g * xhat) (= dgamma) per channel BEFORE any dy can be formed.
+    // Each wave folds them over its 64 pixels here -- yref is read once, by a kernel that is MFMA-bound and leaves the
+    // HBM pipe idle -- instead of a separate 2-tensor pass (reduce2_kernel<BnReluBwdFn>).  Row layout [prow][2][Cout];
+    // tag_bn_grad_from_partials merges the rows in fp64 in a fixed order. ----
+    if (EPI == 1) {
+        const int prow = mt * 2 + (wid >> 1);
+        float* ps = stats + (size_t)prow * 2 * Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + ml;
+            const int nc = n < Cout ? n : 0;
+            const float sc = epi.scale[nc], sh = epi.shift[nc], mu = epi.mean[nc], is = epi.invstd[nc];
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float yv[16];                                // 16 loads in flight, then their arithmetic
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    const int h = h0 + m / TW, w = m % TW;
+                    const int hc = h < H ? h : H - 1;
+                    yv[r] = epi.yref[(((size_t)img * H + hc) * W + w) * Cout + nc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    const bool ok = (h0 + m / TW) < H;
+                    const float g = (ok && fmaf(yv[r], sc, sh) > 0.0f) ? acc[i][j][r] : 0.0f;
+                    s1 += g;
+                    s2 = fmaf(g, (yv[r] - mu) * is, s2);
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (kl == 0 && n < Cout) { ps[n] = s1; ps[Cout + n] = s2; }
+        }
+    }
+    if (EPI == 0 && stats) {
         const int prow = mt * 2 + (wid >> 1);                        // partial row of this wave
         float* ps = stats + (size_t)prow * 3 * Cout;
         float cnt = 0.0f;
@@ -1360,10 +1408,22 @@ static int launch_fwd(const float* x, const float* wp, int pro, const float* s, 
 
 template <int BN_, int TW>
 static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, float* stats,
-                        int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+                        const BnBwdEpi* epi, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = HaloGeom<TW>;
     const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
     const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + TAG_HALO_NB * BK * BN_ + 2 * 512) * sizeof(float);
+    if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, 0, TW, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
+                           B, H, W, Cin, Cout);
+        return;
+    }
+    const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
 #define LAUNCH_PRO(P)                                                                                             \
     {                                                                                                             \
         static bool attr_set = false;                                                                             \
@@ -1373,7 +1433,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
             attr_set = true;                                                                                      \
         }                                                                                                         \
         hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
-                           B, H, W, Cin, Cout);                                                                   \
+                           none, B, H, W, Cin, Cout);                                                             \
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;
@@ -1404,11 +1464,12 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     hipStream_t st = as_stream(stream);
     const bool halo = conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(stats == nullptr || halo);
+#define EPI_PTR nullptr
 #define HALO_BY_W(BN_)                                                                                          \
-    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);        \
-    else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st); \
-    else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st); \
-    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, stats, B, H, W, Cin, Cout, st);
+    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);        \
+    else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
+    else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
+    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);
     if (halo) {
         if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
     } else if (Cout >= 128) {
@@ -1416,6 +1477,32 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     } else {
         launch_fwd<64>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
     }
+#undef EPI_PTR
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgrad convolution + the reduction half of the BatchNorm+ReLU backward its output flows into (see the EPI == 1 epilogue).
+// Only the halo-tile kernel has it: widths 8/16/32/64 (tag_conv3x3_stats_rows > 0); other shapes use tag_conv3x3_forward +
+// tag_bnrelu_backward.
+extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, float* da, const float* yref,
+                                        const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                        const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
+                                        void* stream) {
+    TAG_CHECK_ARG(dy && wpack && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart);
+    TAG_CHECK_ARG(B > 0 && H > 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
+    TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));
+    TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
+    hipStream_t st = as_stream(stream);
+    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd};
+    const float* x = dy;
+    float* y = da;
+    float* stats = bnpart;
+    const int prologue = 0;
+    const float *in_scale = nullptr, *in_shift = nullptr;
+#define EPI_PTR (&epi)
+    if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+#undef EPI_PTR
 #undef HALO_BY_W
     TAG_LAUNCH_CHECK();
     return 0;

@@ -218,17 +218,6 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
         db[r * D + d] = ds * a[r * D + d];
     }
 }
-// dtable[text[b,l]] += dtok[b,l,:]  (embedding scatter-add; rows can repeat -> atomics, as in tag_embed_mean_backward)
-__global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __restrict__ dtok, const long* __restrict__ text,
-                                                               float* __restrict__ dtable, long rows, int D, int V) {
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const long id = text[r];
-    if (id < 0 || id >= V) return;
-    for (int d = lane; d < D; d += 64) atomicAdd(dtable + id * D + d, dtok[r * D + d]);
-}
-
 }  // namespace
 
 extern "C" int tag_addattn_forward(const float* aq, const float* ak, const float* v, const float* kv, const long* qlen,
@@ -316,12 +305,3 @@ extern "C" int tag_rowdot_sigmoid_backward(const float* a, const float* b, const
     return 0;
 }
 
-extern "C" int tag_embed_tokens_backward(const float* dtok, const long* text, float* dtable, int B, int L, int D, int V,
-                                         void* stream) {
-    TAG_CHECK_ARG(dtok && text && dtable && B > 0 && L > 0 && D > 0 && V > 0);
-    const long rows = (long)B * L;
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), dtok, text, dtable, rows,
-                       D, V);
-    TAG_LAUNCH_CHECK();
-    return 0;
-}

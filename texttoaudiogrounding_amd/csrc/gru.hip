@@ -9,6 +9,7 @@
 // split over the 4 waves of a workgroup on v_mfma_f32_16x16x4_f32 and reduced through LDS, so a
 // step is ~130 workgroups of a few hundred cycles.  All launches of a sequence are issued
 // back-to-back from one C call on the caller's stream.
+#include <stdlib.h>
 #include "tag_common.h"
 
 namespace {
@@ -406,12 +407,38 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
     }
 }
 
-// the persistent kernels need every workgroup resident at once (one per CU): grid <= CUs of THIS device (256 on a
-// whole MI355X, fewer in a partitioned mode); otherwise the per-step kernels are used
-bool gru_persistent_ok(int B, int H) {
+// The persistent kernels spin on their neighbours: every workgroup of the grid must be resident at once.
+// (1) static check: grid <= occupancy(kernel) x CUs of THIS device (256 on a whole MI355X, fewer in a partitioned mode);
+// (2) the launch itself is hipLaunchCooperativeKernel -- the runtime then guarantees co-residency (it refuses an
+//     over-size grid with hipErrorCooperativeLaunchTooLarge and does not interleave the grid with other queues' work);
+// (3) if either fails the launcher falls back to the per-step kernels (same arithmetic, one launch per time step);
+// (4) every spin is bounded and a timeout raises the STICKY error word of the scratch (ops.check_async_errors()).
+// TAG_GRU_COOP=0 (environment) switches (2) off -> plain launch, for A/B timing only.
+template <class K>
+bool gru_grid_fits(K kernel, int grid_blocks) {
     static int cus = 0;
     if (cus == 0) { cus = tag_device_cu_count(); if (cus <= 0) cus = 1; }
-    return (H == 256 || H == 128) && (H / 16) * ((B + 15) / 16) * 2 <= cus;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return false;
+    // one workgroup per CU is what the exchange latency was tuned for; more than one per CU is still correct as long
+    // as all are resident, but keep a margin of one block per CU against the occupancy API's optimism (guide, residency)
+    const int safe = per_cu > 1 ? per_cu - 1 : 1;
+    return grid_blocks <= safe * cus;
+}
+bool gru_coop_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TAG_GRU_COOP"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+// returns hipSuccess when the persistent kernel was launched; anything else -> caller falls back to the step kernels
+template <class K>
+hipError_t gru_launch_persistent(K kernel, dim3 grid, void** args, hipStream_t st) {
+    if (!gru_coop_enabled()) {
+        return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, dim3(256), args, 0, st);
+    }
+    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, dim3(256), args, 0, st);
+    if (e != hipSuccess) (void)hipGetLastError();       // clear the sticky launch error; the caller falls back
+    return e;
 }
 
 }  // namespace
@@ -444,17 +471,20 @@ extern "C" int tag_gru_forward(const float* gi, const float* w_hh, const float* 
     hipLaunchKernelGGL(gru_transpose_whh_kernel, dim3(cdiv((long)6 * H * H, 256)), dim3(256), 0, st, w_hh, wt, H);
     TAG_LAUNCH_CHECK();
     const dim3 grid(H / 16, (B + 15) / 16, 2);
-    if (gru_persistent_ok(B, H) && T > 1) {
+    const int nblk = (int)(grid.x * grid.y * grid.z);
+    if ((H == 256 || H == 128) && T > 1) {
         u64* hx = reinterpret_cast<u64*>(static_cast<char*>(ws) + off_x);
         unsigned* err = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + off_err);
-        // tags must not match any epoch (1..T) before the first write; also clears the error word
-        if (hipMemsetAsync(hx, 0, off_err + 256 - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
-        if (H == 256)
-            hipLaunchKernelGGL(gru_fwd_persistent_kernel<256>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, hx, err, B, T);
-        else
-            hipLaunchKernelGGL(gru_fwd_persistent_kernel<128>, grid, dim3(256), 0, st, gi, wt, b_hh, y, gates, hx, err, B, T);
-        TAG_LAUNCH_CHECK();
-        return 0;
+        void* args[] = {(void*)&gi, (void*)&wt, (void*)&b_hh, (void*)&y, (void*)&gates, (void*)&hx, (void*)&err, (void*)&B, (void*)&T};
+        const bool fits = H == 256 ? gru_grid_fits(gru_fwd_persistent_kernel<256>, nblk)
+                                   : gru_grid_fits(gru_fwd_persistent_kernel<128>, nblk);
+        if (fits) {
+            // tags must not match any epoch (1..T) before the first write; the error word behind them is sticky
+            if (hipMemsetAsync(hx, 0, off_err - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
+            const hipError_t e = H == 256 ? gru_launch_persistent(gru_fwd_persistent_kernel<256>, grid, args, st)
+                                          : gru_launch_persistent(gru_fwd_persistent_kernel<128>, grid, args, st);
+            if (e == hipSuccess) return 0;
+        }
     }
     for (int s = 0; s < T; ++s) {
         if (H == 256)
@@ -475,18 +505,22 @@ extern "C" int tag_gru_backward(const float* dy, const float* y, const float* ga
     TAG_CHECK_ARG(H % 16 == 0 && (3 * H) % 32 == 0);
     hipStream_t st = as_stream(stream);
     const dim3 grid(H / 16, (B + 15) / 16, 2);
-    if (gru_persistent_ok(B, H) && T > 1) {
+    const int nblk = (int)(grid.x * grid.y * grid.z);
+    if ((H == 256 || H == 128) && T > 1) {
         size_t off_x, off_err;
         gru_ws_layout(B, H, &off_x, &off_err);
         u64* gx = reinterpret_cast<u64*>(static_cast<char*>(scratch) + off_x);
         unsigned* err = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + off_err);
-        if (hipMemsetAsync(gx, 0, off_err + 256 - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
-        if (H == 256)
-            hipLaunchKernelGGL(gru_bwd_persistent_kernel<256>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev, gx, err, B, T);
-        else
-            hipLaunchKernelGGL(gru_bwd_persistent_kernel<128>, grid, dim3(256), 0, st, dy, y, gates, w_hh, dgi, dgh, hprev, gx, err, B, T);
-        TAG_LAUNCH_CHECK();
-        return 0;
+        void* args[] = {(void*)&dy, (void*)&y, (void*)&gates, (void*)&w_hh, (void*)&dgi, (void*)&dgh, (void*)&hprev, (void*)&gx,
+                        (void*)&err, (void*)&B, (void*)&T};
+        const bool fits = H == 256 ? gru_grid_fits(gru_bwd_persistent_kernel<256>, nblk)
+                                   : gru_grid_fits(gru_bwd_persistent_kernel<128>, nblk);
+        if (fits) {
+            if (hipMemsetAsync(gx, 0, off_err - off_x, st) != hipSuccess) { tag_set_error("memset failed"); return TAG_ELAUNCH; }
+            const hipError_t e = H == 256 ? gru_launch_persistent(gru_bwd_persistent_kernel<256>, grid, args, st)
+                                          : gru_launch_persistent(gru_bwd_persistent_kernel<128>, grid, args, st);
+            if (e == hipSuccess) return 0;
+        }
     }
     float* dhbuf = static_cast<float*>(scratch);
     for (int s = 0; s < T; ++s) {

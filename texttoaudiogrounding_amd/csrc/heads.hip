@@ -30,19 +30,49 @@ __global__ __launch_bounds__(256) void embed_mean_fwd_kernel(const int64_t* __re
         seq_emb[(size_t)b * D + d] = s / (float)len;
     }
 }
-__global__ __launch_bounds__(256) void embed_mean_bwd_kernel(const float* __restrict__ dseq,
-                                                             const int64_t* __restrict__ text,
-                                                             const int64_t* __restrict__ text_len,
-                                                             float* __restrict__ dtable, int L, int D, int V) {
-    const int b = blockIdx.x;
-    const int len = (int)text_len[b];
-    for (int d = threadIdx.x; d < D; d += 256) {
-        const float g = dseq[(size_t)b * D + d] / (float)len;
-        for (int l = 0; l < L && l < len; ++l) {
-            int64_t tok = text[(size_t)b * L + l];
-            tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-            atomicAdd(dtable + (size_t)tok * D + d, g);
+// Deterministic embedding-table gradient (no atomics): one workgroup per (clip, position) pair p.  The workgroup whose
+// pair is the FIRST occurrence of its token id walks all later pairs with the same id in ascending order and adds
+//   [l < text_len[b]] * dseq[b] / text_len[b]   (mean_with_lens backward)   and / or   dtok[b,l]   (token_emb backward)
+// into registers, then adds the total to dtable[token] once -- every table row is owned by exactly one workgroup and
+// summed in a fixed order, so a training step is bit-reproducible.  O(P^2) id compares for P = B*L pairs (P <= a few
+// thousand on this path).  Out-of-range ids contribute nothing (tag_embed_check_ids raises the error flag for them).
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const float* __restrict__ dseq, const float* __restrict__ dtok,
+                                                            const int64_t* __restrict__ text,
+                                                            const int64_t* __restrict__ text_len,
+                                                            float* __restrict__ dtable, int P, int L, int D, int V) {
+    __shared__ int earlier;
+    const int p = blockIdx.x;
+    const int64_t tok = text[p];
+    if (tok < 0 || tok >= V) return;
+    if (threadIdx.x == 0) earlier = 0;
+    __syncthreads();
+    int found = 0;
+    for (int q = threadIdx.x; q < p; q += 256) found |= (text[q] == tok);
+    if (found) earlier = 1;                       // benign race: every writer stores 1
+    __syncthreads();
+    if (earlier) return;
+    for (int d0 = 0; d0 < D; d0 += 256) {
+        const int d = d0 + threadIdx.x;
+        float acc = 0.0f;
+        for (int q = p; q < P; ++q) {
+            if (text[q] != tok) continue;         // uniform across the workgroup
+            const int b = q / L, l = q - b * L;
+            if (d < D) {
+                if (dseq) {
+                    const int len = (int)text_len[b];
+                    if (l < len) acc += dseq[(size_t)b * D + d] / (float)len;
+                }
+                if (dtok) acc += dtok[(size_t)q * D + d];
+            }
         }
+        if (d < D) dtable[(size_t)tok * D + d] += acc;
+    }
+}
+__global__ __launch_bounds__(256) void embed_check_ids_kernel(const int64_t* __restrict__ text, long n, int V,
+                                                              int* __restrict__ err) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int64_t t = text[i];
+        if (t < 0 || t >= V) atomicExch(err, 1);
     }
 }
 
@@ -311,6 +341,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                    float bc1, float bc2_sqrt, const double* __restrict__ gnorm_sq,
                                                    float max_norm, float grad_scale) {
+    // a non-finite gradient norm (e.g. a GRU exchange that timed out and poisoned its outputs with NaN) must not reach
+    // the parameters or the moments: the whole step is skipped (the sticky error word tells the host why)
+    if (gnorm_sq && !isfinite(gnorm_sq[0])) return;
     float coef = grad_scale;
     if (max_norm > 0.0f && gnorm_sq) {
         const float norm = (float)sqrt(gnorm_sq[0]) * grad_scale;
@@ -511,12 +544,26 @@ extern "C" int tag_embed_mean_forward(const int64_t* text, const int64_t* text_l
 extern "C" int tag_embed_mean_backward(const float* dseq, const int64_t* text, const int64_t* text_len, float* dtable,
                                        int B, int L, int D, int V, void* stream) {
     TAG_CHECK_ARG(dseq && text && text_len && dtable && B > 0 && L > 0 && D > 0 && V > 0);
-    hipLaunchKernelGGL(embed_mean_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dseq, text, text_len, dtable,
-                       L, D, V);
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(B * L), dim3(256), 0, as_stream(stream), dseq, (const float*)nullptr, text,
+                       text_len, dtable, B * L, L, D, V);
     TAG_LAUNCH_CHECK();
     return 0;
 }
-
+extern "C" int tag_embed_tokens_backward(const float* dtok, const long* text, float* dtable, int B, int L, int D, int V,
+                                         void* stream) {
+    TAG_CHECK_ARG(dtok && text && dtable && B > 0 && L > 0 && D > 0 && V > 0);
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(B * L), dim3(256), 0, as_stream(stream), (const float*)nullptr, dtok,
+                       reinterpret_cast<const int64_t*>(text), (const int64_t*)nullptr, dtable, B * L, L, D, V);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_embed_check_ids(const int64_t* text, long n, int V, int* err_flag, void* stream) {
+    TAG_CHECK_ARG(text && err_flag && n > 0 && V > 0);
+    hipLaunchKernelGGL(embed_check_ids_kernel, dim3(cdiv(n, 256) > 64 ? 64 : cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                       text, n, V, err_flag);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int tag_match_forward(const float* audio, const float* text, float* sim, int kind, int l2norm, int scale,
                                  int B, int T, int D, void* stream) {
     TAG_CHECK_ARG(audio && text && sim && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);

@@ -33,6 +33,10 @@ _SIGS = {
     "tag_bn_stats_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
     "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_dgrad_bnsums": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_bn_grad_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
+    "tag_bn_grad_from_partials": (c_int, [P, c_int, c_int, P, P, P, P]),
+    "tag_bnrelu_backward_apply": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P]),
     "tag_conv3x3_x3_pack_bytes": (c_size_t, [c_int, c_int]),
     "tag_pack_conv_weight_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "tag_conv3x3_forward_x3": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -68,6 +72,7 @@ _SIGS = {
     "tag_gru_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_embed_mean_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_embed_mean_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_embed_check_ids": (c_int, [P, c_long, c_int, P, P]),
     "tag_match_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_match_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_align_dot_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -56,9 +56,55 @@ class _timed:
             PROFILE.setdefault(self.key, []).append((self.e0, self.e1, self.flops))
 
 
+#: data-parallel rank folded into every dropout seed (set by runner.StrongRunner): ranks seeded alike by
+#: torch.manual_seed still draw different masks for their different clips
+SEED_RANK = 0
+
+
 def new_seed() -> int:
-    """Dropout seed drawn from torch's global CPU generator (so torch.manual_seed controls it)."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    """Dropout seed drawn from torch's global CPU generator (so torch.manual_seed controls it), decorrelated per rank."""
+    s = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return (s + SEED_RANK * 0x9E3779B97F4A7C15) % (2 ** 62)
+
+
+# ------------------------------------------------------------------------------------------------
+# Direct gradients.  runner.FlatParams gives every trainable parameter a view of ONE flat gradient buffer
+# (``p._tag_grad_sink``).  While DIRECT_GRADS is on (StrongRunner.forward_backward, after its zero_grad) the autograd
+# nodes below write parameter gradients straight into those views and return None for them: no AccumulateGrad
+# ``grad += new`` kernels, and a node can announce "these gradients are final" (GRAD_READY) so that the data-parallel
+# all-reduce of a bucket starts while the rest of backward is still running (runner.GradBuckets).
+# ------------------------------------------------------------------------------------------------
+DIRECT_GRADS = False
+GRAD_READY = None        # callable(list of parameters) -> None: their gradient kernels are enqueued
+GRAD_FLUSH = None        # callable() -> None: a safe point to launch the all-reduce of every complete bucket
+
+
+def _sinks(params):
+    """Per input parameter: its flat-gradient view, or None (frozen parameter / direct gradients off)."""
+    if not DIRECT_GRADS:
+        return [None] * len(params)
+    return [getattr(t, "_tag_grad_sink", None) if (isinstance(t, torch.Tensor) and t.requires_grad) else None
+            for t in params]
+
+
+def _deliver(grads, sinks, i, val):
+    """Gradient ``val`` of input i: copied into its sink (the node then returns None) or returned to autograd."""
+    if sinks[i] is not None:
+        if val.data_ptr() != sinks[i].data_ptr():
+            sinks[i].copy_(val.view_as(sinks[i]))
+        grads[i] = None
+    else:
+        grads[i] = val
+
+
+def _ready(params):
+    if GRAD_READY is not None and params:
+        GRAD_READY([t for t in params if isinstance(t, torch.Tensor)])
+
+
+def _flush():
+    if GRAD_FLUSH is not None:
+        GRAD_FLUSH()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -185,10 +231,41 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     return y, part
 
 
-def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None):
+#: BatchNorm-backward sums in the dgrad conv epilogue (tag_conv3x3_dgrad_bnsums) instead of a separate two-tensor pass
+FUSE_BN_BWD_SUMS = os.environ.get("TAG_FUSE_BN_BWD", "1") != "0"
+
+
+def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=None, db_out=None):
+    """The dgrad convolution da = conv(dy_in, wpack) followed by the backward of relu(bn(yref)):
+    returns (dy_ref, dgamma, dbeta) with dy_ref = dL/d yref (written in place over da).  Exact-fp32 halo-tile shapes
+    fold the per-channel sums into the conv epilogue; other shapes / arithmetics run the conv and tag_bnrelu_backward."""
+    B, H, W, Cin = dy_in.shape
+    C = yref.shape[3]
+    fused = (FUSE_BN_BWD_SUMS and wpack.dtype != torch.uint8 and st.train and W in (8, 16, 32, 64)
+             and query("tag_conv3x3_stats_rows", B, H, W, C) > 0)
+    if not fused:
+        da = conv3x3(dy_in, wpack, C)
+        return bnrelu_backward(yref, st, gamma, da, dg_out=dg_out, db_out=db_out)
+    P = query("tag_conv3x3_stats_rows", B, H, W, C)
+    da = _empty(B, H, W, C, like=dy_in)
+    part = _empty(P * 2 * C, like=dy_in)
+    with _timed(("conv3x3_halo_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+        call("tag_conv3x3_dgrad_bnsums", ptr(dy_in), ptr(wpack), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
+             ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C)
+    dg = dg_out if dg_out is not None else _empty(C, like=da)
+    db = db_out if db_out is not None else _empty(C, like=da)
+    ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), da)
+    call("tag_bn_grad_from_partials", ptr(part), P, C, ptr(dg), ptr(db), ptr(ws))
+    rows = B * H * W
+    call("tag_bnrelu_backward_apply", ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+         ptr(da), ptr(da), ptr(dg), ptr(db), rows, C, int(st.train))
+    return da, dg, db
+
+
+def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
-    dw = _empty(Cout, Cin, 3, 3, like=x)
+    dw = out if out is not None else _empty(Cout, Cin, 3, 3, like=x)
     if CONV_MATH in _X3_PRODUCTS and W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0:
         ws = _ws(query("tag_conv3x3_wgrad_x3_ws_bytes", B, H, W, Cin, Cout), x)
         with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
@@ -220,12 +297,12 @@ def conv3x3_c1_wgrad(x, dy, col_scale=None, col_shift=None):
     return dw
 
 
-def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None):
+def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None, out=None):
     """(dw, dx) of the Cin = 1 convolution; one fused pass over dy when the shape allows (W == 64, Cout == 64)."""
     B, H, W = x.shape
     Cout = dy.shape[3]
     if W == 64 and Cout == 64:
-        dw = _empty(Cout, 1, 3, 3, like=x)
+        dw = out if out is not None else _empty(Cout, 1, 3, 3, like=x)
         dx = _empty(B, H, W, like=x)
         ws = _ws(query("tag_conv3x3_c1_backward_ws_bytes", B, H, W, Cout), x)
         call("tag_conv3x3_c1_backward", ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(w), ptr(dw), ptr(dx), B, H,
@@ -249,30 +326,33 @@ def bnact_pool(y, st: Optional[BNStat], ph, pw, act=1, pool=0, drop_p=0.0, seed=
     return out
 
 
-def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0):
+def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None):
     B, H, W, C = y.shape
     dy = _empty(B, H, W, C, like=y)
-    dg, db = _empty(C, like=y), _empty(C, like=y)
+    dg = dg_out if dg_out is not None else _empty(C, like=y)
+    db = db_out if db_out is not None else _empty(C, like=y)
     ws = _ws(query("tag_bn_backward_ws_bytes", B * H * W, C), y)
     call("tag_bnrelu_pool_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, float(drop_p), seed, int(st.train), ptr(ws))
     return dy, dg, db
 
 
-def bnrelu_backward(y, st: BNStat, gamma, da, inplace=True):
+def bnrelu_backward(y, st: BNStat, gamma, da, inplace=True, dg_out=None, db_out=None):
     C = y.shape[-1]
     rows = y.numel() // C
     dy = da if inplace else torch.empty_like(da)
-    dg, db = _empty(C, like=y), _empty(C, like=y)
+    dg = dg_out if dg_out is not None else _empty(C, like=y)
+    db = db_out if db_out is not None else _empty(C, like=y)
     ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), y)
     call("tag_bnrelu_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(da), ptr(dy), ptr(dg), ptr(db), rows, C, int(st.train), ptr(ws))
     return dy, dg, db
 
 
-def bn_param_grad(x2d, dy2d, st: BNStat):
+def bn_param_grad(x2d, dy2d, st: BNStat, dg_out=None, db_out=None):
     rows, C = x2d.shape
-    dg, db = _empty(C, like=x2d), _empty(C, like=x2d)
+    dg = dg_out if dg_out is not None else _empty(C, like=x2d)
+    db = db_out if db_out is not None else _empty(C, like=x2d)
     ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), x2d)
     call("tag_bn_param_grad", ptr(x2d), ptr(dy2d), rows, C, ptr(st.mean), ptr(st.invstd), ptr(dg), ptr(db), ptr(ws))
     return dg, db
@@ -300,8 +380,8 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     return out
 
 
-def colsum(x, M, N, ld=None):
-    out = _empty(N, like=x)
+def colsum(x, M, N, ld=None, out=None):
+    out = out if out is not None else _empty(N, like=x)
     ws = _ws(query("tag_colsum_ws_bytes", M, N), x)
     call("tag_colsum", ptr(x), ld if ld is not None else N, M, N, ptr(out), ptr(ws))
     return out
@@ -340,6 +420,50 @@ def align_dot(audio, text, l2norm=False, scaled=False):
 # bidirectional GRU (row A4): input projection GEMM + persistent recurrence, and its backward
 # ------------------------------------------------------------------------------------------------
 
+#: persistent scratch of the GRU kernels per (device, B, T, H, pass): recurrent-weight transpose, exchange granules and a
+#: STICKY error word (last 256 bytes; zeroed once here, raised by a persistent kernel whose bounded spin ran out and never
+#: cleared by the library) -> check_async_errors()
+_gru_scratch = {}
+
+
+def _gru_ws(B, T, Hh, like, which):
+    key = (like.device.type, like.device.index, B, T, Hh, which)
+    ws = _gru_scratch.get(key)
+    if ws is None:
+        nbytes = query("tag_gru_ws_bytes", B, T, Hh)
+        ws = torch.zeros((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
+        ws._tag_err_index = (nbytes - 256) // 4          # int32 index of the sticky error word
+        _gru_scratch[key] = ws
+    return ws
+
+
+def check_async_errors():
+    """Host-side check of the sticky device error words (synchronises): raises RuntimeError when a persistent GRU kernel
+    timed out waiting for its neighbours (its outputs were poisoned with NaN and the Adam kernel skipped the step) or an
+    embedding lookup saw a token id outside the table.  Called by StrongRunner whenever it hands a loss VALUE to the host."""
+    for key, ws in _gru_scratch.items():
+        word = ws.view(torch.int32)[ws._tag_err_index: ws._tag_err_index + 1]
+        err = word.cpu()
+        if query("tag_gru_timed_out", err.data_ptr()):
+            word.zero_()
+            raise RuntimeError(f"persistent GRU kernel timed out waiting for a neighbouring workgroup (B,T,H,pass = {key[2:]}): "
+                               "its workgroups were not co-resident; outputs of that step are NaN and the optimiser skipped it")
+    for dev, flag in _embed_err.items():
+        if int(flag.cpu().item()) != 0:
+            flag.zero_()
+            raise IndexError("embedding lookup: token id out of range (nn.Embedding would raise; models/text_encoder.py:39)")
+
+
+_embed_err = {}
+
+
+def _embed_flag(like):
+    key = (like.device.type, like.device.index)
+    if key not in _embed_err:
+        _embed_err[key] = torch.zeros(1, device=like.device, dtype=torch.int32)
+    return _embed_err[key]
+
+
 def gru_bidir_forward(x2d, rnn, B, T, need_grad):
     """x2d (B*T, I); rnn = [w_ih, w_hh, b_ih, b_hh] x (forward, reverse).  Returns y (B,T,2H) and the saved state."""
     Hh = rnn[1].shape[1]
@@ -351,32 +475,34 @@ def gru_bidir_forward(x2d, rnn, B, T, need_grad):
     gi = gemm(x2d, w_ih, M, 6 * Hh, x2d.shape[1], transB=True, bias=b_ih)
     y = _empty(B, T, 2 * Hh, like=x2d)
     gates = _empty(B, T, 2, 4 * Hh, like=x2d) if need_grad else None
-    wsr = _ws(query("tag_gru_ws_bytes", B, T, Hh), x2d)
+    wsr = _gru_ws(B, T, Hh, x2d, "fwd")
     call("tag_gru_forward", ptr(gi), ptr(w_hh), ptr(b_hh), ptr(y), ptr(gates), ptr(wsr), B, T, Hh)
     return y, (dict(gates=gates, y=y, w_ih=w_ih, w_hh=w_hh, Hh=Hh) if need_grad else None)
 
 
-def gru_bidir_backward(dy, x2d, sv):
-    """Returns (dx2d, [8 parameter gradients in nn.GRU order])."""
+def gru_bidir_backward(dy, x2d, sv, outs=None):
+    """Returns (dx2d, [8 parameter gradients in nn.GRU order]).  outs: optional 8 destination tensors (flat-gradient
+    views); a gradient whose destination is given is written there directly."""
     Hh, y, gates = sv["Hh"], sv["y"], sv["gates"]
     B, T, _ = y.shape
     M = B * T
     dgi = _empty(B, T, 2, 3 * Hh, like=y)
     dgh = _empty(B, T, 2, 3 * Hh, like=y)
     hprev = _empty(B, T, 2, Hh, like=y)
-    scratch = _ws(query("tag_gru_ws_bytes", B, T, Hh), y)
+    scratch = _gru_ws(B, T, Hh, y, "bwd")
     call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
          ptr(scratch), B, T, Hh)
     I = x2d.shape[1]
-    dw_ih = gemm(dgi, x2d, 6 * Hh, I, M, transA=True, lda=6 * Hh)                  # (6H, I)
+    outs = outs if outs is not None else [None] * 8
+    g = [None] * 8
     db_ih = colsum(dgi, M, 6 * Hh)
     db_hh = colsum(dgh, M, 6 * Hh)
-    g = [None] * 8
     for d in range(2):
+        ai = dgi.view(M, 6 * Hh)[:, d * 3 * Hh:]
         a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
         hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
-        g[4 * d + 0] = dw_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
-        g[4 * d + 1] = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh)
+        g[4 * d + 0] = gemm(ai, x2d, 3 * Hh, I, M, transA=True, lda=6 * Hh, out=outs[4 * d + 0])
+        g[4 * d + 1] = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh, out=outs[4 * d + 1])
         g[4 * d + 2] = db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
         g[4 * d + 3] = db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
     dx = gemm(dgi, sv["w_ih"], M, I, 6 * Hh)
@@ -403,6 +529,12 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+def side_streams(device):
+    """Side streams this process has used on ``device`` (the gradient all-reduce must wait for their wgrad kernels)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    return [_side_streams[key]] if key in _side_streams else []
+
+
 class _SideWgrad:
     """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them."""
 
@@ -411,12 +543,12 @@ class _SideWgrad:
         self.main = torch.cuda.current_stream(device)
         self.side = _side_stream(device) if self.on else None
 
-    def wgrad(self, x, dy, prologue=0, scale=None, shift=None):
+    def wgrad(self, x, dy, prologue=0, scale=None, shift=None, out=None):
         if not self.on:
-            return conv3x3_wgrad(x, dy, prologue, scale, shift)
+            return conv3x3_wgrad(x, dy, prologue, scale, shift, out=out)
         self.side.wait_stream(self.main)                 # x, dy (and the BN constants) are ready
         with torch.cuda.stream(self.side):
-            dw = conv3x3_wgrad(x, dy, prologue, scale, shift)
+            dw = conv3x3_wgrad(x, dy, prologue, scale, shift, out=out)
         for t in (x, dy, scale, shift):
             if t is not None:
                 t.record_stream(self.side)               # the caching allocator must not recycle them early
@@ -480,7 +612,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         y, gsave = gru_bidir_forward(fc, rnn, Bx, Tp, need_grad)
         if need_grad:
             ctx.saved = dict(lm=lm, st0=st0, acts=acts, x_last=x, xm=xm, fc=fc, gsave=gsave, p=p, drop=drop,
-                             seeds=seeds)
+                             seeds=seeds, sinks=_sinks(params), params=params if DIRECT_GRADS else None)
         mod._last_dropout = dict(p=drop, seeds=seeds)
         return y
 
@@ -492,14 +624,22 @@ class Cnn8RnnFunction(torch.autograd.Function):
         drop, seeds = sv["drop"], sv["seeds"]
         dy = _chk(dy, "grad_output")
         grads: List[Optional[torch.Tensor]] = [None] * len(p)
+        sk, prm = sv["sinks"], sv["params"]
         fc = sv["fc"]
-        dfc, grads[28:36] = gru_bidir_backward(dy, fc, sv["gsave"])
+        dfc, ggru = gru_bidir_backward(dy, fc, sv["gsave"], outs=sk[28:36])
+        for k in range(8):
+            _deliver(grads, sk, 28 + k, ggru[k])
         M = fc.shape[0]
         dfc = relu_backward(fc, dfc)
         xm = sv["xm"]
         fc_w = p[26]
-        grads[26] = gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0])
-        grads[27] = colsum(dfc, M, fc_w.shape[0])
+        _deliver(grads, sk, 26, gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0], out=sk[26]))
+        _deliver(grads, sk, 27, colsum(dfc, M, fc_w.shape[0], out=sk[27]))
+        if prm is not None:
+            # the persistent GRU backward is enqueued: from here on a bucket's all-reduce may run beside the kernels of
+            # this stream (never beside the spinning GRU workgroups: the collective is ordered after them)
+            _ready(prm[26:36])
+            _flush()
         dxm = gemm(dfc, fc_w, M, fc_w.shape[1], fc_w.shape[0])
         x_last = sv["x_last"]
         Bx, Tp, Wp, C = x_last.shape
@@ -511,24 +651,33 @@ class Cnn8RnnFunction(torch.autograd.Function):
         for i in range(3, -1, -1):
             x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
             c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]
+            o = 2 + 6 * i
             ph, pw = CNN8_POOLS[i]
             C = y2.shape[3]
-            dy2, grads[2 + 6 * i + 4], grads[2 + 6 * i + 5] = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0],
-                                                                                   seeds[i])
+            dy2, dg2, db2 = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0], seeds[i], dg_out=sk[o + 4], db_out=sk[o + 5])
+            _deliver(grads, sk, o + 4, dg2)
+            _deliver(grads, sk, o + 5, db2)
             del dx
-            grads[2 + 6 * i + 3] = sw.wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift)
-            da1 = conv3x3(dy2, wd2, C)
+            _deliver(grads, sk, o + 3, sw.wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift, out=sk[o + 3]))
+            dy1, dg1, db1 = conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1, dg_out=sk[o + 1], db_out=sk[o + 2])
             del dy2
-            dy1, grads[2 + 6 * i + 1], grads[2 + 6 * i + 2] = bnrelu_backward(y1, s1, g1, da1)
+            _deliver(grads, sk, o + 1, dg1)
+            _deliver(grads, sk, o + 2, db1)
             if i > 0:
-                grads[2 + 6 * i] = sw.wgrad(x_in, dy1)
+                _deliver(grads, sk, o, sw.wgrad(x_in, dy1, out=sk[o]))
                 dx = conv3x3(dy1, wd1, x_in.shape[3])
             else:
-                grads[2], dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift)   # dbn0: (B,F,64) grad wrt bn0 output
+                dw0, dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift, out=sk[2])   # dbn0: (B,F,64) grad wrt bn0 output
+                _deliver(grads, sk, 2, dw0)
                 Bq, Fr, NM = lm.shape
-                grads[0], grads[1] = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0)
-            del dy1, da1
+                dg0, db0 = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0, dg_out=sk[0], db_out=sk[1])
+                _deliver(grads, sk, 0, dg0)
+                _deliver(grads, sk, 1, db0)
+            del dy1
             sv["acts"][i] = None
+            if prm is not None:
+                _ready(prm[o:o + 6] + ((prm[0], prm[1]) if i == 0 else ()))
+                _flush()
         sw.join()
         return (None, None, *grads)
 
@@ -608,7 +757,8 @@ class CrnnFunction(torch.autograd.Function):
         y, gsave = gru_bidir_forward(x2d, rnn, Bx, Tp, need_grad)
         if need_grad:
             ctx.saved = dict(lm=lm, cs=cs, ct=ct, st=st, y=[y0, y1, y2, y3, y4], pool=[p1, p2, p3], wd=[wd1, wd2, wd3, wd4],
-                             x2d=x2d, gsave=gsave, p=p, drop=drop, seed=seed)
+                             x2d=x2d, gsave=gsave, p=p, drop=drop, seed=seed, sinks=_sinks(params),
+                             params=params if DIRECT_GRADS else None)
         mod._last_dropout = dict(p=drop, seeds=[seed])
         return y
 
@@ -651,6 +801,11 @@ class CrnnFunction(torch.autograd.Function):
         st0c.mean, st0c.invstd = st[0].mean.expand(NM).contiguous(), st[0].invstd.expand(NM).contiguous()
         dgc, dbc = bn_param_grad(lm.view(B * Fr, NM), du0.view(B * Fr, NM), st0c)
         grads[0], grads[1] = dgc.sum().view(1), dbc.sum().view(1)                   # 64 columns share one channel
+        sk = sv["sinks"]
+        for k in range(len(grads)):
+            if grads[k] is not None:
+                _deliver(grads, sk, k, grads[k])
+        _ready(sv["params"])
         return (None, None, *grads)
 
 
@@ -671,6 +826,8 @@ class LinearFunction(torch.autograd.Function):
         ctx.save_for_backward(x2, w_)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
+        ctx.sinks = _sinks([x, w, b])
+        ctx.params = [w, b] if DIRECT_GRADS else None
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -680,9 +837,13 @@ class LinearFunction(torch.autograd.Function):
         N = w.shape[0]
         dy2 = _chk(dy, "grad").view(M, N)
         dx = gemm(dy2, w, M, K, N).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = gemm(dy2, x2, N, K, M, transA=True, lda=N)
-        db = colsum(dy2, M, N) if ctx.has_bias else None
-        return dx, dw, db
+        sk = ctx.sinks
+        g = [dx, None, None]
+        _deliver(g, sk, 1, gemm(dy2, x2, N, K, M, transA=True, lda=N, out=sk[1]))
+        if ctx.has_bias:
+            _deliver(g, sk, 2, colsum(dy2, M, N, out=sk[2]))
+        _ready(ctx.params)
+        return tuple(g)
 
 
 class EmbedMeanFunction(torch.autograd.Function):
@@ -696,9 +857,12 @@ class EmbedMeanFunction(torch.autograd.Function):
         V, D = tab.shape
         seq = _empty(B, D, like=tab)
         tok = _empty(B, L, D, like=tab) if want_tokens else None
+        call("tag_embed_check_ids", ptr(text), B * L, V, ptr(_embed_flag(tab)))     # nn.Embedding raises; see check_async_errors
         call("tag_embed_mean_forward", ptr(text), ptr(text_len), ptr(tab), ptr(tok), ptr(seq), B, L, D, V)
         ctx.save_for_backward(text, text_len)
         ctx.shape = (B, L, D, V)
+        ctx.sink = _sinks([table])[0]
+        ctx.table = table if ctx.sink is not None else None
         ctx.set_materialize_grads(False)
         return seq, tok
 
@@ -706,11 +870,17 @@ class EmbedMeanFunction(torch.autograd.Function):
     def backward(ctx, dseq, dtok):
         text, text_len = ctx.saved_tensors
         B, L, D, V = ctx.shape
-        dtab = torch.zeros(V, D, device=text.device, dtype=F32)
+        # direct gradients: scatter straight into the (zeroed) flat-gradient rows of the table; otherwise a dense zeroed
+        # (V,D) gradient for autograd.  Deterministic either way (fixed-order per-row sums, no atomics).
+        direct = ctx.sink is not None
+        dtab = ctx.sink if direct else torch.zeros(V, D, device=text.device, dtype=F32)
         if dseq is not None:
             call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
         if dtok is not None:
             call("tag_embed_tokens_backward", ptr(_chk(dtok, "grad")), ptr(text), ptr(dtab), B, L, D, V)
+        if direct:
+            _ready([ctx.table])
+            return None, None, None, None
         return dtab, None, None, None
 
 
@@ -826,6 +996,8 @@ class CrossEncoderFunction(torch.autograd.Function):
         B, T, D = a.shape
         L, Dk = t.shape[1], t.shape[2]
         Da = w_h.shape[0]
+        ctx.sinks = _sinks([w_h, b_h, v, w_u, b_u, w_s, b_s])
+        ctx.params = [w_h, b_h, v, w_u, b_u, w_s, b_s] if DIRECT_GRADS else None
         w_h, b_h, v, w_u, b_u, w_s, b_s = (_chk(x.detach(), "parameter") for x in (w_h, b_h, v, w_u, b_u, w_s, b_s))
         if w_h.shape[1] != D + Dk or w_u.shape != (D, D) or w_s.shape != (Dk, Dk) or D != Dk:
             raise RuntimeError("CrossAttentionGating: inconsistent dimensions")
@@ -874,7 +1046,11 @@ class CrossEncoderFunction(torch.autograd.Function):
         db_h = colsum(dak, B * L, Da)
         gemm(daq, w_h, M, D, Da, ldb=D + Dk, out=da, accumulate=True)
         gemm(dak, w_h[:, D:], B * L, Dk, Da, ldb=D + Dk, out=dkv, accumulate=True)
-        return da, dkv, None, None, dw_h, db_h, dv, dw_u, db_u, dw_s, db_s
+        g = [dw_h, db_h, dv, dw_u, db_u, dw_s, db_s]
+        for k in range(7):
+            _deliver(g, ctx.sinks, k, g[k])
+        _ready(ctx.params)
+        return (da, dkv, None, None, *g)
 
 
 class RowDotFunction(torch.autograd.Function):

@@ -1,14 +1,15 @@
 """Training-step driver for the strongly-supervised path -- the counterpart of
 Runner.forward / Runner.train_epoch in python_scripts/training/run_strong.py:92-152.
 
-One process per GPU.  Parameters live in ONE flat fp32 buffer (and gradients in another) so that
-the data-parallel exchange is a single RCCL all-reduce over xGMI and clip_grad_norm_ + Adam are two
-kernels over the flat buffers (tag_sumsq, tag_adam_step) instead of ~40 small launches each.
+One process per GPU.  Parameters live in ONE flat fp32 buffer (and gradients in another) so that clip_grad_norm_ +
+Adam are two kernels over the flat buffers (tag_sumsq, tag_adam_step) instead of ~40 small launches each, and the
+data-parallel exchange is a handful of large all-reduces over contiguous slices of the flat gradient (RCCL over xGMI),
+launched from inside backward as soon as a slice is final so that they overlap the remaining dgrad / wgrad kernels.
 """
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -28,7 +29,12 @@ def build_model(model_cfg: Dict):
 
 
 class FlatParams:
-    """Re-homes every trainable parameter (and its .grad) into one contiguous buffer each."""
+    """Re-homes every trainable parameter (and its .grad) into one contiguous buffer each.
+
+    ``p._tag_grad_sink`` is the parameter's view of the flat gradient: inside ``direct_grads()`` the HIP autograd nodes
+    write gradients there themselves (no ``grad += new`` kernels).  Only ``FlatParams.zero_grad`` may clear gradients:
+    ``model.zero_grad()`` / ``optimizer.zero_grad()`` (set_to_none) detach ``p.grad`` from the flat buffer -- ``check()``
+    (called by StrongRunner.optimizer_step) raises if that happened instead of silently stepping on zeros."""
 
     def __init__(self, model: torch.nn.Module):
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -36,21 +42,113 @@ class FlatParams:
         dev = self.params[0].device
         self.flat = torch.empty(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offsets: List[int] = []
         off = 0
         for p in self.params:
             k = p.numel()
+            self.offsets.append(off)
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
+            p._tag_grad_sink = p.grad
             off += k
         self.numel = n
 
     def zero_grad(self):
         self.grad.zero_()
 
+    def check(self):
+        base, esz = self.grad.data_ptr(), self.grad.element_size()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != base + off * esz or p.data.data_ptr() != self.flat.data_ptr() + off * esz:
+                raise RuntimeError("a parameter or its .grad no longer aliases the flat buffers (model.zero_grad() / "
+                                   "optimizer.zero_grad(set_to_none=True) / p.grad = None / .to() after FlatParams was built); "
+                                   "use FlatParams.zero_grad() only")
+
+
+class GradBuckets:
+    """Bucketed data-parallel gradient exchange over the flat gradient buffer.
+
+    Buckets are contiguous slices of ``flat.grad`` holding whole parameters, in parameter order, cut whenever a slice
+    reaches ``bucket_bytes``.  The autograd nodes call ``ready(params)`` when the kernels producing those gradients are
+    enqueued and ``flush()`` at points where a collective may start; ``flush`` launches ONE asynchronous all-reduce(sum)
+    per complete bucket on a communication stream that waits for the compute stream (and the wgrad side stream) as of
+    that moment, so the exchange of conv_block4 runs beside the backward of conv_block3...1.  ``finish()`` (after
+    loss.backward()) launches whatever is left and makes the compute stream wait for all of them.  The mean (1/world) is
+    folded into the Adam kernel; with equal per-rank batch sizes the result is the gradient of the mean over ranks of
+    the per-replica mean losses (= the reference's single-device loss on the concatenated batch when all clips have the
+    same number of valid frames; otherwise each replica's frames are weighted by its own mask count -- DESIGN.md section 5).
+    Device-agnostic: on CPU tensors (gloo, tests/test_dp_gloo.py) the same code runs without streams."""
+
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 8 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.cuda = flat.grad.is_cuda
+        self.bounds: List[tuple] = []          # (start element, end element, first param index, last param index + 1)
+        start, first, acc = 0, 0, 0
+        for i, p in enumerate(flat.params):
+            acc += p.numel() * 4
+            last = i == len(flat.params) - 1
+            if acc >= bucket_bytes or last:
+                end = flat.offsets[i] + p.numel()
+                self.bounds.append((start, end, first, i + 1))
+                start, first, acc = end, i + 1, 0
+        self.bucket_of = {}
+        for b, (_, _, i0, i1) in enumerate(self.bounds):
+            for i in range(i0, i1):
+                self.bucket_of[id(flat.params[i])] = b
+        self.comm_stream = torch.cuda.Stream(device=flat.grad.device) if self.cuda else None
+        self.reset()
+
+    def reset(self):
+        self.missing = [i1 - i0 for (_, _, i0, i1) in self.bounds]
+        self.seen = set()
+        self.launched = [False] * len(self.bounds)
+        self.works = []
+
+    def ready(self, params):
+        for p in params:
+            b = self.bucket_of.get(id(p))
+            if b is None or id(p) in self.seen:
+                continue
+            self.seen.add(id(p))
+            self.missing[b] -= 1
+
+    def _launch(self, b):
+        s, e, _, _ = self.bounds[b]
+        buf = self.flat.grad[s:e]
+        if self.cuda:
+            main = torch.cuda.current_stream(buf.device)
+            self.comm_stream.wait_stream(main)
+            for side in ops.side_streams(buf.device):
+                self.comm_stream.wait_stream(side)
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(buf, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(buf, group=self.group, async_op=True)
+        self.works.append(w)
+        self.launched[b] = True
+
+    def flush(self):
+        for b in range(len(self.bounds)):
+            if not self.launched[b] and self.missing[b] <= 0:
+                self._launch(b)
+
+    def finish(self):
+        """Everything not yet exchanged goes now (parameters no node announced, e.g. unused ones whose gradient is the
+        zero fill); then the compute stream waits for every collective."""
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        if self.cuda:
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.comm_stream)
+        self.works = []
+
 
 class StrongRunner:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, device="cuda"):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, device="cuda",
+                 bucket_bytes: int = 8 << 20, overlap_comm: bool = True):
         self.device = torch.device(device)
         self.model = model.to(self.device)
         self.loss_fn = FrameBceLoss()
@@ -59,7 +157,20 @@ class StrongRunner:
         self.v = torch.zeros_like(self.flat.flat)
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         self.step_count = 0
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+        self.overlap_comm = overlap_comm
+        self.buckets: Optional[GradBuckets] = None
+        if self.world > 1:
+            # replicas must START identical whatever each rank's seed / checkpoint was: parameters and every buffer
+            # (BatchNorm running statistics, num_batches_tracked) come from rank 0; Adam moments start at zero everywhere
+            dist.broadcast(self.flat.flat, 0)
+            for b in self.model.buffers():
+                dist.broadcast(b, 0)
+            self.buckets = GradBuckets(self.flat, bucket_bytes)
+        # ranks seeded alike still need different dropout masks for their different clips
+        ops.SEED_RANK = self.rank
 
     # Runner.forward (run_strong.py:92-120)
     def forward(self, batch: Dict, training: bool = True):
@@ -86,17 +197,27 @@ class StrongRunner:
         return output
 
     def forward_backward(self, batch: Dict):
-        """zero_grad -> forward -> FrameBceLoss -> backward [-> gradient all-reduce]."""
+        """zero_grad -> forward -> FrameBceLoss -> backward [with the bucketed gradient all-reduce inside it]."""
         self.flat.zero_grad()
-        output = self.forward(batch, training=True)
-        loss = self.loss_fn(output)
-        loss.backward()
-        if self.world > 1:
-            dist.all_reduce(self.flat.grad)          # RCCL sum; the mean is folded into the Adam kernel
+        prev = (ops.DIRECT_GRADS, ops.GRAD_READY, ops.GRAD_FLUSH)
+        ops.DIRECT_GRADS = True
+        if self.buckets is not None:
+            self.buckets.reset()
+            ops.GRAD_READY = self.buckets.ready
+            ops.GRAD_FLUSH = self.buckets.flush if self.overlap_comm else None
+        try:
+            output = self.forward(batch, training=True)
+            loss = self.loss_fn(output)
+            loss.backward()
+        finally:
+            ops.DIRECT_GRADS, ops.GRAD_READY, ops.GRAD_FLUSH = prev
+        if self.buckets is not None:
+            self.buckets.finish()                # RCCL sums; the mean is folded into the Adam kernel
         return loss
 
     def optimizer_step(self):
         """clip_grad_norm_(max_grad_norm) + Adam (run_strong.py:143-145) on the flat buffers."""
+        self.flat.check()
         self.step_count += 1
         gsq = ops.grad_sumsq(self.flat.grad)
         ops.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
@@ -108,16 +229,27 @@ class StrongRunner:
         self.optimizer_step()
         return loss
 
+    def loss_value(self, loss) -> float:
+        """loss.item() + the deferred device-side error checks (GRU exchange timeout, embedding ids out of range)."""
+        v = float(loss.item())
+        ops.check_async_errors()
+        return v
 
-def init_distributed():
-    """One process per GPU, torch.distributed over RCCL (backend 'nccl' on ROCm)."""
+
+def init_distributed(backend: Optional[str] = None):
+    """One process per GPU, torch.distributed over RCCL (backend 'nccl' on ROCm).  TAG_DIST_BACKEND=gloo and
+    TAG_SHARE_GPU=1 are test hooks: N ranks on ONE GPU exchanging through gloo (how the N > 1 path is exercised on a
+    1-GPU box; RCCL refuses two ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend or os.environ.get("TAG_DIST_BACKEND", "nccl")
+    if os.environ.get("TAG_SHARE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local

@@ -145,6 +145,11 @@ int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_scale, const
  * (bn0 folded: the BatchNorm2d(64) over the mel axis), w (Cout,1,3,3) */
 int tag_conv3x3_c1_forward(const float* x, const float* col_scale, const float* col_shift,
                            const float* w, float* y, int B, int H, int W, int Cout, void* stream);
+/* the same with the BatchNorm partial statistics of y written by the kernel (W == 64, Cout == 64: rows > 0):
+ * stats = [P][3][Cout] rows (pivot, sum(y - pivot), sum((y - pivot)^2)) + [P] pixel counts -> tag_bn_stats_from_partials */
+int tag_conv3x3_c1_stats_rows(int B, int H, int W, int Cout);
+int tag_conv3x3_c1_forward_stats(const float* x, const float* col_scale, const float* col_shift, const float* w,
+                                 float* y, float* stats, int B, int H, int W, int Cout, void* stream);
 size_t tag_conv3x3_c1_wgrad_ws_bytes(int B, int H, int W, int Cout);
 int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, const float* col_shift,
                          const float* dy, float* dw, int B, int H, int W, int Cout, void* ws,

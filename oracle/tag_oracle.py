@@ -225,6 +225,38 @@ def _dropout(x, p, training, masks, name):
     return F.dropout(x, p=p, training=True)
 
 
+def dropout_keep_mask(seed: int, n: int, p: float) -> np.ndarray:
+    """The HIP path's counter-based keep mask restated on the CPU (texttoaudiogrounding_amd/csrc/tag_common.h:
+    tag_mix64 / tag_keep): element i is kept iff u >= p with u = (splitmix64(seed * 0xD1342543DE82EF95 + i) >> 40) / 2^24,
+    compared in fp32.  Not torch's Philox stream (the reference's F.dropout draws from that, models/audio_encoder.py:203-215);
+    the oracle replays THESE masks so that a dropout-on step can be compared element by element."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + np.arange(n, dtype=np.uint64)) & M
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return u >= np.float32(p)
+
+
+def cnn8rnn_dropout_masks(seeds, B: int, n_frames: int, p_drop=(0.2, 0.5), dtype=torch.float32):
+    """The five keep masks of one Cnn8Rnn training step for the HIP path's seeds, in the oracle's NCHW layout
+    (the HIP kernels index the channels-last pooled outputs (B,H,W,C) and the (B*T',512) mean-pooled rows flat)."""
+    shapes, H, W = [], n_frames, 64
+    for i, (ph, pw) in enumerate([(2, 2), (2, 2), (1, 2), (1, 2)]):
+        H, W = H // ph, W // pw
+        shapes.append((B, H, W, 64 << i))
+    masks = {}
+    for i, shp in enumerate(shapes):
+        m = dropout_keep_mask(seeds[i], int(np.prod(shp)), p_drop[0]).reshape(shp)
+        masks[f"drop{i + 1}"] = torch.from_numpy(m).permute(0, 3, 1, 2).to(dtype)
+    m = dropout_keep_mask(seeds[4], B * shapes[3][1] * 512, p_drop[1]).reshape(B, shapes[3][1], 512)
+    masks["drop5"] = torch.from_numpy(m).to(dtype)
+    return masks
+
+
 def conv_block(x, st, prefix, pool_size, training, taps=None):
     """ConvBlock.forward with pool_type='avg+max' (models/panns.py:46-62)."""
     y1 = F.conv2d(x, st[prefix + "conv1.weight"], None, 1, 1)

@@ -354,6 +354,35 @@ def case_frontend():
         assert d < 1e-5
     np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
     print("  wrote frontend.npz")
+    case_frontend_witness(noise)
+
+
+def case_frontend_witness(noise):
+    """INDEPENDENT witness for rows F1/F2: the same two seeded noise clips through
+    transformers.audio_utils (window_function -> spectrogram(center, reflect, power 2, onesided) -> mel_filter_bank), in
+    fp64, with ITS OWN window and filterbank.  Nothing of the oracle is used to produce these arrays; the oracle (and,
+    on the GPU, logmel.hip) must agree with them in the power domain.  torchaudio itself stays absent: this pins the
+    oracle's reading of torch.stft / MelScale / AmplitudeToDB against a second implementation of the published algorithm
+    for both parameter sets (Cnn8Rnn n_fft = win = 1024; CrnnEncoder win 1280 zero-padded centred to n_fft 2048)."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    out = {}
+    for kind in ("cnn8rnn", "crnn"):
+        p = O.FRONTEND[kind]
+        fb = mel_filter_bank(p["n_fft"] // 2 + 1, p["n_mels"], p["f_min"], p["f_max"], p["sample_rate"], p["norm"],
+                             p["mel_scale"])
+        win = window_function(p["win_length"], "hann", periodic=True, frame_length=p["n_fft"], center=True)
+        P = np.stack([spectrogram(noise[b].double().numpy(), win, frame_length=p["n_fft"], hop_length=p["hop_length"],
+                                  fft_length=p["n_fft"], power=2.0, center=True, pad_mode="reflect", onesided=True,
+                                  mel_filters=fb, mel_floor=0.0, dtype=np.float64) for b in range(noise.shape[0])])
+        out[f"power_{kind}"] = P
+        out[f"db_{kind}"] = 10.0 * np.log10(np.maximum(P, 1e-10))
+        mine = O.mel_spectrogram(noise.double(), kind).numpy()
+        d = np.abs(P - mine).max() / np.abs(P).max()
+        ddb = np.abs(out[f"db_{kind}"] - O.logmel(noise.double(), kind).numpy()).max()
+        print(f"  witness[{kind}] vs oracle(fp64): power rel {d:.2e}, dB {ddb:.2e}")
+        assert d < 1e-5 and ddb < 2e-4
+    np.savez_compressed(os.path.join(HERE, "frontend_witness.npz"), **out)
+    print("  wrote frontend_witness.npz")
 
 
 if __name__ == "__main__":

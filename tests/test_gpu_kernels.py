@@ -56,6 +56,25 @@ def test_logmel_vs_oracle(ops, dev, kind):
     assert torch.all(db[1, -5:].cpu() == -100.0)            # silent frames hit the clamp exactly
 
 
+@pytest.mark.parametrize("kind", ["cnn8rnn", "crnn"])
+def test_logmel_vs_independent_witness(ops, dev, golden_dir, kind):
+    """logmel.hip against the fixture a SECOND implementation produced (transformers.audio_utils, fp64, its own window
+    and filterbank; tests/golden/make_golden.py:case_frontend_witness) -- not against the oracle."""
+    gold = np.load(f"{golden_dir}/frontend_witness.npz")
+    g = torch.Generator().manual_seed(11)
+    noise = 0.1 * torch.randn(2, 32000, generator=g)
+    p = O.FRONTEND[kind]
+    window, fb = O.frontend_tables(kind)          # the buffers the mirror modules hold (torchaudio's fp32 tables)
+    db, power = ops.logmel(noise.to(dev), p["n_fft"], p["win_length"], p["hop_length"], window.to(dev), fb.to(dev),
+                           want_power=True)
+    P = torch.from_numpy(gold[f"power_{kind}"]).transpose(1, 2)               # (B,F,mel) fp64
+    scale = P.abs().amax(dim=(1, 2), keepdim=True)
+    err = ((power.cpu().double() - P).abs() / scale).max().item()
+    ddb = (db.cpu().double() - torch.from_numpy(gold[f"db_{kind}"]).transpose(1, 2)).abs().max().item()
+    print(f"logmel[{kind}] vs independent witness: power {err:.2e} of clip max, dB {ddb:.2e}")
+    assert err < 1e-5 and ddb < 1e-3
+
+
 def test_logmel_known_answers(ops, dev, golden_dir):
     gold = np.load(f"{golden_dir}/frontend.npz")
     n = torch.arange(32000, dtype=torch.float32)
@@ -292,6 +311,30 @@ def test_conv3x3_c1(ops, dev, B, H):
     assert relerr(dx, xin.grad[:, 0]) < 2e-6
     dw2, dx2 = ops.conv3x3_c1_backward(x.to(dev), nhwc(dy).to(dev), w.to(dev), cs.to(dev), ct.to(dev))   # fused pass
     assert relerr(dw2, wd.grad) < 2e-6 and relerr(dx2, xin.grad[:, 0]) < 2e-6
+
+
+@pytest.mark.parametrize("B,H", [(2, 21), (3, 1001), (64, 37)])
+def test_conv3x3_c1_fused_bn_stats(ops, dev, B, H):
+    """The Cin = 1 forward kernel writes the BatchNorm partial statistics of its own output (no second pass over the
+    1 GB tensor); channels whose |mean| >> std keep their variance (pivoted sums)."""
+    g = torch.Generator().manual_seed(B * H)
+    W, Cout = 64, 64
+    x = torch.randn(B, H, W, generator=g) * 10 - 30
+    cs, ct = torch.rand(W, generator=g) * 0.1 + 0.05, torch.randn(W, generator=g) + 40.0     # strongly offset input
+    w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, 0.2 * torch.randn(Cout, generator=g)
+    y, part = ops.conv3x3_c1_stats(x.to(dev), w.to(dev), cs.to(dev), ct.to(dev), want_stats=True)
+    assert part is not None and part[0] == ops.query("tag_conv3x3_c1_stats_rows", B, H, W, Cout)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    st = ops.bn_stats(y.view(-1, Cout), gamma.to(dev), beta.to(dev), rm.clone().to(dev), rv.clone().to(dev), True,
+                      partials=part)
+    st2 = ops.bn_stats(y.view(-1, Cout), gamma.to(dev), beta.to(dev), rm.clone().to(dev), rv.clone().to(dev), True)
+    yd = y.cpu().double().view(-1, Cout)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    assert relerr(st.mean, mean) < 1e-6 and relerr(st2.mean, mean) < 1e-6
+    e = ((st.invstd.cpu().double() - 1.0 / torch.sqrt(var + 1e-5)).abs() * torch.sqrt(var + 1e-5)).max().item()
+    print(f"c1 fused stats: invstd rel err {e:.2e}; |mean|/std up to {(mean.abs() / var.sqrt()).max().item():.1f}")
+    assert e < 5e-6
 
 
 # ------------------------------------------------------------------------------------------- bn+relu+pool

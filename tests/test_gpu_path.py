@@ -54,6 +54,24 @@ def sample_grad(g):
     return np.concatenate([[g.norm().item(), g.abs().max().item()], g[idx].numpy()])
 
 
+def assert_grad_close(name, err, floor):
+    """Per-tensor gradient rule (errors are max-normalised distances from the fp64 twin; ``floor`` = the fp32 CPU
+    reference's / oracle's own distance on the same tensor):
+
+    * tensors ABOVE the last ReLU / max-pool of the encoder (fc1, GRU, embedding, projections): pure round-off ->
+      err <= 4 x max(floor, 1e-6);
+    * conv-block / bn0 tensors: a ReLU or max-pool decision whose operands differ by less than fp32 rounding can flip in
+      ANY fp32 implementation, and one flip moves O(1e-3) of such a tensor's gradient at these 2-clip sizes.  With 0 or 1
+      flips per tensor the floor of ONE other fp32 run is not a statistic (it is 1e-6 when that run happened not to
+      flip), so here the rule is err <= max(4 x floor, 1e-2); the strict 4 x floor rule for EVERY tensor is asserted
+      where flips are counted in thousands: test_full_length_train_step_vs_oracle (B = 6, 10 s) and
+      test_benched_size_train_step_vs_fixture (B = 64, 10 s)."""
+    if "conv_block" in name or "bn0" in name or ".cnn." in name:
+        assert err <= max(4.0 * floor, 1e-2), (name, err, floor)
+    else:
+        assert err <= 4.0 * max(floor, 1e-6), (name, err, floor)
+
+
 @pytest.fixture(params=["fp32", "x3"])
 def conv_math(request):
     """Both arithmetics of the 3x3 convolutions: exact fp32 MFMA (default) and the opt-in 3 x bf16 split (conv_x3.hip);
@@ -133,7 +151,8 @@ def test_golden_train_step_grads(dev, golden_dir, conv_math):
         e32 = np.abs(ref32[2:] - want[2:]).max() / scale
         worst32 = max(worst32, e32)
         print(f"  {name:55s} hip {err:.2e} (norm {nerr:.2e})  reference-f32 {e32:.2e}")
-        assert err < 1e-2 and nerr < 1e-2, (name, err, nerr)
+        assert_grad_close(name, err, e32)
+        assert nerr < 1e-2, (name, nerr)
     print(f"train: loss {loss.item():.7f} (ref f64 {float(gold['loss_f64']):.7f}); worst grad err vs f64 "
           f"{worst:.2e} (reference's own f32 {worst32:.2e})")
     sd = model.state_dict()
@@ -182,13 +201,8 @@ def test_proj_expnegl2_dropout_replay_vs_oracle(dev):
         e32 = (g32 - g64).abs().max().item() / scale
         print(f"  {name:55s} hip-vs-f64 {err:.2e}   cpu-f32-oracle-vs-f64 {e32:.2e}")
         errs[name] = (err, e32)
-    # ReLU / max-pool decisions that flip under fp32 rounding move O(1e-3..1e-2) of a tensor's gradient in ANY fp32
-    # implementation (the CPU fp32 oracle shows the same on the layers below a flip); bound = 5e-2 absolute and
-    # the loss / forward agreement above.
     for name, (err, e32) in errs.items():
-        assert err < 5e-2, (name, err, e32)
-        if "conv_block" not in name and "bn0" not in name:          # above the last ReLU/max-pool: round-off only
-            assert err < 2e-5, (name, err, e32)
+        assert_grad_close(name, err, e32)
 
 
 def test_full_length_frame_sim_and_segments(dev, conv_math):
@@ -338,8 +352,10 @@ def test_full_length_train_step_vs_oracle(dev):
     print(f"full-length train step: loss {loss.item():.7f} vs {oloss.item():.7f}; grad err median {np.median(errs):.2e} "
           f"max {max(errs):.2e}; cpu-fp32-oracle floor median {np.median(floor):.2e} max {max(floor):.2e}")
     assert float(np.median(errs)) < max(2e-5, 4 * float(np.median(floor)))
-    for name, e in zip([n for n, _ in model.named_parameters()], errs):
-        assert e < 5e-2, (name, e)
+    # every tensor within 4 x the fp32 CPU oracle's own distance from fp64 (clamped below at 2e-6: pure round-off
+    # tensors); at this size every conv-block tensor sees hundreds of flipped decisions, so the floor is a statistic
+    for name, e, f in zip([n for n, _ in model.named_parameters()], errs, floor):
+        assert e <= 4.0 * max(f, 2e-6), (name, e, f)
     # optimiser at full parameter size: clip_grad_norm_(1.0) + Adam in fp64 on the SAME (HIP) gradients
     # (the first Adam step is lr * g/|g|, so it must be fed identical gradients to be comparable)
     params = [before[k].double().requires_grad_(True) for k, _ in model.named_parameters()]
@@ -351,6 +367,60 @@ def test_full_length_train_step_vs_oracle(dev):
     runner.optimizer_step()
     for (name, p), q in zip(model.named_parameters(), params):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name
+
+
+def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch):
+    """Parity AT THE BENCHED SIZE (BASELINE configs[1]: B = 64, 10 s clips, train-mode BatchNorm, dropout ON) -- the grids
+    where the XCD remap, 3-workgroup/CU residency, split-K counts and the 128-workgroup persistent GRU actually live.
+    tests/golden/b64_train_step.npz holds the CPU oracle's fp64 step (truth) and its own fp32 step (the noise floor of
+    any fp32 implementation) with THESE dropout masks (make_golden_b64.py; the oracle replays the HIP generator from the
+    same seeds).  loss <= 2e-5, frame_sim <= 1e-4, every gradient tensor within 4 x the fp32 oracle's own distance from
+    fp64 (floor clamped below by 2e-5 of the tensor's max: above the last ReLU the floor is pure round-off)."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    gold = np.load(f"{golden_dir}/b64_train_step.npz")
+    st = O.init_state(seed=5, logit_gain=120.0)
+    batch = O.synthetic_batch(64, 320000, seed=99, ragged=True)
+    chk = checksum(batch["waveform"]) + checksum(batch["text"].float()) + checksum(st["audio_encoder.fc1.weight"])
+    assert np.allclose(chk, gold["input_checksum"], rtol=1e-9), "seeded inputs drifted from the fixture"
+    seeds = iter(int(v) for v in gold["dropout_seeds"])
+    monkeypatch.setattr(ops, "new_seed", lambda: next(seeds))
+    model = build_hip_model(st, "dot", dev).train()
+    runner = StrongRunner(model, device=str(dev))
+    loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    lv = runner.loss_value(loss)                       # also raises if the GRU exchange timed out at this grid
+    info = model.audio_encoder._last_dropout
+    assert info["seeds"] == [int(v) for v in gold["dropout_seeds"]]
+    # the masks the kernels drew are the masks the oracle replayed (CPU restatement of the generator, checked by count)
+    shapes = [(64, 500, 32, 64), (64, 250, 16, 128), (64, 250, 8, 256), (64, 250, 4, 512), (64, 250, 512)]
+    for i, shp in enumerate(shapes):
+        kept = int(ops.dropout_mask(info["seeds"][i], shp, 0.2 if i < 4 else 0.5, dev).sum().item())
+        assert kept == int(gold["mask_keep_counts"][i]), (i, kept)
+    assert abs(lv - float(gold["loss_f64"])) < 2e-5, (lv, float(gold["loss_f64"]))
+    # frame_sim of the training forward: re-run the forward with the same seeds (BatchNorm batch statistics, same masks)
+    seeds2 = iter(int(v) for v in gold["dropout_seeds"])
+    monkeypatch.setattr(ops, "new_seed", lambda: next(seeds2))
+    with torch.no_grad():
+        out = runner.forward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, training=True)
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    print(f"B=64: loss {lv:.7f} vs {float(gold['loss_f64']):.7f}; frame_sim err {fs_err:.2e} "
+          f"(fp32 oracle itself {float(gold['frame_sim_floor']):.2e})")
+    assert fs_err < 1e-4
+    worst = 0.0
+    for name, p in model.named_parameters():
+        want, floor = gold[f"grad/{name}"], gold[f"floor/{name}"]
+        g = p.grad.detach().double().flatten().cpu()
+        gi = torch.Generator().manual_seed(sum(map(ord, name)))
+        idx = torch.randint(0, g.numel(), (min(1024, g.numel()),), generator=gi)
+        scale = want[1] + 1e-300
+        err = np.abs(g[idx].numpy() - want[2:]).max() / scale
+        nerr = abs(g.norm().item() - want[0]) / (want[0] + 1e-300)
+        bound = 4.0 * max(float(floor[0]), 2e-5)
+        worst = max(worst, err / bound)
+        print(f"  {name:55s} hip {err:.2e} (norm {nerr:.2e})  fp32-oracle floor {floor[0]:.2e}  -> {err / bound:.2f} of the bound")
+        assert err <= bound, (name, err, float(floor[0]))
+        assert nerr <= 4.0 * max(float(floor[2]), 2e-5), (name, nerr, float(floor[2]))
+    print(f"B=64 gradients: worst tensor at {worst:.2f} of its 4 x floor bound")
 
 
 @pytest.mark.parametrize("B,S", [(1, 4000), (3, 9999), (2, 32000)])

@@ -1158,8 +1158,8 @@ constexpr int C1B_GW = 66, C1B_GT = 10;        // LDS ring rows: 64 + 2 halo pix
 // pure 1 GB write stream.
 __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                                const float* __restrict__ ct, const float* __restrict__ wgt,
-                                                               float* __restrict__ y, int H, int strips,
-                                                               int rows_per_strip) {
+                                                               float* __restrict__ y, float* __restrict__ stats, int H,
+                                                               int strips, int rows_per_strip) {
     constexpr int W = 64, Cout = 64;
     __shared__ float Xs[4][C1B_GW];
     const int img = blockIdx.x / strips, strip = blockIdx.x % strips;
@@ -1184,6 +1184,12 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
             Xs[(row + 8) & 3][tid] = v;
         }
     };
+    // fused BatchNorm statistics (training): every thread keeps, for its 4 couts, a pivot K (its first output) and the
+    // shifted sums r = sum(y - K), q = sum((y - K)^2) over its 4 pixels x the rows of the strip; the 16 threads of a pixel
+    // group form one partial row [K | r | q] of 64 channels (same layout as the MFMA conv epilogues ->
+    // tag_bn_stats_from_partials), so the 1 GB output is never re-read for its statistics.
+    float sk[4] = {0, 0, 0, 0}, sr[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    bool have_pivot = false;
     stage_x(r0 - 1);
     stage_x(r0);
     stage_x(r0 + 1);
@@ -1204,8 +1210,24 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fmaf(xin[tap / 3][px + tap % 3], wr[j][tap], o[j]);
             *reinterpret_cast<float4*>(yrow + (size_t)px * Cout) = make_float4(o[0], o[1], o[2], o[3]);
+            if (stats) {
+                if (!have_pivot) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sk[j] = o[j];
+                    have_pivot = true;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = o[j] - sk[j]; sr[j] += d; sq[j] = fmaf(d, d, sq[j]); }
+            }
         }
         __syncthreads();
+    }
+    if (stats) {
+        const int P = gridDim.x * 16, prow = blockIdx.x * 16 + grp;
+        float* ps = stats + (size_t)prow * 3 * Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ps[c + j] = sk[j]; ps[Cout + c + j] = sr[j]; ps[2 * Cout + c + j] = sq[j]; }
+        if (c == 0) stats[(size_t)P * 3 * Cout + prow] = (float)((r1 - r0) * 4);
     }
 }
 
@@ -1647,7 +1669,7 @@ extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, co
         int strips, rows;
         c1_bwd_geom(B, H, &strips, &rows);
         hipLaunchKernelGGL(conv_c1_fwd_rows_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
-                           col_shift, w, y, H, strips, rows);
+                           col_shift, w, y, (float*)nullptr, H, strips, rows);
     } else if (W % 4 == 0 && 256 % (Cout / 4) == 0) {
         nb = ((M / 4) * (Cout / 4) + 255) / 256;
         if (nb > 8192) nb = 8192;
@@ -1657,6 +1679,26 @@ extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, co
         hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, col_scale,
                            col_shift, w, y, M, H, W, Cout);
     }
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Cin = 1 forward with the BatchNorm statistics of its output fused (W == 64, Cout == 64 only: tag_conv3x3_c1_stats_rows
+// > 0); stats = [P][3][Cout] partial rows + [P] counts -> tag_bn_stats_from_partials
+extern "C" int tag_conv3x3_c1_stats_rows(int B, int H, int W, int Cout) {
+    if (!(W == 64 && Cout == 64 && B > 0 && H > 0)) return 0;
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    return B * strips * 16;
+}
+extern "C" int tag_conv3x3_c1_forward_stats(const float* x, const float* col_scale, const float* col_shift, const float* w,
+                                            float* y, float* stats, int B, int H, int W, int Cout, void* stream) {
+    TAG_CHECK_ARG(x && w && y && stats && W == 64 && Cout == 64 && B > 0 && H > 0);
+    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    hipLaunchKernelGGL(conv_c1_fwd_rows_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, w,
+                       y, stats, H, strips, rows);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -45,6 +45,8 @@ _SIGS = {
     "tag_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "tag_conv3x3_wgrad": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_c1_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_c1_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_c1_forward_stats": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_c1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_c1_wgrad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_c1_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -281,11 +281,23 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
 
 
 def conv3x3_c1(x, w, col_scale=None, col_shift=None):
+    return conv3x3_c1_stats(x, w, col_scale, col_shift, want_stats=False)[0]
+
+
+def conv3x3_c1_stats(x, w, col_scale=None, col_shift=None, want_stats=True):
+    """(y, partials) of the Cin = 1 convolution; partials = (P, buffer) when the kernel wrote the BatchNorm statistics of
+    y itself (W == 64, Cout == 64), else None."""
     B, H, W = x.shape
     Cout = w.shape[0]
     y = _empty(B, H, W, Cout, like=x)
+    P = query("tag_conv3x3_c1_stats_rows", B, H, W, Cout) if (want_stats and FUSE_BN_STATS) else 0
+    if P > 0:
+        part = (P, _empty(P * (3 * Cout + 1), like=x))
+        call("tag_conv3x3_c1_forward_stats", ptr(x), ptr(col_scale), ptr(col_shift), ptr(w), ptr(y), ptr(part[1]), B, H, W,
+             Cout)
+        return y, part
     call("tag_conv3x3_c1_forward", ptr(x), ptr(col_scale), ptr(col_shift), ptr(w), ptr(y), B, H, W, Cout)
-    return y
+    return y, None
 
 
 def conv3x3_c1_wgrad(x, dy, col_scale=None, col_shift=None):
@@ -587,8 +599,8 @@ class Cnn8RnnFunction(torch.autograd.Function):
         for i, (c1w, g1, b1, c2w, g2, b2) in enumerate(blocks):
             blk = getattr(mod, f"conv_block{i + 1}")
             if i == 0:
-                y1 = conv3x3_c1(lm, c1w, st0.scale, st0.shift)
-                wf1 = wd1 = part1 = None
+                y1, part1 = conv3x3_c1_stats(lm, c1w, st0.scale, st0.shift, want_stats=bn_train)
+                wf1 = wd1 = None
             else:
                 wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
                 y1, part1 = conv3x3_stats(x, wf1, c1w.shape[0], want_stats=bn_train)

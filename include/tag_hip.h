@@ -393,6 +393,39 @@ int tag_maxmargin_forward(const float* x /*(n,n)*/, int n, float margin, float l
 int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, const float* dloss, float* dx,
                            void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BASELINE configs[2]: bf16 ACTIVATION STORAGE.  The big tensors of the conv stack -- raw conv outputs, pooled block
+ * outputs and the gradients of both -- are bf16 in HBM (void* here: raw 16-bit patterns, channels-last as before);
+ * every product is bf16 x bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm statistics (from the fp32
+ * accumulators / values before rounding), scale/shift, the per-channel gradient sums (fp64), weight gradients, the
+ * GRU, the heads, the loss and the master weights stay fp32.  Outputs are rounded to nearest-even.  Same argument
+ * meaning as the fp32 entry points of the same name (models/panns.py:46-62, models/audio_encoder.py:202-212).
+ * tag_conv3x3_forward_x3_bf16 / tag_conv3x3_wgrad_x3_bf16 take the ONE-product weight pack
+ * (tag_pack_conv_weight_x3(..., products = 1)).
+ * ------------------------------------------------------------------------------------------- */
+int tag_conv3x3_c1_forward_stats_bf16(const float* x, const float* col_scale, const float* col_shift, const float* w,
+                                      void* y, float* stats /* nullable */, int B, int H, int W, int Cout, void* stream);
+int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_scale, const float* col_shift, const void* dy,
+                                 const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
+                                 void* stream);
+int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int prologue, const float* in_scale,
+                                const float* in_shift, void* y, float* stats, int B, int H, int W, int Cin, int Cout,
+                                void* stream);
+int tag_conv3x3_wgrad_x3_bf16(const void* x, int prologue, const float* in_scale, const float* in_shift, const void* dy,
+                              float* dw, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
+int tag_bnact_pool_forward_bf16(const void* y, const float* scale, const float* shift, void* out, int B, int H, int W,
+                                int C, int ph, int pw, int act, int pool, float drop_p, uint64_t seed, void* stream);
+int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                  const float* invstd, const float* gamma, const void* dout, void* dy, float* dgamma,
+                                  float* dbeta, int B, int H, int W, int C, int ph, int pw, float drop_p, uint64_t seed,
+                                  int bn_train, void* ws, void* stream);
+int tag_bnrelu_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const float* gamma, const void* da, void* dy, float* dgamma,
+                             float* dbeta, long rows, int C, int bn_train, void* ws, void* stream);
+int tag_mean_w_forward_bf16(const void* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out, void* stream);
+int tag_mean_w_backward_bf16(const float* dout, long rows, int W, int C, float drop_p, uint64_t seed, void* dx,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

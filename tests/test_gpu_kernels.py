@@ -259,6 +259,108 @@ def test_conv3x3_bf16_mode(ops, dev, B, H, W, Cin, Cout):
     assert e_f < 5e-6 and e_d < 5e-6 and e_w < 5e-6
 
 
+# ------------------------------------------------------------------------------------------- bf16 activation storage
+def bf(t):
+    return t.bfloat16()
+
+
+def ulp_bf16(ref):
+    """Half a bf16 ulp of |ref| (8 significand bits): the rounding budget of a value stored as bf16."""
+    return ref.abs().double() * 2.0 ** -8 + 1e-30
+
+
+@pytest.mark.parametrize("pro", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 32, 64, 64), (1, 17, 16, 64, 128), (2, 250, 8, 256, 512), (2, 37, 64, 64, 64),
+                                            (2, 500, 32, 128, 128)])
+def test_conv3x3_bf16_storage(ops, dev, B, H, W, Cin, Cout, pro):
+    """configs[2] storage: bf16 tensors in, bf16 tensors out, fp32 accumulate.  Forward (with / without the producer's
+    BN+ReLU folded into the operand load), dgrad and wgrad equal the fp64 convolution of the SAME bf16 operands up to one
+    bf16 rounding of the result (forward / dgrad outputs are bf16) or fp32 round-off (wgrad output is fp32)."""
+    g = torch.Generator().manual_seed(H + W + pro)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    wb = w.bfloat16().double()
+    a = x.double()
+    if pro:
+        a = F.relu(a * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        a = (a.float()).bfloat16().double()     # the kernel rounds the prologue's fp32 result to bf16 for the MFMA
+    y_ref = F.conv2d(a, wb, None, 1, 1)
+    da_ref = torch.nn.grad.conv2d_input(x.shape, wb, dy.double(), 1, 1)
+    dw_ref = torch.nn.grad.conv2d_weight(a, w.shape, dy.double(), 1, 1)
+    old = ops.CONV_MATH
+    ops.CONV_MATH = "bf16"
+    try:
+        wf, wdg = ops.pack_conv_weight(w.to(dev), W=W)
+        xs, dys = nhwc(x).to(dev), nhwc(dy).to(dev)
+        assert xs.dtype == torch.bfloat16
+        kw = dict(prologue=1, scale=sc.to(dev), shift=sh.to(dev)) if pro else {}
+        y, part = ops.conv3x3_stats(xs, wf, Cout, want_stats=True, **kw)
+        da = ops.conv3x3(dys, wdg, Cin)
+        dw = ops.conv3x3_wgrad(xs, dys, **kw)
+    finally:
+        ops.CONV_MATH = old
+    assert y.dtype == torch.bfloat16 and da.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    ey = ((nchw(y).cpu().double() - y_ref).abs() / (ulp_bf16(y_ref) + 1e-3 * 2.0 ** -8)).max().item()
+    ed = ((nchw(da).cpu().double() - da_ref).abs() / (ulp_bf16(da_ref) + 1e-3 * 2.0 ** -8)).max().item()
+    ew = relerr(dw, dw_ref)
+    print(f"bf16 storage conv {B}x{H}x{W} {Cin}->{Cout} pro={pro}: fwd {ey:.2f} dgrad {ed:.2f} (in half-ulps of bf16), wgrad {ew:.2e}")
+    # a prologue value that sits on a bf16 rounding boundary may round the other way in fp32 vs fp64: allow 2 half-ulps
+    assert ey <= (2.0 if pro else 1.01) and ed <= 1.01 and ew < (2e-3 if pro else 1e-5)
+    # BatchNorm statistics come from the fp32 accumulators (before the bf16 rounding of y)
+    st = ops.bn_stats(y.view(-1, Cout), torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev), None, None, True,
+                      partials=part)
+    yd = y_ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert relerr(st.mean, yd.mean(0)) < (5e-3 if pro else 2e-5)
+    assert relerr(1.0 / st.invstd.cpu().double() ** 2, yd.var(0, unbiased=False) + 1e-5) < (5e-3 if pro else 2e-5)
+
+
+@pytest.mark.parametrize("H,W,C,ph,pw,p", [(9, 8, 64, 2, 2, 0.0), (7, 8, 128, 1, 2, 0.2), (1001, 64, 64, 2, 2, 0.2),
+                                           (250, 8, 512, 1, 2, 0.2)])
+def test_bn_pool_kernels_bf16_storage(ops, dev, H, W, C, ph, pw, p):
+    """The BatchNorm / ReLU / pool / dropout kernels on bf16 tensors = the fp32 kernels on the same (bf16-representable)
+    values, up to the bf16 rounding of their outputs; per-channel sums (fp64) to fp32 round-off."""
+    B = 2
+    g = torch.Generator().manual_seed(H + C)
+    y = bf(torch.randn(B, H, W, C, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    y32 = y.float().to(dev)
+    st = ops.bn_stats(y32.view(-1, C), gamma.to(dev), beta.to(dev), None, None, True)
+    seed = 777
+    out32 = ops.bnact_pool(y32, st, ph, pw, 1, 0, p, seed)
+    out16 = ops.bnact_pool(y.to(dev), st, ph, pw, 1, 0, p, seed)
+    assert out16.dtype == torch.bfloat16
+    assert ((out16.float() - out32).abs().cpu().double() / (ulp_bf16(out32.cpu()) + 1e-9)).max().item() <= 1.01
+    dout = bf(torch.randn(out32.shape, generator=g))
+    dy32, dg32, db32 = ops.bnrelu_pool_backward(y32, st, gamma.to(dev), dout.float().to(dev), ph, pw, p, seed)
+    dy16, dg16, db16 = ops.bnrelu_pool_backward(y.to(dev), st, gamma.to(dev), dout.to(dev), ph, pw, p, seed)
+    assert dy16.dtype == torch.bfloat16
+    assert ((dy16.float() - dy32).abs().cpu().double() / (ulp_bf16(dy32.cpu()) + 1e-9)).max().item() <= 1.01
+    assert relerr(dg16, dg32) < 1e-6 and relerr(db16, db32) < 1e-6
+    da = bf(torch.randn(B, H, W, C, generator=g))
+    e32, eg32, eb32 = ops.bnrelu_backward(y32, st, gamma.to(dev), da.float().to(dev), inplace=False)
+    e16, eg16, eb16 = ops.bnrelu_backward(y.to(dev), st, gamma.to(dev), da.to(dev), inplace=False)
+    assert ((e16.float() - e32).abs().cpu().double() / (ulp_bf16(e32.cpu()) + 1e-9)).max().item() <= 1.01
+    assert relerr(eg16, eg32) < 1e-6 and relerr(eb16, eb32) < 1e-6
+
+
+def test_conv_c1_bf16_storage(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cout = 3, 101, 64, 64
+    x = torch.randn(B, H, W, generator=g) * 10 - 30
+    cs, ct = torch.rand(W, generator=g) * 0.1 + 0.05, torch.randn(W, generator=g)
+    w = torch.randn(Cout, 1, 3, 3, generator=g) / 3
+    y32, p32 = ops.conv3x3_c1_stats(x.to(dev), w.to(dev), cs.to(dev), ct.to(dev), want_stats=True)
+    y16, p16 = ops.conv3x3_c1_stats(x.to(dev), w.to(dev), cs.to(dev), ct.to(dev), want_stats=True, out_dtype=torch.bfloat16)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())          # same fp32 values, rounded once
+    assert torch.equal(p16[1], p32[1])                                                # statistics from the fp32 values
+    dy = bf(torch.randn(B, H, W, Cout, generator=g))
+    dw32, dx32 = ops.conv3x3_c1_backward(x.to(dev), dy.float().to(dev), w.to(dev), cs.to(dev), ct.to(dev))
+    dw16, dx16 = ops.conv3x3_c1_backward(x.to(dev), dy.to(dev), w.to(dev), cs.to(dev), ct.to(dev))
+    assert torch.equal(dw16, dw32) and torch.equal(dx16, dx32)                        # fp32 outputs of identical inputs
+
+
 @pytest.mark.parametrize("math_", ["fp32", "x3"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 8, 64, 128), (1, 17, 16, 64, 64), (2, 1001, 64, 64, 64), (3, 250, 8, 256, 512),
                                             (2, 501, 32, 64, 128)])

@@ -305,11 +305,11 @@ struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
 // ------------------------------------------------------------------------------------------
 // forward: act(bn(y)) -> pool -> dropout
 // ------------------------------------------------------------------------------------------
-template <int PH, int PW>
-__global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __restrict__ y,
+template <int PH, int PW, class TS = float>
+__global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restrict__ y,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
-                                                             float* __restrict__ out, int B, int H, int W, int C,
+                                                             TS* __restrict__ out, int B, int H, int W, int C,
                                                              int act, int pool, float drop_p, uint64_t seed) {
     const int Ho = H / PH, Wo = W / PW, C4 = C >> 2, rpi = 256 / C4;
     const int c = (threadIdx.x % C4) << 2, rsub = threadIdx.x / C4;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __rest
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
                 const size_t off = (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c;
-                const float4 v = *reinterpret_cast<const float4*>(y + off);
+                const f32x4 v = Act<TS>::ld4(y + off);
                 float a[4] = {fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __rest
             rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
             if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)i * 4 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
         }
-        reinterpret_cast<float4*>(out)[i] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        Act<TS>::st4(out + i * 4, (f32x4){rr[0], rr[1], rr[2], rr[3]});
     }
 }
 
@@ -360,10 +360,10 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const float* __rest
 // including the partial slots of the floor-dropped last row/column (dz = 0 there).
 // MODE 0: accumulate (sum dz, sum dz*xhat); MODE 1: write dy.
 // ------------------------------------------------------------------------------------------
-template <int PH, int PW>
+template <int PH, int PW, class TS = float>
 struct PoolBwdCtx {
-    const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
-    const float* dout; int B, H, W, C; float drop_p; uint64_t seed;
+    const TS* y; const float* scale; const float* shift; const float* mean; const float* invstd;
+    const TS* dout; int B, H, W, C; float drop_p; uint64_t seed;
     float sv[4], tv[4], mv[4], iv[4];      // per-channel constants of this thread's channel quad
     __device__ void prep(int c) {
 #pragma unroll
@@ -381,8 +381,8 @@ struct PoolBwdCtx {
             for (int dw = 0; dw < PW; ++dw) {
                 const int h = hs * PH + dh, w = ws * PW + dw;
                 ex[dh][dw] = h < H && w < W;
-                float4 v = make_float4(0, 0, 0, 0);
-                if (ex[dh][dw]) v = *reinterpret_cast<const float4*>(y + (((size_t)b * H + h) * W + w) * C + c);
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (ex[dh][dw]) v = Act<TS>::ld4(y + (((size_t)b * H + h) * W + w) * C + c);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -393,7 +393,7 @@ struct PoolBwdCtx {
             }
         if (!full) return;
         const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
-        const float4 g4 = *reinterpret_cast<const float4*>(dout + oi);
+        const f32x4 g4 = Act<TS>::ld4(dout + oi);
         float g[4] = {g4.x, g4.y, g4.z, g4.w};
         const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
 #pragma unroll
@@ -419,8 +419,8 @@ struct PoolBwdCtx {
     }
 };
 
-template <int PH, int PW>
-__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW> ctx, double* __restrict__ partials) {
+template <int PH, int PW, class TS = float>
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW, TS> ctx, double* __restrict__ partials) {
     extern __shared__ double sred[];
     const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
     const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
@@ -456,11 +456,11 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW>
     }
 }
 
-template <int PH, int PW>
-__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW> ctx, const float* __restrict__ gamma,
+template <int PH, int PW, class TS = float>
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, TS> ctx, const float* __restrict__ gamma,
                                                              const float* __restrict__ dgamma,
                                                              const float* __restrict__ dbeta, int bn_train,
-                                                             float* __restrict__ dy) {
+                                                             TS* __restrict__ dy) {
     const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
     const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
     const int Hs = (ctx.H + PH - 1) / PH, Ws = (ctx.W + PW - 1) / PW;
@@ -488,16 +488,16 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW> 
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
-                *reinterpret_cast<float4*>(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c) =
-                    make_float4(o[0], o[1], o[2], o[3]);
+                Act<TS>::st4(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c, (f32x4){o[0], o[1], o[2], o[3]});
             }
     }
 }
 
 // plain relu(bn(y)) backward (no pooling)
-struct BnReluBwdFn {
-    const float* y; const float* scale; const float* shift; const float* mean; const float* invstd;
-    const float* da; int C;
+template <class TS = float>
+struct BnReluBwdFnT {
+    const TS* y; const float* scale; const float* shift; const float* mean; const float* invstd;
+    const TS* da; int C;
     float4 s, t, m, is;
     __device__ void prep(int c) {
         s = *reinterpret_cast<const float4*>(scale + c);
@@ -506,8 +506,8 @@ struct BnReluBwdFn {
         is = *reinterpret_cast<const float4*>(invstd + c);
     }
     __device__ void operator()(long r, int c, float4& a, float4& b) const {
-        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * C + c);
-        const float4 g = *reinterpret_cast<const float4*>(da + (size_t)r * C + c);
+        const f32x4 v = Act<TS>::ld4(y + (size_t)r * C + c);
+        const f32x4 g = Act<TS>::ld4(da + (size_t)r * C + c);
         a.x = fmaf(v.x, s.x, t.x) > 0.0f ? g.x : 0.0f;
         a.y = fmaf(v.y, s.y, t.y) > 0.0f ? g.y : 0.0f;
         a.z = fmaf(v.z, s.z, t.z) > 0.0f ? g.z : 0.0f;
@@ -517,10 +517,13 @@ struct BnReluBwdFn {
     }
 };
 
-__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFn fn, const float* __restrict__ gamma,
+typedef BnReluBwdFnT<float> BnReluBwdFn;
+
+template <class TS>
+__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFnT<TS> fn, const float* __restrict__ gamma,
                                                                const float* __restrict__ dgamma,
                                                                const float* __restrict__ dbeta, int bn_train,
-                                                               long rows, float* __restrict__ dy) {
+                                                               long rows, TS* __restrict__ dy) {
     const int C = fn.C, tpr = C >> 2, rpi = 256 / tpr;
     const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
     const float invN = 1.0f / (float)rows;
@@ -536,12 +539,12 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(BnReluBwdFn fn, c
     for (long r = (long)blockIdx.x * rpi + rsub; r < rows; r += (long)gridDim.x * rpi) {
         float4 dz, dzx;
         fn(r, c, dz, dzx);
-        const float4 v = *reinterpret_cast<const float4*>(fn.y + (size_t)r * C + c);
+        const f32x4 v = Act<TS>::ld4(fn.y + (size_t)r * C + c);
         const float vv[4] = {v.x, v.y, v.z, v.w}, dzv[4] = {dz.x, dz.y, dz.z, dz.w};
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = k0[j] * (dzv[j] - k1[j] - (vv[j] - mv[j]) * iv[j] * k2[j]);
-        *reinterpret_cast<float4*>(dy + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+        Act<TS>::st4(dy + (size_t)r * C + c, (f32x4){o[0], o[1], o[2], o[3]});
     }
 }
 
@@ -666,21 +669,23 @@ __global__ void dropout_mask_kernel(uint64_t seed, long n, float p, uint8_t* mas
 }
 
 // mean over W then dropout: x (rows, W, C) -> (rows, C)
-__global__ __launch_bounds__(256) void mean_w_fwd_kernel(const float* __restrict__ x, long rows, int W, int C,
+template <class TS>
+__global__ __launch_bounds__(256) void mean_w_fwd_kernel(const TS* __restrict__ x, long rows, int W, int C,
                                                          float drop_p, uint64_t seed, float* __restrict__ out) {
     const long total = rows * C;
     const float ks = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C; const int c = (int)(i % C);
         float s = 0.0f;
-        for (int w = 0; w < W; ++w) s += x[((size_t)r * W + w) * C + c];
+        for (int w = 0; w < W; ++w) s += Act<TS>::ld1(x + ((size_t)r * W + w) * C + c);
         s = s / (float)W;
         if (drop_p > 0.0f) s = tag_keep(seed, (uint64_t)i, drop_p) ? s * ks : 0.0f;
         out[i] = s;
     }
 }
+template <class TS>
 __global__ __launch_bounds__(256) void mean_w_bwd_kernel(const float* __restrict__ dout, long rows, int W, int C,
-                                                         float drop_p, uint64_t seed, float* __restrict__ dx) {
+                                                         float drop_p, uint64_t seed, TS* __restrict__ dx) {
     const long total = rows * C;
     const float ks = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256) void mean_w_bwd_kernel(const float* __restrict
         float g = dout[i];
         if (drop_p > 0.0f) g = tag_keep(seed, (uint64_t)i, drop_p) ? g * ks : 0.0f;
         g = g / (float)W;
-        for (int w = 0; w < W; ++w) dx[((size_t)r * W + w) * C + c] = g;
+        for (int w = 0; w < W; ++w) Act<TS>::st1(dx + ((size_t)r * W + w) * C + c, g);
     }
 }
 
@@ -810,34 +815,45 @@ extern "C" int tag_bn_param_grad(const float* x, const float* dy, long rows, int
 #define DISPATCH_POOL(PH_, PW_, ...)                       \
     if (ph == PH_ && pw == PW_) { constexpr int PH = PH_, PW = PW_; __VA_ARGS__; launched = true; }
 
-extern "C" int tag_bnact_pool_forward(const float* y, const float* scale, const float* shift, float* out, int B,
-                                      int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
-                                      uint64_t seed, void* stream) {
+template <class TS>
+static int bnact_pool_forward_impl(const TS* y, const float* scale, const float* shift, TS* out, int B, int H, int W, int C,
+                                   int ph, int pw, int act, int pool, float drop_p, uint64_t seed, void* stream) {
     TAG_CHECK_ARG(y && out && C % 4 == 0 && (act == 1 || act == 2) && (pool == 0 || pool == 1));
     TAG_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
     TAG_CHECK_ARG(vec_ok(C));
     bool launched = false;
     const int nb = apply_blocks((long)B * (H / ph) * (W / pw), C);
-    DISPATCH_POOL(2, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
-                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
-    DISPATCH_POOL(1, 2, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
-                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
-    DISPATCH_POOL(2, 4, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
-                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
-    DISPATCH_POOL(1, 4, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
-                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
-    DISPATCH_POOL(1, 1, hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream),
-                                           y, scale, shift, out, B, H, W, C, act, pool, drop_p, seed))
+#define POOL_FWD_BODY                                                                                              \
+    hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW, TS>), dim3(nb), dim3(256), 0, as_stream(stream), y, scale, shift, \
+                       out, B, H, W, C, act, pool, drop_p, seed)
+    DISPATCH_POOL(2, 2, POOL_FWD_BODY)
+    DISPATCH_POOL(1, 2, POOL_FWD_BODY)
+    DISPATCH_POOL(2, 4, POOL_FWD_BODY)
+    DISPATCH_POOL(1, 4, POOL_FWD_BODY)
+    DISPATCH_POOL(1, 1, POOL_FWD_BODY)
+#undef POOL_FWD_BODY
     TAG_CHECK_ARG(launched);
     TAG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int tag_bnact_pool_forward(const float* y, const float* scale, const float* shift, float* out, int B,
+                                      int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
+                                      uint64_t seed, void* stream) {
+    return bnact_pool_forward_impl<float>(y, scale, shift, out, B, H, W, C, ph, pw, act, pool, drop_p, seed, stream);
+}
+extern "C" int tag_bnact_pool_forward_bf16(const void* y, const float* scale, const float* shift, void* out, int B,
+                                           int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
+                                           uint64_t seed, void* stream) {
+    return bnact_pool_forward_impl<bf16_t>(static_cast<const bf16_t*>(y), scale, shift, static_cast<bf16_t*>(out), B, H, W, C,
+                                           ph, pw, act, pool, drop_p, seed, stream);
+}
 
-extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift, const float* mean,
-                                        const float* invstd, const float* gamma, const float* dout, float* dy,
-                                        float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
-                                        float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+template <class TS>
+static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const float* gamma, const TS* dout, TS* dy, float* dgamma,
+                                     float* dbeta, int B, int H, int W, int C, int ph, int pw, float drop_p, uint64_t seed,
+                                     int bn_train, void* ws, void* stream) {
     TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && dout && dy && dgamma && dbeta && ws);
     TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
     double* partials = static_cast<double*>(ws);
@@ -846,12 +862,12 @@ extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, cons
     const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C);
     bool launched = false;
 #define POOL_BWD_BODY                                                                                              \
-    PoolBwdCtx<PH, PW> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                         \
-    hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),          \
+    PoolBwdCtx<PH, PW, TS> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                     \
+    hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW, TS>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),      \
                        as_stream(stream), ctx, partials);                                                          \
     hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, \
                        C, dgamma, dbeta);                                                                          \
-    hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma,     \
+    hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW, TS>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma, \
                        dgamma, dbeta, bn_train, dy);
     DISPATCH_POOL(2, 2, POOL_BWD_BODY)
     DISPATCH_POOL(1, 2, POOL_BWD_BODY)
@@ -861,24 +877,54 @@ extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, cons
     TAG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, const float* gamma, const float* dout, float* dy,
+                                        float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
+                                        float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+    return bnrelu_pool_backward_impl<float>(y, scale, shift, mean, invstd, gamma, dout, dy, dgamma, dbeta, B, H, W, C, ph, pw,
+                                            drop_p, seed, bn_train, ws, stream);
+}
+extern "C" int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                             const float* invstd, const float* gamma, const void* dout, void* dy,
+                                             float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
+                                             float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+    return bnrelu_pool_backward_impl<bf16_t>(static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
+                                             static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dy), dgamma, dbeta, B, H, W,
+                                             C, ph, pw, drop_p, seed, bn_train, ws, stream);
+}
 
-extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, const float* mean,
-                                   const float* invstd, const float* gamma, const float* da, float* dy,
-                                   float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
-                                   void* stream) {
+template <class TS>
+static int bnrelu_backward_impl(const TS* y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* gamma, const TS* da, TS* dy, float* dgamma,
+                                float* dbeta, long rows, int C, int bn_train, void* ws, void* stream) {
     TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && da && dy && dgamma && dbeta && ws && vec_ok(C));
     double* partials = static_cast<double*>(ws);
     const int nblk = red_blocks(rows, C);
-    BnReluBwdFn fn{y, scale, shift, mean, invstd, da, C};
-    hipLaunchKernelGGL(reduce2_kernel<BnReluBwdFn>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
+    BnReluBwdFnT<TS> fn{y, scale, shift, mean, invstd, da, C};
+    hipLaunchKernelGGL(reduce2_kernel<BnReluBwdFnT<TS>>, dim3(nblk), dim3(256), 256 * 8 * sizeof(double),
                        as_stream(stream), fn, rows, C, partials);
     TAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, C,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn,
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<TS>, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn,
                        gamma, dgamma, dbeta, bn_train, rows, dy);
     TAG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const float* gamma, const float* da, float* dy,
+                                   float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
+                                   void* stream) {
+    return bnrelu_backward_impl<float>(y, scale, shift, mean, invstd, gamma, da, dy, dgamma, dbeta, rows, C, bn_train, ws,
+                                       stream);
+}
+extern "C" int tag_bnrelu_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, const float* gamma, const void* da, void* dy,
+                                        float* dgamma, float* dbeta, long rows, int C, int bn_train, void* ws,
+                                        void* stream) {
+    return bnrelu_backward_impl<bf16_t>(static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
+                                        static_cast<const bf16_t*>(da), static_cast<bf16_t*>(dy), dgamma, dbeta, rows, C,
+                                        bn_train, ws, stream);
 }
 
 extern "C" size_t tag_bn_grad_from_partials_ws_bytes(int P, int C) {
@@ -906,7 +952,7 @@ extern "C" int tag_bnrelu_backward_apply(const float* y, const float* scale, con
                                          void* stream) {
     TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && da && dy && dgamma && dbeta && vec_ok(C));
     BnReluBwdFn fn{y, scale, shift, mean, invstd, da, C};
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn, gamma,
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn, gamma,
                        dgamma, dbeta, bn_train, rows, dy);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -922,7 +968,7 @@ extern "C" int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, v
 extern "C" int tag_mean_w_forward(const float* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out,
                                   void* stream) {
     TAG_CHECK_ARG(x && out && rows > 0 && W > 0 && C > 0);
-    hipLaunchKernelGGL(mean_w_fwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), x, rows, W, C,
+    hipLaunchKernelGGL(mean_w_fwd_kernel<float>, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), x, rows, W, C,
                        drop_p, seed, out);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -930,8 +976,24 @@ extern "C" int tag_mean_w_forward(const float* x, long rows, int W, int C, float
 extern "C" int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p, uint64_t seed, float* dx,
                                    void* stream) {
     TAG_CHECK_ARG(dout && dx && rows > 0 && W > 0 && C > 0);
-    hipLaunchKernelGGL(mean_w_bwd_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), dout, rows, W,
+    hipLaunchKernelGGL(mean_w_bwd_kernel<float>, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), dout, rows, W,
                        C, drop_p, seed, dx);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_mean_w_forward_bf16(const void* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out,
+                                       void* stream) {
+    TAG_CHECK_ARG(x && out && rows > 0 && W > 0 && C > 0);
+    hipLaunchKernelGGL(mean_w_fwd_kernel<bf16_t>, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream),
+                       static_cast<const bf16_t*>(x), rows, W, C, drop_p, seed, out);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_mean_w_backward_bf16(const float* dout, long rows, int W, int C, float drop_p, uint64_t seed, void* dx,
+                                        void* stream) {
+    TAG_CHECK_ARG(dout && dx && rows > 0 && W > 0 && C > 0);
+    hipLaunchKernelGGL(mean_w_bwd_kernel<bf16_t>, dim3(ew_blocks(rows * C)), dim3(256), 0, as_stream(stream), dout, rows, W,
+                       C, drop_p, seed, static_cast<bf16_t*>(dx));
     TAG_LAUNCH_CHECK();
     return 0;
 }

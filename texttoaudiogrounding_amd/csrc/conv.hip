@@ -1156,9 +1156,10 @@ constexpr int C1B_GW = 66, C1B_GT = 10;        // LDS ring rows: 64 + 2 halo pix
 // three input rows of the current output row live in an LDS ring (bn0 affine and zero padding applied once per value),
 // every thread produces 4 pixels x 4 couts per row (weights in registers) and stores 16 B per pixel -> the kernel is a
 // pure 1 GB write stream.
+template <class TS>
 __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                                const float* __restrict__ ct, const float* __restrict__ wgt,
-                                                               float* __restrict__ y, float* __restrict__ stats, int H,
+                                                               TS* __restrict__ y, float* __restrict__ stats, int H,
                                                                int strips, int rows_per_strip) {
     constexpr int W = 64, Cout = 64;
     __shared__ float Xs[4][C1B_GW];
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int k = 0; k < 6; ++k) xin[r][k] = Xs[(h + r - 1 + 8) & 3][grp * 4 + k];
-        float* yrow = y + (((size_t)img * H + h) * W + grp * 4) * Cout + c;
+        TS* yrow = y + (((size_t)img * H + h) * W + grp * 4) * Cout + c;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             float o[4] = {0, 0, 0, 0};
@@ -1209,7 +1210,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fmaf(xin[tap / 3][px + tap % 3], wr[j][tap], o[j]);
-            *reinterpret_cast<float4*>(yrow + (size_t)px * Cout) = make_float4(o[0], o[1], o[2], o[3]);
+            Act<TS>::st4(yrow + (size_t)px * Cout, (f32x4){o[0], o[1], o[2], o[3]});
             if (stats) {
                 if (!have_pivot) {
 #pragma unroll
@@ -1252,8 +1253,9 @@ __device__ __forceinline__ float sum16(float v) {
     v = dpp_add<0x140>(v);       // row_mirror
     return v;
 }
+template <class TS>
 __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ cs,
-                                                          const float* __restrict__ ct, const float* __restrict__ dy,
+                                                          const float* __restrict__ ct, const TS* __restrict__ dy,
                                                           const float* __restrict__ wgt, float* __restrict__ dx,
                                                           double* __restrict__ partials, int H, int strips,
                                                           int rows_per_strip) {
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
         for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
     for (int i = tid; i < 4 * C1B_GW * C1B_GT; i += 256) (&Gs[0][0][0])[i] = 0.0f;      // halo columns stay zero
     const float* ximg = x + (size_t)img * H * W;
-    const float* dimg = dy + (size_t)img * H * W * Cout;
+    const TS* dimg = dy + (size_t)img * H * W * Cout;
     auto stage_x = [&](int row) {                                         // bn0 affine applied; zero outside the image
         if (tid < C1B_GW) {
             const int w = tid - 1;
@@ -1294,10 +1296,10 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
     f32x4 g[4], gn[4];
     auto load_dy = [&](int row, f32x4 (&dst)[4]) {
         const bool ok = (unsigned)row < (unsigned)H;
-        const float* p = dimg + ((size_t)(ok ? row : 0) * W + wid * 16 + psub) * Cout + c;
+        const TS* p = dimg + ((size_t)(ok ? row : 0) * W + wid * 16 + psub) * Cout + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dst[i] = *reinterpret_cast<const f32x4*>(p + (size_t)i * 4 * Cout);
+            dst[i] = Act<TS>::ld4(p + (size_t)i * 4 * Cout);
             if (!ok) dst[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
@@ -1668,7 +1670,7 @@ extern "C" int tag_conv3x3_c1_forward(const float* x, const float* col_scale, co
     if (W == 64 && Cout == 64) {
         int strips, rows;
         c1_bwd_geom(B, H, &strips, &rows);
-        hipLaunchKernelGGL(conv_c1_fwd_rows_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
+        hipLaunchKernelGGL(conv_c1_fwd_rows_kernel<float>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
                            col_shift, w, y, (float*)nullptr, H, strips, rows);
     } else if (W % 4 == 0 && 256 % (Cout / 4) == 0) {
         nb = ((M / 4) * (Cout / 4) + 255) / 256;
@@ -1697,8 +1699,21 @@ extern "C" int tag_conv3x3_c1_forward_stats(const float* x, const float* col_sca
     TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
     int strips, rows;
     c1_bwd_geom(B, H, &strips, &rows);
-    hipLaunchKernelGGL(conv_c1_fwd_rows_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, w,
+    hipLaunchKernelGGL(conv_c1_fwd_rows_kernel<float>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, w,
                        y, stats, H, strips, rows);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+// bf16 activation storage (BASELINE configs[2]): y is written as bf16, statistics come from the fp32 values
+extern "C" int tag_conv3x3_c1_forward_stats_bf16(const float* x, const float* col_scale, const float* col_shift,
+                                                 const float* w, void* y, float* stats, int B, int H, int W, int Cout,
+                                                 void* stream) {
+    TAG_CHECK_ARG(x && w && y && W == 64 && Cout == 64 && B > 0 && H > 0);
+    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    hipLaunchKernelGGL(conv_c1_fwd_rows_kernel<bf16_t>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
+                       col_shift, w, static_cast<bf16_t*>(y), stats, H, strips, rows);
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -1766,8 +1781,25 @@ extern "C" int tag_conv3x3_c1_backward(const float* x, const float* col_scale, c
     int strips, rows;
     c1_bwd_geom(B, H, &strips, &rows);
     double* partials = static_cast<double*>(ws);
-    hipLaunchKernelGGL(conv_c1_bwd_kernel, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, dy,
+    hipLaunchKernelGGL(conv_c1_bwd_kernel<float>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, dy,
                        w, dx, partials, H, strips, rows);
+    TAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
+                       partials, B * strips, Cout * 9, dw);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_scale, const float* col_shift, const void* dy,
+                                            const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
+                                            void* stream) {
+    TAG_CHECK_ARG(x && dy && w && dw && dx && ws && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 64 && Cout == 64);
+    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
+    int strips, rows;
+    c1_bwd_geom(B, H, &strips, &rows);
+    double* partials = static_cast<double*>(ws);
+    hipLaunchKernelGGL(conv_c1_bwd_kernel<bf16_t>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift,
+                       static_cast<const bf16_t*>(dy), w, dx, partials, H, strips, rows);
     TAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
                        partials, B * strips, Cout * 9, dw);

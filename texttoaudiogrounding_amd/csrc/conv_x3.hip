@@ -94,15 +94,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 
 // MB = 32-pixel MFMA blocks per wave (4: wave = 128 px x 32 co, workgroup 128 x 128; 2: wave = 64 px x 32 co,
 // workgroup 128 x 64).  NP = products per fp32 multiply (6 default, 9 exact, 1 plain bf16).
-template <int MB, int PRO, int TW, int NP>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restrict__ x, const u32x4* __restrict__ wp,
+// TS = activation storage of x and y: float, or bf16_t (BASELINE configs[2]: bf16 tensors; NP == 1 only) -- then the
+// patch is staged as (pixel, channel OCTET) items of 16 B, copied to LDS as they are when there is no prologue, and the
+// output is rounded to bf16 (nearest-even) and stored as channel pairs.
+template <int MB, int PRO, int TW, int NP, class TS = float>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict__ x, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ in_scale,
-                                                            const float* __restrict__ in_shift, float* __restrict__ y,
+                                                            const float* __restrict__ in_shift, TS* __restrict__ y,
                                                             float* __restrict__ stats, int B, int H, int W, int Cin,
                                                             int Cout) {
     using G = X3Geom<TW>;
+    constexpr bool HS16 = Act<TS>::is_bf16;
+    static_assert(!HS16 || NP == 1, "bf16 storage goes with the one-product arithmetic");
     constexpr int BN_ = MB == 4 ? 128 : 64;
     constexpr int NSPL = NP == 1 ? 1 : 3;                         // planes actually read
+    constexpr int QPP = HS16 ? 4 : 8;                             // staging items per pixel: octets (16 B bf16) | quads (16 B fp32)
+    constexpr int QSH = HS16 ? 2 : 3;
+    constexpr int ITEMS = (G::PH * (TW + 2) * QPP + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Ss = reinterpret_cast<float*>(smem + 3 * G::PLANE);    // [2][Cin]
 
@@ -121,14 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     if (PRO != 0)
         for (int c = tid; c < Cin; c += 256) { Ss[c] = in_scale[c]; Ss[Cin + c] = in_shift[c]; }
 
-    // ---- patch staging geometry: item = (patch pixel, channel quad) ----
-    const int q = tid & 7;
-    unsigned poff[G::ITEMS];
+    // ---- patch staging geometry: item = (patch pixel, channel quad | octet) ----
+    const int q = tid & (QPP - 1);
+    unsigned poff[ITEMS];
     unsigned pvalid = 0, pexist = 0;
 #pragma unroll
-    for (int i = 0; i < G::ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int idx = tid + 256 * i;
-        const int pp = idx >> 3;                                  // 0 .. PH*(TW+2)-1 (dense numbering of real patch pixels)
+        const int pp = idx >> QSH;                                // 0 .. PH*(TW+2)-1 (dense numbering of real patch pixels)
         const int pr = pp / (TW + 2), pc = pp - pr * (TW + 2);
         const int h = h0 - 1 + pr, w = pc - 1;
         const bool ex = pp < G::PH * (TW + 2);
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
         pexist |= (unsigned)ex << i;
         pvalid |= (unsigned)ok << i;
         const long pix = ok ? ((long)img * H + h) * W + w : (long)img * H * W;
-        poff[i] = (unsigned)((pix * Cin + q * 4) * 4);
+        poff[i] = HS16 ? (unsigned)((pix * Cin + q * 8) * 2) : (unsigned)((pix * Cin + q * 4) * 4);
     }
     // per-lane LDS byte offset of tap (ky=0,kx=0) for each MFMA block, channel octet kl
     unsigned abase[MB];
@@ -149,38 +157,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
     const int KK = Cin / 16, NBK = Cout / 32;
     const u32x4* wlane = wp + (size_t)(n0 / 32 + wn) * 192 + lane;        // + ((tap*KK + kk) * NBK) * 192 + s*64
 
-    f32x4 ra[G::ITEMS];
+    u32x4 ra[ITEMS];                                              // 16 B per item: 4 fp32 or 8 bf16
     auto issue_patch = [&](int cc) {
-        const unsigned coff = (unsigned)(cc * KC * 4);
+        const unsigned coff = (unsigned)(cc * KC * (HS16 ? 2 : 4));
 #pragma unroll
-        for (int i = 0; i < G::ITEMS; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + (poff[i] + coff));
+        for (int i = 0; i < ITEMS; ++i)
+            ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + (poff[i] + coff));
     };
     auto store_patch = [&](int cc) {
-        f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (PRO != 0) {
-            rs = *reinterpret_cast<const f32x4*>(Ss + cc * KC + q * 4);
-            rt = *reinterpret_cast<const f32x4*>(Ss + Cin + cc * KC + q * 4);
-        }
 #pragma unroll
-        for (int i = 0; i < G::ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             if (!((pexist >> i) & 1u)) continue;
-            const int pp = (tid + 256 * i) >> 3;
+            const int pp = (tid + 256 * i) >> QSH;
             const int pr = pp / (TW + 2), pc = pp - pr * (TW + 2);
-            f32x4 v;
-            v.x = prologue1(ra[i].x, PRO, rs.x, rt.x);
-            v.y = prologue1(ra[i].y, PRO, rs.y, rt.y);
-            v.z = prologue1(ra[i].z, PRO, rs.z, rt.z);
-            v.w = prologue1(ra[i].w, PRO, rs.w, rt.w);
-            if (!((pvalid >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
-            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
-            unsigned char* dst = smem + (pr * G::S + pc) * PIXB + q * 8;
-            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
-            if (NSPL == 3) {
-                *reinterpret_cast<u32x2*>(dst + G::PLANE) = (u32x2){m0_, m1_};
-                *reinterpret_cast<u32x2*>(dst + 2 * G::PLANE) = (u32x2){l0_, l1_};
+            const bool valid = (pvalid >> i) & 1u;
+            if constexpr (HS16) {
+                u32x4 o = ra[i];
+                if (PRO != 0) {
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(Ss + cc * KC + q * 8);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(Ss + cc * KC + q * 8 + 4);
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(Ss + Cin + cc * KC + q * 8);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(Ss + Cin + cc * KC + q * 8 + 4);
+                    o.x = tag_pack_bf16(prologue1(tag_bf16_lo(ra[i].x), PRO, s0.x, t0.x), prologue1(tag_bf16_hi(ra[i].x), PRO, s0.y, t0.y));
+                    o.y = tag_pack_bf16(prologue1(tag_bf16_lo(ra[i].y), PRO, s0.z, t0.z), prologue1(tag_bf16_hi(ra[i].y), PRO, s0.w, t0.w));
+                    o.z = tag_pack_bf16(prologue1(tag_bf16_lo(ra[i].z), PRO, s1.x, t1.x), prologue1(tag_bf16_hi(ra[i].z), PRO, s1.y, t1.y));
+                    o.w = tag_pack_bf16(prologue1(tag_bf16_lo(ra[i].w), PRO, s1.z, t1.z), prologue1(tag_bf16_hi(ra[i].w), PRO, s1.w, t1.w));
+                }
+                if (!valid) o = (u32x4){0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(smem + (pr * G::S + pc) * PIXB + q * 16) = o;
+            } else {
+                f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (PRO != 0) {
+                    rs = *reinterpret_cast<const f32x4*>(Ss + cc * KC + q * 4);
+                    rt = *reinterpret_cast<const f32x4*>(Ss + Cin + cc * KC + q * 4);
+                }
+                const f32x4 rv = __builtin_bit_cast(f32x4, ra[i]);
+                f32x4 v;
+                v.x = prologue1(rv.x, PRO, rs.x, rt.x);
+                v.y = prologue1(rv.y, PRO, rs.y, rt.y);
+                v.z = prologue1(rv.z, PRO, rs.z, rt.z);
+                v.w = prologue1(rv.w, PRO, rs.w, rt.w);
+                if (!valid) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+                split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+                split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
+                unsigned char* dst = smem + (pr * G::S + pc) * PIXB + q * 8;
+                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+                if (NSPL == 3) {
+                    *reinterpret_cast<u32x2*>(dst + G::PLANE) = (u32x2){m0_, m1_};
+                    *reinterpret_cast<u32x2*>(dst + 2 * G::PLANE) = (u32x2){l0_, l1_};
+                }
             }
         }
     };
@@ -275,7 +301,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const float* __restr
             pix_to_yx<TW>((wm * MB + i) * 32 + row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl), ty, tx);
             const int h = h0 + ty;
             okrow[i][r] = h < H;
-            if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
+            if constexpr (HS16) {
+                // channel pairs: even lanes store (n, n+1) of the even rows r, odd lanes (n-1, n) of the odd rows
+                const float other = __shfl_xor(acc[i][r], 1, 64);
+                const bool mine = ((r ^ ml) & 1) == 0;
+                const unsigned w2 = (ml & 1) ? tag_pack_bf16(other, acc[i][r]) : tag_pack_bf16(acc[i][r], other);
+                if (mine && h < H)
+                    *reinterpret_cast<unsigned*>(y + (((size_t)img * H + h) * W + tx) * Cout + (n & ~1)) = w2;
+            } else {
+                if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
+            }
         }
     // ---- fused BatchNorm statistics (see conv.hip): one partial row per wave M-group (MB * 32 pixels) ----
     if (stats) {
@@ -371,16 +406,20 @@ __device__ __forceinline__ u32x2 lds_tr_read(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-template <int TW, int PRO, int NP>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* __restrict__ x,
+template <int TW, int PRO, int NP, class TS = float>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __restrict__ x,
                                                                   const float* __restrict__ in_scale,
                                                                   const float* __restrict__ in_shift,
-                                                                  const float* __restrict__ dy,
+                                                                  const TS* __restrict__ dy,
                                                                   float* __restrict__ partial, int B, int H, int W,
                                                                   int Cin, int Cout, int splits, int chunks_per_split) {
     using G = WX3Geom<TW>;
     constexpr int CW = G::CW, CH = G::CH, PW = G::PW, R = G::R;
     constexpr int NSPL = NP == 1 ? 1 : 3;
+    constexpr bool HS16 = Act<TS>::is_bf16;                      // bf16 tensors: items are (pixel, channel OCTET) of 16 B
+    static_assert(!HS16 || NP == 1, "bf16 storage goes with the one-product arithmetic");
+    constexpr int QPP = HS16 ? 8 : 16, QSH = HS16 ? 3 : 4;       // items per pixel (64 channels)
+    constexpr int XITEMS = (CH * PW * QPP + 255) / 256, DITEMS = 32 * QPP / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Xs = smem;
     unsigned char* Ys = smem + G::XBYTES;
@@ -401,14 +440,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
     const int wi = wid >> 1, wj = wid & 1;                       // ci / co 32-block of the wave
     const int kl = lane >> 5, half = (lane >> 4) & 1, li = lane & 15;
 
-    // ---- staging geometry: item = (pixel, channel quad); quad = tid & 15 -> block (quad>>3), 8 B at (quad&7)*8 ----
-    const int quad = tid & 15;
-    const int ca = ci0 + quad * 4, cb = co0 + quad * 4;
-    const unsigned qoff = (unsigned)((quad >> 3) * 1 /*block*/), qbyte = (unsigned)((quad & 7) * 8);
-    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (PRO != 0) { rs = *reinterpret_cast<const f32x4*>(in_scale + ca); rt = *reinterpret_cast<const f32x4*>(in_shift + ca); }
+    // ---- staging geometry: item = (pixel, channel quad | octet); LDS block = 32 channels = 64 B per pixel ----
+    const int quad = tid & (QPP - 1);
+    const int ca = ci0 + quad * (HS16 ? 8 : 4), cb = co0 + quad * (HS16 ? 8 : 4);
+    const unsigned qoff = HS16 ? (unsigned)(quad >> 2) : (unsigned)(quad >> 3);
+    const unsigned qbyte = HS16 ? (unsigned)((quad & 3) * 16) : (unsigned)((quad & 7) * 8);
+    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f}, rs1 = rs, rt1 = rt;
+    if (PRO != 0) {
+        rs = *reinterpret_cast<const f32x4*>(in_scale + ca); rt = *reinterpret_cast<const f32x4*>(in_shift + ca);
+        if (HS16) { rs1 = *reinterpret_cast<const f32x4*>(in_scale + ca + 4); rt1 = *reinterpret_cast<const f32x4*>(in_shift + ca + 4); }
+    }
 
-    f32x4 rx[G::XITEMS], rd[2];
+    u32x4 rx[XITEMS], rd[DITEMS];
     unsigned xok = 0, dok = 0;
     // chunk index -> (img, h0, w0); row blocks run fastest so that consecutive chunks walk down a strip
     auto origin = [&](int c, int& img, int& h0, int& w0) {
@@ -420,40 +463,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
         const long ibase = (long)img * H * W;
         xok = 0;
 #pragma unroll
-        for (int i = 0; i < G::XITEMS; ++i) {
-            const int pp = (tid + 256 * i) >> 4;
+        for (int i = 0; i < XITEMS; ++i) {
+            const int pp = (tid + 256 * i) >> QSH;
             const int pr = pp / PW, pc = pp - pr * PW;
             const int h = first_row + pr, w = w0 - 1 + pc;
             const unsigned ok = (unsigned)(pp < CH * PW) & (unsigned)((unsigned)h < (unsigned)H) &
                                 (unsigned)((unsigned)w < (unsigned)W);
             xok |= ok << i;
             const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rx[i] = *reinterpret_cast<const f32x4*>(x + pix * Cin + ca);
+            rx[i] = *reinterpret_cast<const u32x4*>(x + pix * Cin + ca);
         }
     };
     auto store_rows = [&](int first_row, int last_wanted) {      // rows > last_wanted are not stored (priming overshoot)
 #pragma unroll
-        for (int i = 0; i < G::XITEMS; ++i) {
-            const int pp = (tid + 256 * i) >> 4;
+        for (int i = 0; i < XITEMS; ++i) {
+            const int pp = (tid + 256 * i) >> QSH;
             if (pp >= CH * PW) continue;
             const int pr = pp / PW, pc = pp - pr * PW;
             const int row = first_row + pr;
             if (row > last_wanted) continue;
             const int slot = (row + 4 * R) % R;
-            f32x4 v;
-            v.x = prologue1(rx[i].x, PRO, rs.x, rt.x);
-            v.y = prologue1(rx[i].y, PRO, rs.y, rt.y);
-            v.z = prologue1(rx[i].z, PRO, rs.z, rt.z);
-            v.w = prologue1(rx[i].w, PRO, rs.w, rt.w);
-            if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
-            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
+            const bool valid = (xok >> i) & 1u;
             unsigned char* dst = Xs + qoff * G::XPL + (slot * PW + pc) * 64 + qbyte;
-            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
-            if (NSPL == 3) {
-                *reinterpret_cast<u32x2*>(dst + 2 * G::XPL) = (u32x2){m0_, m1_};
-                *reinterpret_cast<u32x2*>(dst + 4 * G::XPL) = (u32x2){l0_, l1_};
+            if constexpr (HS16) {
+                u32x4 o = rx[i];
+                if (PRO != 0) {
+                    o.x = tag_pack_bf16(prologue1(tag_bf16_lo(rx[i].x), PRO, rs.x, rt.x), prologue1(tag_bf16_hi(rx[i].x), PRO, rs.y, rt.y));
+                    o.y = tag_pack_bf16(prologue1(tag_bf16_lo(rx[i].y), PRO, rs.z, rt.z), prologue1(tag_bf16_hi(rx[i].y), PRO, rs.w, rt.w));
+                    o.z = tag_pack_bf16(prologue1(tag_bf16_lo(rx[i].z), PRO, rs1.x, rt1.x), prologue1(tag_bf16_hi(rx[i].z), PRO, rs1.y, rt1.y));
+                    o.w = tag_pack_bf16(prologue1(tag_bf16_lo(rx[i].w), PRO, rs1.z, rt1.z), prologue1(tag_bf16_hi(rx[i].w), PRO, rs1.w, rt1.w));
+                }
+                if (!valid) o = (u32x4){0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(dst) = o;
+            } else {
+                const f32x4 rv = __builtin_bit_cast(f32x4, rx[i]);
+                f32x4 v;
+                v.x = prologue1(rv.x, PRO, rs.x, rt.x);
+                v.y = prologue1(rv.y, PRO, rs.y, rt.y);
+                v.z = prologue1(rv.z, PRO, rs.z, rt.z);
+                v.w = prologue1(rv.w, PRO, rs.w, rt.w);
+                if (!valid) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+                split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+                split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
+                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+                if (NSPL == 3) {
+                    *reinterpret_cast<u32x2*>(dst + 2 * G::XPL) = (u32x2){m0_, m1_};
+                    *reinterpret_cast<u32x2*>(dst + 4 * G::XPL) = (u32x2){l0_, l1_};
+                }
             }
         }
     };
@@ -461,29 +518,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const float* _
         const long ibase = (long)img * H * W;
         dok = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = (tid + 256 * i) >> 4;
+        for (int i = 0; i < DITEMS; ++i) {
+            const int k = (tid + 256 * i) >> QSH;
             const int h = h0 + k / CW, w = w0 + k % CW;
             const unsigned ok = (unsigned)(h < H);
             dok |= ok << i;
             const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rd[i] = *reinterpret_cast<const f32x4*>(dy + pix * Cout + cb);
+            rd[i] = *reinterpret_cast<const u32x4*>(dy + pix * Cout + cb);
         }
     };
     auto store_dy = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = (tid + 256 * i) >> 4;
-            f32x4 v = rd[i];
-            if (!((dok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            unsigned h0_, m0_, l0_, h1_, m1_, l1_;
-            split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
-            split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
+        for (int i = 0; i < DITEMS; ++i) {
+            const int k = (tid + 256 * i) >> QSH;
+            const bool valid = (dok >> i) & 1u;
             unsigned char* dst = Ys + buf * G::YBYTES + qoff * G::YPL + k * 64 + qbyte;
-            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
-            if (NSPL == 3) {
-                *reinterpret_cast<u32x2*>(dst + 2 * G::YPL) = (u32x2){m0_, m1_};
-                *reinterpret_cast<u32x2*>(dst + 4 * G::YPL) = (u32x2){l0_, l1_};
+            if constexpr (HS16) {
+                *reinterpret_cast<u32x4*>(dst) = valid ? rd[i] : (u32x4){0u, 0u, 0u, 0u};
+            } else {
+                f32x4 v = __builtin_bit_cast(f32x4, rd[i]);
+                if (!valid) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                unsigned h0_, m0_, l0_, h1_, m1_, l1_;
+                split_pack<NP == 1>(v.x, v.y, h0_, m0_, l0_);
+                split_pack<NP == 1>(v.z, v.w, h1_, m1_, l1_);
+                *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+                if (NSPL == 3) {
+                    *reinterpret_cast<u32x2*>(dst + 2 * G::YPL) = (u32x2){m0_, m1_};
+                    *reinterpret_cast<u32x2*>(dst + 4 * G::YPL) = (u32x2){l0_, l1_};
+                }
             }
         }
     };
@@ -659,8 +721,8 @@ static int x3_products(int requested) {
     return v;
 }
 
-template <int MB, int TW, int NP>
-void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, float* stats, int B,
+template <int MB, int TW, int NP, class TS = float>
+void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
                int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = X3Geom<TW>;
     constexpr int BN_ = MB == 4 ? 128 : 64;
@@ -670,11 +732,11 @@ void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const f
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, P, TW, NP>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, P, TW, NP, TS>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
+        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP, TS>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
                            B, H, W, Cin, Cout);                                                                     \
     }
     switch (pro) {
@@ -686,17 +748,17 @@ void launch_x3(const float* x, const u32x4* wp, int pro, const float* s, const f
 #undef LAUNCH_PRO
 }
 
-template <int MB, int NP>
-void launch_x3_w(const float* x, const u32x4* wp, int pro, const float* s, const float* t, float* y, float* stats, int B,
+template <int MB, int NP, class TS = float>
+void launch_x3_w(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
                  int H, int W, int Cin, int Cout, hipStream_t st) {
-    if (W == 8) launch_x3<MB, 8, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else if (W == 16) launch_x3<MB, 16, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else if (W == 32) launch_x3<MB, 32, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else launch_x3<MB, 64, NP>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    if (W == 8) launch_x3<MB, 8, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else if (W == 16) launch_x3<MB, 16, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else if (W == 32) launch_x3<MB, 32, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+    else launch_x3<MB, 64, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
 }
 
-template <int TW, int NP>
-void launch_wgrad_x3(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial, int B,
+template <int TW, int NP, class TS = float>
+void launch_wgrad_x3(const TS* x, int pro, const float* s, const float* t, const TS* dy, float* partial, int B,
                      int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
     using G = WX3Geom<TW>;
     const int grid = (Cin / 64) * (Cout / 64) * splits;
@@ -705,11 +767,11 @@ void launch_wgrad_x3(const float* x, int pro, const float* s, const float* t, co
     {                                                                                                                \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_x3_kernel<TW, P, NP>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_x3_kernel<TW, P, NP, TS>),        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<TW, P, NP>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
+        hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<TW, P, NP, TS>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
                            B, H, W, Cin, Cout, splits, cps);                                                         \
     }
     switch (pro) {
@@ -721,13 +783,13 @@ void launch_wgrad_x3(const float* x, int pro, const float* s, const float* t, co
 #undef LAUNCH_PRO
 }
 
-template <int NP>
-void launch_wgrad_x3_w(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial, int B,
+template <int NP, class TS = float>
+void launch_wgrad_x3_w(const TS* x, int pro, const float* s, const float* t, const TS* dy, float* partial, int B,
                        int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
-    if (W == 8) launch_wgrad_x3<8, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
-    else if (W == 16) launch_wgrad_x3<16, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
-    else if (W == 32) launch_wgrad_x3<32, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
-    else launch_wgrad_x3<64, NP>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    if (W == 8) launch_wgrad_x3<8, NP, TS>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else if (W == 16) launch_wgrad_x3<16, NP, TS>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else if (W == 32) launch_wgrad_x3<32, NP, TS>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
+    else launch_wgrad_x3<64, NP, TS>(x, pro, s, t, dy, partial, B, H, W, Cin, Cout, splits, cps, st);
 }
 
 }  // namespace
@@ -773,6 +835,26 @@ extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int pro
     return 0;
 }
 
+// bf16 activation storage (BASELINE configs[2]): x and y are bf16 tensors, weights the one-product (rounded) pack
+extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int prologue, const float* in_scale,
+                                           const float* in_shift, void* y, float* stats, int B, int H, int W, int Cin,
+                                           int Cout, void* stream) {
+    TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
+    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
+    TAG_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32));
+    TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    hipStream_t st = as_stream(stream);
+    const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
+    const bf16_t* xi = static_cast<const bf16_t*>(x);
+    bf16_t* yo = static_cast<bf16_t*>(y);
+    if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
+    else launch_x3_w<2, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t tag_conv3x3_wgrad_x3_ws_bytes(int B, int H, int W, int Cin, int Cout) {
     int cps;
     return (size_t)tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps) * 9 * Cin * Cout * sizeof(float);
@@ -795,6 +877,25 @@ extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* i
     if (np == 6) launch_wgrad_x3_w<6>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else if (np == 9) launch_wgrad_x3_w<9>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else launch_wgrad_x3_w<1>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+    TAG_LAUNCH_CHECK();
+    return tag_launch_wgrad_reduce(partial, sp, Cin, Cout, dw, st);
+}
+
+extern "C" int tag_conv3x3_wgrad_x3_bf16(const void* x, int prologue, const float* in_scale, const float* in_shift,
+                                         const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                         void* stream) {
+    TAG_CHECK_ARG(x && dy && dw && ws && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
+    TAG_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && prologue >= 0 && prologue <= 3);
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    const long M = (long)B * H * W;
+    TAG_CHECK_ARG(M < (1L << 31));
+    float* partial = static_cast<float*>(ws);
+    hipStream_t st = as_stream(stream);
+    int cps;
+    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps);
+    launch_wgrad_x3_w<1, bf16_t>(static_cast<const bf16_t*>(x), prologue, in_scale, in_shift, static_cast<const bf16_t*>(dy),
+                                 partial, B, H, W, Cin, Cout, sp, cps, st);
     TAG_LAUNCH_CHECK();
     return tag_launch_wgrad_reduce(partial, sp, Cin, Cout, dw, st);
 }

@@ -69,3 +69,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + i;
 }
+
+// ---- activation storage types: fp32 (exact path) or bf16 (BASELINE configs[2]: bf16 tensors, fp32 arithmetic) ----
+// bf16 values travel as raw 16-bit patterns; conversion to fp32 is a shift, rounding to bf16 is round-to-nearest-even.
+typedef unsigned short bf16_t;
+typedef unsigned tag_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned tag_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned tag_bf16_rne(float f) {           // -> bits in the LOW half
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned tag_pack_bf16(float lo, float hi) { return tag_bf16_rne(lo) | (tag_bf16_rne(hi) << 16); }
+__device__ __forceinline__ float tag_bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float tag_bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <class T> struct Act;
+template <> struct Act<float> {
+    static constexpr bool is_bf16 = false;
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct Act<bf16_t> {
+    static constexpr bool is_bf16 = true;
+    static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {       // 4 channels = one 8-byte load
+        const tag_u32x2 w = *reinterpret_cast<const tag_u32x2*>(p);
+        return (f32x4){tag_bf16_lo(w.x), tag_bf16_hi(w.x), tag_bf16_lo(w.y), tag_bf16_hi(w.y)};
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+        *reinterpret_cast<tag_u32x2*>(p) = (tag_u32x2){tag_pack_bf16(v.x, v.y), tag_pack_bf16(v.z, v.w)};
+    }
+    static __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+    static __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)tag_bf16_rne(v); }
+};

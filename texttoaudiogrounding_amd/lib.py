@@ -103,6 +103,17 @@ _SIGS = {
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),
+    "tag_conv3x3_c1_forward_stats_bf16": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_c1_backward_bf16": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_forward_x3_bf16": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_conv3x3_wgrad_x3_bf16": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "tag_bnact_pool_forward_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_float, c_uint64, P]),
+    "tag_bnrelu_pool_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                              c_float, c_uint64, c_int, P, P]),
+    "tag_bnrelu_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
+    "tag_mean_w_forward_bf16": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
+    "tag_mean_w_backward_bf16": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_sumsq_ws_bytes": (c_size_t, [c_long]),
     "tag_sumsq": (c_int, [P, c_long, P, P, P]),
     "tag_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P, c_float, c_float, P]),

@@ -140,6 +140,8 @@ def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     if training:
         st.mean = _empty(C, like=x2d)
         st.invstd = _empty(C, like=x2d)
+        if x2d.dtype != F32 and not (partials is not None and pre_op == 0):
+            raise RuntimeError("bf16 activations: BatchNorm batch statistics come from the producing conv kernel's epilogue")
         if partials is not None and pre_op == 0:
             ws = _ws(query("tag_bn_stats_from_partials_ws_bytes", partials[0], C), x2d)
             call("tag_bn_stats_from_partials", ptr(partials[1]), partials[0], C, ptr(gamma), ptr(beta), eps, momentum,
@@ -163,6 +165,21 @@ def bn_stats(x2d, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
 # "x9" = all 9 partial products; "bf16" = operands rounded to bf16, one product (BASELINE configs[2] arithmetic).
 CONV_MATH = os.environ.get("TAG_CONV_MATH", "fp32")
 _X3_PRODUCTS = {"x3": 6, "x9": 9, "bf16": 1}
+# Storage of the big activations of the conv stack (raw conv outputs, pooled block outputs and their gradients):
+# "fp32" (default) or "bf16" = BASELINE configs[2] proper -- bf16 tensors in HBM, fp32 accumulation / BatchNorm statistics /
+# GRU / heads / loss / master weights.  Only meaningful with CONV_MATH == "bf16" (the one-product bf16 MFMA kernels);
+# with any other conv arithmetic the setting is ignored.
+ACT_DTYPE = os.environ.get("TAG_ACT_DTYPE", "fp32")
+BF16 = torch.bfloat16
+
+
+def act_bf16() -> bool:
+    return CONV_MATH == "bf16" and ACT_DTYPE == "bf16"
+
+
+def _sfx(t) -> str:
+    """Entry-point suffix for an activation tensor: '' (fp32) or '_bf16'."""
+    return "_bf16" if t.dtype == BF16 else ""
 
 
 def _x3_ok(W, K, N):
@@ -211,7 +228,7 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     """(y, partials): y = conv(prologue(x)) and, when want_stats, the BatchNorm partial statistics of y that the kernel
     writes in its epilogue ((P, buffer), or None when this shape has no fused statistics) -> bn_stats(..., partials=...)."""
     B, H, W, Cin = x.shape
-    y = _empty(B, H, W, Cout, like=x)
+    y = _empty(B, H, W, Cout, like=x, dtype=x.dtype)
     x3 = wpack.dtype == torch.uint8
     part = None
     if want_stats and FUSE_BN_STATS:
@@ -219,7 +236,14 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
         if P > 0:
             part = (P, _empty(P * (3 * Cout + 1), like=x))
     sp = ptr(part[1]) if part else None
-    if x3:
+    if x.dtype == BF16:
+        if not (x3 and wpack.products == 1):
+            raise RuntimeError("bf16 activations need the one-product bf16 conv kernels (CONV_MATH='bf16') and an image width "
+                               "of 8/16/32/64")
+        with _timed(("conv3x3_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_forward_x3_bf16", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H,
+                 W, Cin, Cout)
+    elif x3:
         with _timed(("conv3x3_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
             call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H, W,
                  Cin, Cout, wpack.products)
@@ -266,6 +290,14 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     dw = out if out is not None else _empty(Cout, Cin, 3, 3, like=x)
+    if x.dtype == BF16:
+        if dy.dtype != BF16 or not (W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0):
+            raise RuntimeError("bf16 wgrad: both operands must be bf16, width 8/16/32/64, channels multiples of 64")
+        ws = _ws(query("tag_conv3x3_wgrad_x3_ws_bytes", B, H, W, Cin, Cout), x)
+        with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_wgrad_x3_bf16", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
+                 ptr(ws))
+        return dw
     if CONV_MATH in _X3_PRODUCTS and W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0:
         ws = _ws(query("tag_conv3x3_wgrad_x3_ws_bytes", B, H, W, Cin, Cout), x)
         with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
@@ -284,12 +316,20 @@ def conv3x3_c1(x, w, col_scale=None, col_shift=None):
     return conv3x3_c1_stats(x, w, col_scale, col_shift, want_stats=False)[0]
 
 
-def conv3x3_c1_stats(x, w, col_scale=None, col_shift=None, want_stats=True):
+def conv3x3_c1_stats(x, w, col_scale=None, col_shift=None, want_stats=True, out_dtype=F32):
     """(y, partials) of the Cin = 1 convolution; partials = (P, buffer) when the kernel wrote the BatchNorm statistics of
-    y itself (W == 64, Cout == 64), else None."""
+    y itself (W == 64, Cout == 64), else None.  out_dtype bf16: y stored as bf16 (statistics from the fp32 values)."""
     B, H, W = x.shape
     Cout = w.shape[0]
-    y = _empty(B, H, W, Cout, like=x)
+    y = _empty(B, H, W, Cout, like=x, dtype=out_dtype)
+    if out_dtype == BF16:
+        P = query("tag_conv3x3_c1_stats_rows", B, H, W, Cout)
+        if P <= 0:
+            raise RuntimeError("bf16 activations: the Cin = 1 convolution is implemented for 64 mel bins x 64 channels")
+        part = (P, _empty(P * (3 * Cout + 1), like=x)) if want_stats else None
+        call("tag_conv3x3_c1_forward_stats_bf16", ptr(x), ptr(col_scale), ptr(col_shift), ptr(w), ptr(y),
+             ptr(part[1]) if part else None, B, H, W, Cout)
+        return y, part
     P = query("tag_conv3x3_c1_stats_rows", B, H, W, Cout) if (want_stats and FUSE_BN_STATS) else 0
     if P > 0:
         part = (P, _empty(P * (3 * Cout + 1), like=x))
@@ -317,9 +357,11 @@ def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None, out=None):
         dw = out if out is not None else _empty(Cout, 1, 3, 3, like=x)
         dx = _empty(B, H, W, like=x)
         ws = _ws(query("tag_conv3x3_c1_backward_ws_bytes", B, H, W, Cout), x)
-        call("tag_conv3x3_c1_backward", ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(w), ptr(dw), ptr(dx), B, H,
-             W, Cout, ptr(ws))
+        call("tag_conv3x3_c1_backward" + _sfx(dy), ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(w), ptr(dw), ptr(dx),
+             B, H, W, Cout, ptr(ws))
         return dw, dx
+    if dy.dtype == BF16:
+        raise RuntimeError("bf16 activations: the Cin = 1 backward is implemented for 64 mel bins x 64 channels")
     return conv3x3_c1_wgrad(x, dy, col_scale, col_shift), conv3x3_c1_dgrad(dy, w)
 
 
@@ -332,19 +374,21 @@ def conv3x3_c1_dgrad(dy, w):
 
 def bnact_pool(y, st: Optional[BNStat], ph, pw, act=1, pool=0, drop_p=0.0, seed=0):
     B, H, W, C = y.shape
-    out = _empty(B, H // ph, W // pw, C, like=y)
-    call("tag_bnact_pool_forward", ptr(y), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(out), B,
+    out = _empty(B, H // ph, W // pw, C, like=y, dtype=y.dtype)
+    call("tag_bnact_pool_forward" + _sfx(y), ptr(y), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(out), B,
          H, W, C, ph, pw, act, pool, float(drop_p), seed)
     return out
 
 
 def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None):
     B, H, W, C = y.shape
-    dy = _empty(B, H, W, C, like=y)
+    if dout.dtype != y.dtype:
+        raise RuntimeError("bnrelu_pool_backward: y and dout must share their storage type")
+    dy = _empty(B, H, W, C, like=y, dtype=y.dtype)
     dg = dg_out if dg_out is not None else _empty(C, like=y)
     db = db_out if db_out is not None else _empty(C, like=y)
     ws = _ws(query("tag_bn_backward_ws_bytes", B * H * W, C), y)
-    call("tag_bnrelu_pool_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+    call("tag_bnrelu_pool_backward" + _sfx(y), ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, float(drop_p), seed, int(st.train), ptr(ws))
     return dy, dg, db
 
@@ -356,7 +400,9 @@ def bnrelu_backward(y, st: BNStat, gamma, da, inplace=True, dg_out=None, db_out=
     dg = dg_out if dg_out is not None else _empty(C, like=y)
     db = db_out if db_out is not None else _empty(C, like=y)
     ws = _ws(query("tag_bn_backward_ws_bytes", rows, C), y)
-    call("tag_bnrelu_backward", ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+    if da.dtype != y.dtype:
+        raise RuntimeError("bnrelu_backward: y and da must share their storage type")
+    call("tag_bnrelu_backward" + _sfx(y), ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(da), ptr(dy), ptr(dg), ptr(db), rows, C, int(st.train), ptr(ws))
     return dy, dg, db
 
@@ -599,7 +645,8 @@ class Cnn8RnnFunction(torch.autograd.Function):
         for i, (c1w, g1, b1, c2w, g2, b2) in enumerate(blocks):
             blk = getattr(mod, f"conv_block{i + 1}")
             if i == 0:
-                y1, part1 = conv3x3_c1_stats(lm, c1w, st0.scale, st0.shift, want_stats=bn_train)
+                y1, part1 = conv3x3_c1_stats(lm, c1w, st0.scale, st0.shift, want_stats=bn_train,
+                                             out_dtype=BF16 if act_bf16() else F32)
                 wf1 = wd1 = None
             else:
                 wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
@@ -618,7 +665,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
             x = xo
         Bx, Tp, Wp, C = x.shape
         xm = _empty(Bx * Tp, C, like=x)
-        call("tag_mean_w_forward", ptr(x), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(xm))
+        call("tag_mean_w_forward" + _sfx(x), ptr(x), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(xm))
         M = Bx * Tp
         fc = gemm(xm, fc_w, M, fc_w.shape[0], C, transB=True, bias=fc_b, act=1)
         y, gsave = gru_bidir_forward(fc, rnn, Bx, Tp, need_grad)
@@ -656,7 +703,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
         x_last = sv["x_last"]
         Bx, Tp, Wp, C = x_last.shape
         dx = torch.empty_like(x_last)
-        call("tag_mean_w_backward", ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
+        call("tag_mean_w_backward" + _sfx(dx), ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
         # ---- conv blocks, last to first ----
         lm, st0 = sv["lm"], sv["st0"]
         sw = _SideWgrad(dy.device)

@@ -122,6 +122,10 @@ def main():
                     help="time the variant the strong eg_config literally instantiates instead (cdur_w2vmean.yaml: CrnnEncoder "
                          "(256) + EmbeddingAgg(256) + match.ExpNegL2); NOT the contract's workload")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE configs[2] as a mode: bf16 conv arithmetic (fp32 accumulate) + bf16 storage of the conv "
+                         "stack's activations and gradients + bf16 all-reduce payload; fp32 BatchNorm statistics / GRU / heads "
+                         "/ loss / master weights.  The default (and the contract's `value`) is fp32")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
                          "(the contract's number); x3 = opt-in 3 x bf16 split on the bf16 MFMA (conv_x3.hip)")
@@ -134,6 +138,9 @@ def main():
     from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
     from texttoaudiogrounding_amd.runner import StrongRunner, init_distributed
 
+    if args.dtype == "bf16":
+        args.conv_math = "bf16"
+        ops.ACT_DTYPE = "bf16"
     ops.CONV_MATH = args.conv_math
     rank, world, local = init_distributed()
     if world != args.gpus:
@@ -152,7 +159,8 @@ def main():
     else:
         model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
                                            match.DotProduct(), 512)
-    runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(device))
+    runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(device),
+                          grad_comm_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     batch = synthetic_batch(args.batch, 320000, 1234 + rank, device)
 
     def sync():
@@ -216,10 +224,12 @@ def main():
         alt = {}
         desc = {"x3": "fp32 operands split exactly into 3 bf16 terms, 6 partial products on v_mfma_f32_32x32x16_bf16, f32 "
                       "accumulate (forward, dgrad and wgrad convs; same parity tolerances as fp32; opt-in TAG_CONV_MATH=x3)",
-                "bf16": "conv operands rounded to bf16, one product, f32 accumulate (BASELINE configs[2] arithmetic for the "
-                        "convs; everything else f32; TAG_CONV_MATH=bf16)"}
+                "bf16": "BASELINE configs[2] as a mode (python bench.py --dtype bf16): conv operands bf16, one product, f32 "
+                        "accumulate; raw conv outputs, pooled activations and their gradients STORED as bf16; BatchNorm "
+                        "statistics, GRU, heads, loss, Adam and master weights f32"}
         for mode in ("x3", "bf16"):
             ops.CONV_MATH = mode
+            ops.ACT_DTYPE = "bf16" if mode == "bf16" else "fp32"
             runner.train_step(dict(batch))
             sync()
             ta = time.perf_counter()
@@ -234,25 +244,36 @@ def main():
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
         ops.CONV_MATH = "fp32"
+        ops.ACT_DTYPE = "fp32"
     dom = max(fam, key=lambda k: fam[k]["flop"]) if fam else None
     roof = None
     if dom:
         ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
         iso = fam_iso[dom]["flop"] / (fam_iso[dom]["ms"] * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_kernel.json")
-        if os.path.exists(tpath):      # PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) are collected offline
+        # HBM bytes per launch of the dominant family: PMC counters cannot be collected from inside this process, so the
+        # figure is read from the committed profile of the SAME command (tools/collect_profiles.sh: two separate --pmc passes,
+        # FETCH_SIZE x2 + WRITE_SIZE) and labelled with where and when it was collected -- it is offline data.
+        traffic, traffic_src = None, None
+        tname = f"r02_pmc_hbm_traffic_{'bf16' if args.dtype == 'bf16' else 'fp32'}.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath) and args.conv_math in ("fp32", "bf16"):
             tj = json.load(open(tpath))
+            meta = tj.pop("_meta", {})
             rows = [v for k, v in tj.items() if k.startswith(dom)]
             n = sum(v["launches_in_run"] for v in rows)
             if n:
                 traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
                                     for v in rows) / n, 3)
+                traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
+                               "measured_in_this_run": False,
+                               "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
+                               "algorithmic_lower_bound_GB_per_step": round(0.164 * args.batch, 2)}
         # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
         nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(args.conv_math, 6.0)
         peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / nprod, 1)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC)",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC, offline profile)",
+                "traffic_source": traffic_src,
                 "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
                 "launches_per_step": fam[dom]["launches"] // args.steps,
                 "streams": "overlapped (wgrad on a side stream)" if overlap else "single",
@@ -265,8 +286,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
-               "dtype": {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
-                   args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)"),
+               "dtype": ("bf16 (conv arithmetic + activation storage + all-reduce payload; f32 accumulate, statistics, GRU, "
+                         "heads, master weights)" if args.dtype == "bf16" else
+                         {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
+                             args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)")),
                "data": "synthetic",
                "config": {"workload": "strong eg_config as written (cdur_w2vmean.yaml): CrnnEncoder(256) + EmbeddingAgg(256) + "
                                       "match.ExpNegL2, fwd+bwd+clip+Adam" if args.crnn else ("configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + "

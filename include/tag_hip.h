@@ -394,6 +394,33 @@ int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, co
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * BASELINE configs[3], the head named in the config text: match.CrossAttention (models/match.py:63-88) =
+ * nn.MultiheadAttention(embed_dim E, heads H, dropout p, batch_first, kdim = vdim = kvdim) of every audio frame over the
+ * phrase tokens -> audio + dropout(out) -> LayerNorm(E) -> Linear(E,1) -> sigmoid.  The four projections are tag_gemm
+ * calls; these entry points are the attention core and the fused residual/LayerNorm/head, forward and backward.
+ *   q (B,T,E) projected frames; k, v (B,L,E) projected tokens (L <= 32); klen (B) int64 valid tokens (key_padding_mask);
+ *   attn (B,T,H,L) softmax weights BEFORE dropout (saved for backward); ctx (B,T,E).  head_dim = E/H in {16, 32} or a
+ *   multiple of 64, E <= 1024.  drop_p / seed: dropout on the attention weights (train), counter-based like A2.
+ * backward: dq (B,T,E), dk, dv (B,L,E) (sums over frames folded from per-tile partials in a fixed order).
+ * tag_resln_head_*: x = audio, r = out_proj(ctx); sim (rows) = sigmoid(LayerNorm(x + dropout(r)) . w + b); mu / rstd (rows)
+ * saved.  backward: dx, dr (rows,E) and the per-row terms gw = d logit * n, gg = dn * xhat, gb = dn, ds = d logit, whose
+ * column sums (tag_colsum) are the gradients of linear.weight, norm.weight, norm.bias and linear.bias.
+ * ------------------------------------------------------------------------------------------- */
+int tag_mha_cross_forward(const float* q, const float* k, const float* v, const long* klen, float* attn, float* ctx,
+                          int B, int T, int L, int E, int H, float drop_p, uint64_t seed, void* stream);
+size_t tag_mha_cross_backward_ws_bytes(int B, int T, int L, int E);
+int tag_mha_cross_backward(const float* q, const float* k, const float* v, const float* attn, const float* dctx,
+                           const long* klen, float* dq, float* dk, float* dv, int B, int T, int L, int E, int H,
+                           float drop_p, uint64_t seed, void* ws, void* stream);
+int tag_resln_head_forward(const float* x, const float* r, const float* gamma, const float* beta, const float* w,
+                           const float* bias, float* sim, float* mu, float* rstd, long rows, int E, float eps,
+                           float drop_p, uint64_t seed, void* stream);
+int tag_resln_head_backward(const float* x, const float* r, const float* gamma, const float* beta, const float* w,
+                            const float* mu, const float* rstd, const float* sim, const float* dsim, float* dx, float* dr,
+                            float* gw, float* gg, float* gb, float* ds, long rows, int E, float drop_p, uint64_t seed,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BASELINE configs[2]: bf16 ACTIVATION STORAGE.  The big tensors of the conv stack -- raw conv outputs, pooled block
  * outputs and the gradients of both -- are bf16 in HBM (void* here: raw 16-bit patterns, channels-last as before);
  * every product is bf16 x bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm statistics (from the fp32

@@ -160,6 +160,40 @@ def test_real_runner_host_logic_two_ranks(tmp_path):
     assert err < 1e-5, err
 
 
+def _bf16_wire_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from texttoaudiogrounding_amd.runner import GradBuckets
+        model = _toy()
+        flat = FlatParams(model)
+        bk = GradBuckets(flat, bucket_bytes=256, comm_dtype=torch.bfloat16)       # several small buckets
+        g = torch.Generator().manual_seed(7 + rank)
+        local = torch.randn(flat.numel, generator=g)
+        flat.grad.copy_(local)
+        bk.reset()
+        bk.ready(flat.params)
+        bk.flush()
+        bk.finish()
+        both = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        want = (both[0].bfloat16() + both[1].bfloat16()).float()                 # bf16 payload, bf16 sum, widened back
+        assert flat.grad.dtype == torch.float32 and torch.equal(flat.grad, want)
+        exact = both[0] + both[1]
+        assert (flat.grad - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()
+        if rank == 0:
+            open(out, "w").write(str(len(bk.bounds)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_allreduce_payload(tmp_path):
+    """BASELINE configs[2]: the gradient exchange carries bf16 (half the bytes on xGMI); the flat gradient stays fp32."""
+    out = str(tmp_path / "n")
+    mp.spawn(_bf16_wire_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert int(open(out).read()) >= 2
+
+
 def test_flat_params_rehoming():
     model = _toy()
     before = [p.detach().clone() for p in model.parameters()]

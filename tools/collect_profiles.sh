@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile collection on the GPU box (run through gpurun from the repo root):  bash tools/collect_profiles.sh r02
+# Kernel trace of the default bench command, an isolated (single-stream) trace, and the two separate PMC passes for HBM
+# traffic -- for the fp32 contract workload and for --dtype bf16.  Summaries land in gpurun_out/prof_<round>/.
+set -u
+R=${1:-r02}
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt"
+for mode in fp32 bf16; do
+  extra=""; [ $mode = bf16 ] && extra="--dtype bf16"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$mode -o k -- $BENCH $extra > $OUT/kt_$mode.log 2>&1
+  python tools/kstats.py $OUT/kt_$mode/k_kernel_stats.csv 12 80 > $OUT/${R}_bench_b64_${mode}_kernel_summary.txt
+  cp $OUT/kt_$mode/k_kernel_stats.csv $OUT/${R}_bench_b64_${mode}_kernel_stats.csv
+  grep '^{"metric"' $OUT/kt_$mode.log > $OUT/${R}_bench_b64_${mode}_under_rocprof.json
+  TAG_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iso_$mode -o k -- $BENCH $extra > $OUT/iso_$mode.log 2>&1
+  python tools/kstats.py $OUT/iso_$mode/k_kernel_stats.csv 7 80 > $OUT/${R}_bench_b64_${mode}_isolated_kernel_summary.txt
+  for c in FETCH_SIZE WRITE_SIZE; do
+    TAG_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${mode}_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt $extra > $OUT/pmc_${mode}_$c.log 2>&1
+  done
+  python tools/pmc_traffic.py $OUT/pmc_${mode}_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_${mode}_WRITE_SIZE/p_counter_collection.csv \
+      $OUT/${R}_pmc_hbm_traffic_${mode}.json 3 "bench.py --steps 2 --warmup 1 $extra, TAG_WGRAD_STREAM=0, batch 64" > $OUT/${R}_pmc_hbm_traffic_${mode}.txt
+  rm -f $OUT/kt_$mode/k_kernel_trace.csv $OUT/iso_$mode/k_kernel_trace.csv
+  rm -rf $OUT/pmc_${mode}_FETCH_SIZE $OUT/pmc_${mode}_WRITE_SIZE
+done
+ls -la $OUT

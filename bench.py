@@ -108,6 +108,18 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def workload_name(args):
+    tail = ", fwd+bwd+clip+Adam, dropout on, train-mode BN"
+    if args.crnn:
+        return ("strong eg_config as written (cdur_w2vmean.yaml): CrnnEncoder(256) + EmbeddingAgg(256) + match.ExpNegL2, "
+                "fwd+bwd+clip+Adam")
+    if args.cross_attention:
+        return "configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + match.CrossAttention(512, 8 heads, p 0.1)" + tail
+    if args.cross_encoder:
+        return "configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + match.DotProduct(token)" + tail
+    return "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct" + tail
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +130,10 @@ def main():
     ap.add_argument("--cross-encoder", action="store_true",
                     help="time BASELINE configs[3] instead: the same biencoder with CrossAttentionGating(512) and the "
                          "token-level DotProduct (NOT the contract's workload; for DESIGN.md section 10)")
+    ap.add_argument("--cross-attention", action="store_true",
+                    help="time BASELINE configs[3] with the head its text names: the same biencoder scored by "
+                         "match.CrossAttention(512, 8 heads, dropout 0.1) (nn.MultiheadAttention of every frame over the "
+                         "phrase tokens + residual + LayerNorm + Linear(512,1)); NOT the contract's workload")
     ap.add_argument("--crnn", action="store_true",
                     help="time the variant the strong eg_config literally instantiates instead (cdur_w2vmean.yaml: CrnnEncoder "
                          "(256) + EmbeddingAgg(256) + match.ExpNegL2); NOT the contract's workload")
@@ -151,6 +167,9 @@ def main():
     if args.crnn:
         model = audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(32000, 256), text_encoder.EmbeddingAgg(5221, 256),
                                            match.ExpNegL2(), 256)
+    elif args.cross_attention:
+        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                           match.CrossAttention(512, 8, 0.1), 512)
     elif args.cross_encoder:
         from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
         model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
@@ -291,12 +310,7 @@ def main():
                          {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
                              args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)")),
                "data": "synthetic",
-               "config": {"workload": "strong eg_config as written (cdur_w2vmean.yaml): CrnnEncoder(256) + EmbeddingAgg(256) + "
-                                      "match.ExpNegL2, fwd+bwd+clip+Adam" if args.crnn else ("configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + "
-                                       "match.DotProduct(token), fwd+bwd+clip+Adam, dropout on, train-mode BN"
-                                       if args.cross_encoder else
-                                       "configs[1]: biencoder Cnn8Rnn + EmbeddingAgg(512,mean) + match.DotProduct, "
-                                       "fwd+bwd+clip+Adam, dropout on, train-mode BN"), "batch_per_gpu": args.batch,
+               "config": {"workload": workload_name(args), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math},
                "loss": round(runner.loss_value(loss), 6),

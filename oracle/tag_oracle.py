@@ -653,6 +653,39 @@ def match_dot_product_token(audio, text, scale=True):
     return torch.sigmoid(score).clamp(1e-7, 1.0)
 
 
+def match_cross_attention(st, audio, token, text_len, num_heads, prefix="match_fn.", attn_keep=None, res_keep=None,
+                          p_drop=0.0):
+    """match.CrossAttention (models/match.py:63-88): nn.MultiheadAttention(E, H, p, batch_first=True, kdim = vdim = kvdim)
+    restated -- q/k/v projections (one in_proj_weight (3E,E) when kvdim == E, else q/k/v_proj_weight) + in_proj_bias,
+    per-head softmax(q k^T / sqrt(E/H)) with -inf on tokens >= text_len, dropout on the weights, out_proj; then
+    audio + dropout(out), LayerNorm (eps 1e-5), Linear(E,1), sigmoid.  attn_keep (B,T,H,L) / res_keep (B,T,E): keep masks
+    replayed from the HIP generator for a dropout-on comparison (None = no dropout)."""
+    B, T, E = audio.shape
+    L = token.shape[1]
+    H, dh = num_heads, E // num_heads
+    if prefix + "attn.in_proj_weight" in st:
+        w = st[prefix + "attn.in_proj_weight"]
+        wq, wk, wv = w[:E], w[E:2 * E], w[2 * E:]
+    else:
+        wq, wk, wv = (st[prefix + f"attn.{n}_proj_weight"] for n in "qkv")
+    b = st[prefix + "attn.in_proj_bias"]
+    q = F.linear(audio, wq, b[:E]).view(B, T, H, dh).transpose(1, 2)            # (B,H,T,dh)
+    k = F.linear(token, wk, b[E:2 * E]).view(B, L, H, dh).transpose(1, 2)
+    v = F.linear(token, wv, b[2 * E:]).view(B, L, H, dh).transpose(1, 2)
+    score = q @ k.transpose(-1, -2) / math.sqrt(dh)                              # (B,H,T,L)
+    pad = ~length_mask(torch.as_tensor(text_len), L).to(torch.bool)             # (B,L) True = padding
+    score = score.masked_fill(pad[:, None, None, :], float("-inf"))
+    attn = torch.softmax(score, dim=-1)
+    if attn_keep is not None:
+        attn = attn * attn_keep.permute(0, 2, 1, 3).to(attn.dtype) / (1.0 - p_drop)
+    ctx = (attn @ v).transpose(1, 2).reshape(B, T, E)
+    out = F.linear(ctx, st[prefix + "attn.out_proj.weight"], st[prefix + "attn.out_proj.bias"])
+    if res_keep is not None:
+        out = out * res_keep.to(out.dtype) / (1.0 - p_drop)
+    z = F.layer_norm(audio + out, (E,), st[prefix + "norm.weight"], st[prefix + "norm.bias"], 1e-5)
+    return torch.sigmoid(F.linear(z, st[prefix + "linear.weight"], st[prefix + "linear.bias"])).squeeze(-1)
+
+
 def init_cross_state(seed, dim=512, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     k = 1.0 / math.sqrt(2 * dim)

@@ -1,4 +1,4 @@
-"""Frame x phrase similarity heads (mirror of models/match.py:10-60 in the reference)."""
+"""Frame x phrase similarity heads (mirror of models/match.py:10-88 in the reference)."""
 import torch.nn as nn
 
 from .. import ops
@@ -38,3 +38,32 @@ class DotProduct(nn.Module):
             return ops.RowDotFunction.apply(input_dict["audio_emb"], text, self.scale)
         return ops.MatchFunction.apply(input_dict["audio_emb"], _seq_text(input_dict, self.text_level), 0,
                                        self.l2norm, self.scale)
+
+
+class CrossAttention(nn.Module):
+    """Mirror of models/match.py:63-88: same constructor, same sub-module / parameter names (``attn`` is an
+    nn.MultiheadAttention used as the parameter container, ``norm``, ``linear``) so reference checkpoints load; the forward
+    runs in libtag_hip.so (projection GEMMs on the MFMA + csrc/mha.hip)."""
+
+    def __init__(self, embed_dim, num_heads, dropout, kvdim=None) -> None:
+        super().__init__()
+        self.attn = nn.MultiheadAttention(embed_dim, num_heads, dropout, batch_first=True, kdim=kvdim, vdim=kvdim)
+        self.dropout = nn.Dropout(dropout)
+        self.norm = nn.LayerNorm(embed_dim)
+        self.linear = nn.Linear(embed_dim, 1)
+        self.embed_dim, self.num_heads, self.p = embed_dim, num_heads, dropout
+
+    def forward(self, input_dict):
+        audio = input_dict["audio_emb"]
+        text = input_dict["text_emb"]["token_emb"]
+        m, E = self.attn, self.embed_dim
+        if m.in_proj_weight is not None:
+            # kvdim == embed_dim: nn.MultiheadAttention holds ONE in_proj_weight (3E, E); its three row blocks enter the HIP
+            # node as (differentiable) views and autograd stitches their gradients back into in_proj_weight.grad
+            wq, wk, wv = m.in_proj_weight[:E], m.in_proj_weight[E:2 * E], m.in_proj_weight[2 * E:]
+        else:
+            wq, wk, wv = m.q_proj_weight, m.k_proj_weight, m.v_proj_weight
+        return ops.CrossAttentionHeadFunction.apply(audio, text, input_dict["text_len"], self.num_heads, self.p,
+                                                    self.training, wq, wk, wv, m.in_proj_bias, m.out_proj.weight,
+                                                    m.out_proj.bias, self.norm.weight, self.norm.bias, self.linear.weight,
+                                                    self.linear.bias)

@@ -1112,6 +1112,80 @@ class CrossEncoderFunction(torch.autograd.Function):
         return (da, dkv, None, None, *g)
 
 
+class CrossAttentionHeadFunction(torch.autograd.Function):
+    """match.CrossAttention (models/match.py:63-88): nn.MultiheadAttention(E, H, p, batch_first, kdim = vdim = kvdim) of every
+    audio frame over the phrase tokens, ``audio + dropout(out)``, LayerNorm, Linear(E,1), sigmoid -> (B,T).
+    params = (wq (E,E), wk (E,Dk), wv (E,Dk), in_proj_bias (3E), out_proj.weight, out_proj.bias, norm.weight, norm.bias,
+    linear.weight (1,E), linear.bias (1)); wq/wk/wv may be row blocks of one in_proj_weight (kvdim = E)."""
+
+    @staticmethod
+    def forward(ctx, audio, token, text_len, num_heads, drop_p, training, *params):
+        a, t = _chk(audio, "audio_emb"), _chk(token, "token_emb")
+        B, T, E = a.shape
+        L, Dk = t.shape[1], t.shape[2]
+        sinks = _sinks(params)
+        wq, wk, wv, b_in, wo, bo, g, be, wl, bl = (_chk(x.detach(), "parameter") for x in params)
+        if wq.shape != (E, E) or wk.shape != (E, Dk) or wv.shape != (E, Dk) or wo.shape != (E, E) or E % num_heads:
+            raise RuntimeError("CrossAttention: inconsistent dimensions")
+        kl = torch.as_tensor(text_len).long().to(a.device).contiguous()
+        M, ML = B * T, B * L
+        p = float(drop_p) if training else 0.0
+        seeds = [new_seed(), new_seed()] if p > 0 else [0, 0]
+        q = gemm(a, wq, M, E, E, transB=True, bias=b_in[:E])
+        k = gemm(t, wk, ML, E, Dk, transB=True, bias=b_in[E:2 * E])
+        v = gemm(t, wv, ML, E, Dk, transB=True, bias=b_in[2 * E:])
+        attn = _empty(B, T, num_heads, L, like=a)
+        cx = _empty(B, T, E, like=a)
+        call("tag_mha_cross_forward", ptr(q), ptr(k), ptr(v), ptr(kl), ptr(attn), ptr(cx), B, T, L, E, num_heads, p, seeds[0])
+        r = gemm(cx, wo, M, E, E, transB=True, bias=bo)
+        sim = _empty(B, T, like=a)
+        mu, rstd = _empty(M, like=a), _empty(M, like=a)
+        call("tag_resln_head_forward", ptr(a), ptr(r), ptr(g), ptr(be), ptr(wl), ptr(bl), ptr(sim), ptr(mu), ptr(rstd), M, E,
+             1e-5, p, seeds[1])
+        ctx.save_for_backward(a, t, q, k, v, attn, cx, r, sim, mu, rstd, kl, wq, wk, wv, wo, g, be, wl)
+        ctx.cfg = (num_heads, p, seeds)
+        ctx.sinks = sinks
+        ctx.params = list(params) if DIRECT_GRADS else None
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t, q, k, v, attn, cx, r, sim, mu, rstd, kl, wq, wk, wv, wo, g, be, wl = ctx.saved_tensors
+        H, p, seeds = ctx.cfg
+        B, T, E = a.shape
+        L, Dk = t.shape[1], t.shape[2]
+        M, ML = B * T, B * L
+        dsim = _chk(dsim, "grad")
+        da, dr = torch.empty_like(a), torch.empty_like(a)
+        gw, gg, gb = _empty(M, E, like=a), _empty(M, E, like=a), _empty(M, E, like=a)
+        ds = _empty(M, like=a)
+        call("tag_resln_head_backward", ptr(a), ptr(r), ptr(g), ptr(be), ptr(wl), ptr(mu), ptr(rstd), ptr(sim), ptr(dsim),
+             ptr(da), ptr(dr), ptr(gw), ptr(gg), ptr(gb), ptr(ds), M, E, p, seeds[1])
+        d_wl = colsum(gw, M, E).view(1, E)
+        d_g, d_be = colsum(gg, M, E), colsum(gb, M, E)
+        d_bl = colsum(ds, M, 1)
+        # out_proj
+        d_wo = gemm(dr, cx, E, E, M, transA=True, lda=E)
+        d_bo = colsum(dr, M, E)
+        dcx = gemm(dr, wo, M, E, E)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = _ws(query("tag_mha_cross_backward_ws_bytes", B, T, L, E), a)
+        call("tag_mha_cross_backward", ptr(q), ptr(k), ptr(v), ptr(attn), ptr(dcx), ptr(kl), ptr(dq), ptr(dk), ptr(dv), B, T, L,
+             E, H, p, seeds[0], ptr(ws))
+        d_wq = gemm(dq, a, E, E, M, transA=True, lda=E)
+        d_wk = gemm(dk, t, E, Dk, ML, transA=True, lda=E)
+        d_wv = gemm(dv, t, E, Dk, ML, transA=True, lda=E)
+        d_bin = torch.cat([colsum(dq, M, E), colsum(dk, ML, E), colsum(dv, ML, E)])
+        gemm(dq, wq, M, E, E, out=da, accumulate=True)                     # d audio: residual branch + query projection
+        dt = gemm(dk, wk, ML, Dk, E)
+        gemm(dv, wv, ML, Dk, E, out=dt, accumulate=True)
+        grads = [d_wq, d_wk, d_wv, d_bin, d_wo, d_bo, d_g, d_be, d_wl, d_bl]
+        for i in range(len(grads)):
+            _deliver(grads, ctx.sinks, i, grads[i])
+        _ready(ctx.params)
+        return (da, dt.view(B, L, Dk), None, None, None, None, *grads)
+
+
 class RowDotFunction(torch.autograd.Function):
     """match.DotProduct with text_level='token' after a cross-encoder: one text vector per frame (models/match.py:43-60)."""
 

@@ -394,6 +394,19 @@ int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, co
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * General similarity pooling: models/utils.py:22-105 (mean/max/linear_softmax/exp_softmax _with_lens), all twelve reducers
+ * of models/sim_pooling.py:6-204 and the pooling modes of MultiTextBiEncoder (models/audio_text_model.py:205-215).
+ * sim (R,T,N) fp32, T frames, N tokens/phrases innermost; alen indexed by r / a_div, tlen by r % t_mod.
+ * amode (frames < alen): 0 mean, 1 max (first maximum), 2 linear softmax sum f^2 / sum f, 3 exp softmax sum softmax(f) f.
+ * tmode (tokens < tlen): 0 mean, 1 sum, 2 max (first), 3 mean + sum; -1 = none: out is (R,N), else (R).
+ * backward writes the whole dsim (R,T,N) (zeros outside the valid region).
+ * ------------------------------------------------------------------------------------------- */
+int tag_sim_pool_forward(const float* sim, const long* alen, const long* tlen /* nullable iff tmode < 0 */, float* out,
+                         long R, int T, int N, int a_div, int t_mod, int amode, int tmode, void* stream);
+int tag_sim_pool_backward(const float* sim, const long* alen, const long* tlen, const float* dout, float* dsim, long R,
+                          int T, int N, int a_div, int t_mod, int amode, int tmode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BASELINE configs[3], the head named in the config text: match.CrossAttention (models/match.py:63-88) =
  * nn.MultiheadAttention(embed_dim E, heads H, dropout p, batch_first, kdim = vdim = kvdim) of every audio frame over the
  * phrase tokens -> audio + dropout(out) -> LayerNorm(E) -> Linear(E,1) -> sigmoid.  The four projections are tag_gemm

@@ -711,6 +711,62 @@ def linear_softmax_with_lens(features, lens):
     return (features * features * mask).sum(1) / (features * mask).sum(1)
 
 
+def sum_with_lens(features, lens):
+    """models/utils.py:33-46."""
+    mask = length_mask(torch.as_tensor(lens), features.size(1)).to(features.dtype)
+    while mask.ndim < features.ndim:
+        mask = mask.unsqueeze(-1)
+    return (features * mask).sum(1)
+
+
+def mean_with_lens(features, lens):
+    """models/utils.py:49-58."""
+    s = sum_with_lens(features, lens)
+    lens = torch.as_tensor(lens)
+    while lens.ndim < s.ndim:
+        lens = lens.unsqueeze(1)
+    return s / lens.to(features.dtype)
+
+
+def max_with_lens(features, lens):
+    """models/utils.py:61-72 (positions >= len are -inf; torch.max picks the first maximum)."""
+    mask = length_mask(torch.as_tensor(lens), features.size(1)).to(torch.bool)
+    f = features.clone()
+    f[~mask] = float("-inf")
+    return f.max(1)[0]
+
+
+def exp_softmax_with_lens(features, lens):
+    """models/utils.py:79-84."""
+    normed = features - features.max(1, keepdim=True)[0]
+    e = torch.exp(normed)
+    weight = e / sum_with_lens(e, lens).unsqueeze(1)
+    return sum_with_lens(weight * features, lens)
+
+
+SEQ_POOL = {"mean": mean_with_lens, "max": max_with_lens, "linear_softmax": linear_softmax_with_lens,
+            "exp_softmax": exp_softmax_with_lens}
+
+
+def sim_pooling(sim, audio_len, text_len, audio_mode, text_mode):
+    """The reducers of models/sim_pooling.py:6-189 on a (B,B,T,N) matrix: <audio_mode>_with_lens over the frames, then
+    mean / sum / max / mean+sum over the tokens."""
+    B, _, T, N = sim.shape
+    x = sim.reshape(B * B, T, N)
+    al = torch.as_tensor(audio_len).unsqueeze(1).expand(B, B).reshape(-1)
+    x = SEQ_POOL[audio_mode](x, al)                               # (B*B, N)
+    tl = torch.as_tensor(text_len).repeat(B)
+    if text_mode == "mean":
+        x = mean_with_lens(x, tl)
+    elif text_mode == "sum":
+        x = sum_with_lens(x, tl)
+    elif text_mode == "max":
+        x = max_with_lens(x, tl)
+    else:
+        x = sum_with_lens(x, tl) + mean_with_lens(x, tl)
+    return x.reshape(B, B)
+
+
 def multitext_head(audio_emb, seq_emb, length, n_text, scale=True):
     """audio (B,T,D), seq_emb (B*N,D): expand the audio per phrase, DotProduct(seq), reshape to (B,T,N), pool."""
     B, T, D = audio_emb.shape

@@ -488,6 +488,112 @@ __global__ __launch_bounds__(256) void meanmean_pool_bwd_kernel(const float* __r
         dsim[i] = (t < al && n < tl) ? dout[r] / ((float)al * (float)tl) : 0.0f;
     }
 }
+// ------------------------------------------------------------------------------------------------------------------
+// General similarity pooling (models/utils.py:22-105 *_with_lens; models/sim_pooling.py:6-204, all twelve reducers;
+// MultiTextBiEncoder's pooling modes, models/audio_text_model.py:205-215): sim (R, T, N) -- R rows (clip, or (clip,
+// caption) pairs), T frames, N tokens/phrases innermost.  Audio-axis reducer over the valid frames t < alen[r / a_div]:
+//   0 mean   1 max (first maximum, as torch.max)   2 linear softmax sum f^2 / sum f   3 exp softmax sum softmax(f) f
+// then (tmode >= 0) a text-axis reducer over the valid tokens n < tlen[r % t_mod]:
+//   0 mean   1 sum   2 max (first)   3 mean + sum         (tmode = -1: no text reduction, out is (R, N))
+// One wave per row, lanes over the frames; the backward recomputes the reducers and writes the whole dsim row
+// (zeros outside the valid region): no atomics.
+// ------------------------------------------------------------------------------------------------------------------
+struct SeqPool { float out, s1; int arg; };     // s1: denominator (linear: sum f; exp: sum exp(f - max)); arg: first max
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+__device__ __forceinline__ SeqPool seq_pool(const float* f, int stride, int len, int mode, int lane) {
+    SeqPool r{0.0f, 0.0f, 0};
+    if (mode == 0) {
+        float s = 0.0f;
+        for (int t = lane; t < len; t += 64) s += f[(long)t * stride];
+        r.out = wave_sum(s) / (float)len;
+    } else if (mode == 2) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int t = lane; t < len; t += 64) { const float v = f[(long)t * stride]; s1 += v; s2 = fmaf(v, v, s2); }
+        r.s1 = wave_sum(s1);
+        r.out = wave_sum(s2) / r.s1;
+    } else {
+        float m = -3.0e38f; int am = 0x7fffffff;
+        for (int t = lane; t < len; t += 64) { const float v = f[(long)t * stride]; if (v > m) { m = v; am = t; } }
+        wave_argmax(m, am);
+        r.arg = am;
+        r.out = m;
+        if (mode == 3) {
+            float e = 0.0f, ef = 0.0f;
+            for (int t = lane; t < len; t += 64) { const float v = f[(long)t * stride]; const float x = expf(v - m); e += x; ef = fmaf(x, v, ef); }
+            r.s1 = wave_sum(e);
+            r.out = wave_sum(ef) / r.s1;
+            r.arg = __float_as_int(m);               // the stabiliser, for the backward
+        }
+    }
+    return r;
+}
+// d out / d f_t
+__device__ __forceinline__ float seq_pool_grad(const SeqPool& r, float v, int t, int len, int mode) {
+    if (mode == 0) return 1.0f / (float)len;
+    if (mode == 1) return t == r.arg ? 1.0f : 0.0f;
+    if (mode == 2) return (2.0f * v - r.out) / r.s1;
+    return expf(v - __int_as_float(r.arg)) / r.s1 * (1.0f + v - r.out);
+}
+__global__ __launch_bounds__(256) void sim_pool_fwd_kernel(const float* __restrict__ sim, const long* __restrict__ alen,
+                                                           const long* __restrict__ tlen, float* __restrict__ out, long R,
+                                                           int T, int N, int a_div, int t_mod, int amode, int tmode) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int al = (int)min((long)T, alen[r / a_div]);
+    const int tl = tmode >= 0 ? (int)min((long)N, tlen[r % t_mod]) : N;
+    const float* base = sim + r * T * N;
+    float acc = 0.0f, best = -3.0e38f;
+    for (int n = 0; n < tl; ++n) {
+        const float p = seq_pool(base + n, N, al, amode, lane).out;
+        if (tmode < 0) { if (lane == 0) out[r * N + n] = p; }
+        else if (tmode == 2) best = fmaxf(best, p);
+        else acc += p;
+    }
+    if (tmode >= 0 && lane == 0)
+        out[r] = tmode == 0 ? acc / (float)tl : tmode == 1 ? acc : tmode == 2 ? best : acc + acc / (float)tl;
+}
+__global__ __launch_bounds__(256) void sim_pool_bwd_kernel(const float* __restrict__ sim, const long* __restrict__ alen,
+                                                           const long* __restrict__ tlen, const float* __restrict__ dout,
+                                                           float* __restrict__ dsim, long R, int T, int N, int a_div, int t_mod,
+                                                           int amode, int tmode) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int al = (int)min((long)T, alen[r / a_div]);
+    const int tl = tmode >= 0 ? (int)min((long)N, tlen[r % t_mod]) : N;
+    const float* base = sim + r * T * N;
+    float* dbase = dsim + r * T * N;
+    int argn = 0;
+    if (tmode == 2) {                               // first maximum over the tokens
+        float best = -3.0e38f;
+        for (int n = 0; n < tl; ++n) { const float p = seq_pool(base + n, N, al, amode, lane).out; if (p > best) { best = p; argn = n; } }
+    }
+    for (int n = 0; n < N; ++n) {
+        float dp = 0.0f;
+        if (n < tl) {
+            if (tmode < 0) dp = dout[r * N + n];
+            else if (tmode == 0) dp = dout[r] / (float)tl;
+            else if (tmode == 1) dp = dout[r];
+            else if (tmode == 2) dp = n == argn ? dout[r] : 0.0f;
+            else dp = dout[r] * (1.0f + 1.0f / (float)tl);
+        }
+        SeqPool sp{0.0f, 0.0f, 0};
+        if (n < tl) sp = seq_pool(base + n, N, al, amode, lane);
+        for (int t = lane; t < T; t += 64) {
+            float g = 0.0f;
+            if (n < tl && t < al) g = dp * seq_pool_grad(sp, base[(long)t * N + n], t, al, amode);
+            dbase[(long)t * N + n] = g;
+        }
+    }
+}
 // loss = mean over i != j of relu(m - (x_ii - x_ij)) and relu(m - (x_ii - lam x_ji))   (fix_norm = True)
 __global__ __launch_bounds__(256) void maxmargin_fwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
                                                             float* __restrict__ loss) {
@@ -703,6 +809,24 @@ extern "C" int tag_meanmean_pool_backward(const float* dout, const long* alen, c
     const long total = (long)B * B * T * N;
     hipLaunchKernelGGL(meanmean_pool_bwd_kernel, dim3(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256)), dim3(256), 0,
                        as_stream(stream), dout, alen, tlen, dsim, B, T, N);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_sim_pool_forward(const float* sim, const long* alen, const long* tlen, float* out, long R, int T, int N,
+                                    int a_div, int t_mod, int amode, int tmode, void* stream) {
+    TAG_CHECK_ARG(sim && alen && out && R > 0 && T > 0 && N > 0 && a_div > 0 && amode >= 0 && amode <= 3);
+    TAG_CHECK_ARG(tmode >= -1 && tmode <= 3 && (tmode < 0 || (tlen && t_mod > 0)));
+    hipLaunchKernelGGL(sim_pool_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), sim, alen, tlen, out, R, T, N,
+                       a_div, t_mod > 0 ? t_mod : 1, amode, tmode);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_sim_pool_backward(const float* sim, const long* alen, const long* tlen, const float* dout, float* dsim,
+                                     long R, int T, int N, int a_div, int t_mod, int amode, int tmode, void* stream) {
+    TAG_CHECK_ARG(sim && alen && dout && dsim && R > 0 && T > 0 && N > 0 && a_div > 0 && amode >= 0 && amode <= 3);
+    TAG_CHECK_ARG(tmode >= -1 && tmode <= 3 && (tmode < 0 || (tlen && t_mod > 0)));
+    hipLaunchKernelGGL(sim_pool_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), sim, alen, tlen, dout, dsim, R,
+                       T, N, a_div, t_mod > 0 ? t_mod : 1, amode, tmode);
     TAG_LAUNCH_CHECK();
     return 0;
 }

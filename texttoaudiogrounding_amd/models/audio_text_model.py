@@ -84,8 +84,8 @@ class MultiTextBiEncoder(BiEncoder):
         self.text_forward_keys = list(text_forward_keys)
         if "text_len" not in self.text_forward_keys:
             self.text_forward_keys.append("text_len")
-        if pooling != "linear_softmax":
-            raise NotImplementedError("the HIP path implements pooling='linear_softmax' (the reference's default)")
+        if pooling not in ops.POOL_MODES:
+            raise Exception(f"Unsupported pooling {pooling}")         # the reference raises at forward time (:215)
         self.pooling = pooling
         self.safe_size = safe_size          # chunking knob of the reference: unnecessary here (no expansion)
         if pretrained is not None and type(self) is MultiTextBiEncoder:
@@ -112,7 +112,9 @@ class MultiTextBiEncoder(BiEncoder):
         sim = ops.MatchGroupFunction.apply(audio_emb, seq, N, self.match_fn.scale)            # (B*N, T')
         length = audio_output["length"]
         len_dev = torch.as_tensor(length).long().to(sim.device).contiguous()
-        clip_sim = ops.LinearSoftmaxPoolFunction.apply(sim, len_dev, N).view(B, N)
+        # linear_softmax / max / mean / exp_softmax _with_lens over the valid frames (models/audio_text_model.py:205-215)
+        clip_sim = ops.SimPoolFunction.apply(sim.view(B * N, -1, 1), len_dev, None, N, 1, ops.POOL_MODES[self.pooling],
+                                             -1).view(B, N)
         frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
         return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}
 

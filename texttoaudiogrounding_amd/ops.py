@@ -1279,6 +1279,36 @@ class MeanMeanPoolFunction(torch.autograd.Function):
         return dsim, None, None
 
 
+class SimPoolFunction(torch.autograd.Function):
+    """General similarity pooling (tag_sim_pool_*): sim (R,T,N) -> (R) or, with tmode = -1, (R,N).
+    amode 0 mean / 1 max / 2 linear_softmax / 3 exp_softmax over the frames < alen[r // a_div];
+    tmode 0 mean / 1 sum / 2 max / 3 mean+sum over the tokens < tlen[r % t_mod]."""
+
+    @staticmethod
+    def forward(ctx, sim, alen, tlen, a_div, t_mod, amode, tmode):
+        s = _chk(sim, "sim")
+        R, T, N = s.shape
+        out = _empty(R, N, like=s) if tmode < 0 else _empty(R, like=s)
+        call("tag_sim_pool_forward", ptr(s), ptr(alen), ptr(tlen), ptr(out), R, T, N, a_div, t_mod, amode, tmode)
+        ctx.save_for_backward(s, alen, tlen if tlen is not None else alen)
+        ctx.cfg = (a_div, t_mod, amode, tmode, tlen is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, alen, tlen = ctx.saved_tensors
+        a_div, t_mod, amode, tmode, has_t = ctx.cfg
+        R, T, N = s.shape
+        dsim = torch.empty_like(s)
+        call("tag_sim_pool_backward", ptr(s), ptr(alen), ptr(tlen) if has_t else None, ptr(_chk(dout, "grad")), ptr(dsim), R, T,
+             N, a_div, t_mod, amode, tmode)
+        return dsim, None, None, None, None, None, None
+
+
+POOL_MODES = {"mean": 0, "max": 1, "linear_softmax": 2, "exp_softmax": 3}
+TEXT_MODES = {"mean": 0, "sum": 1, "max": 2, "mean_sum": 3}
+
+
 class MaxMarginFunction(torch.autograd.Function):
     """MaxMarginRankingLoss(fix_norm=True) (losses.py:226-264) on an (n,n) similarity matrix."""
 

@@ -394,6 +394,21 @@ int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, co
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * EmbeddingAgg(aggregation="attention") = AttentionPooling, models/text_encoder.py:46-58,79-86: x (B,L,D) token embeddings,
+ * lens (B), fc.weight w (D), fc.bias (1) -> weight (B,L) softmax over the valid tokens (-1e10 fill), out (B,D).
+ * backward: dx (B,L,D) (to be ADDED to any other gradient of the tokens by the caller), gw (B,D) / gb (B) = per-phrase terms
+ * of d fc.weight / d fc.bias (fold with tag_colsum).
+ * BiEncoder(upsample=True), models/audio_text_model.py:90-97: F.interpolate(mode="linear", align_corners=False) of the
+ * frame scores x (R,T) -> (R, T*ratio); backward gathers (no atomics).
+ * ------------------------------------------------------------------------------------------- */
+int tag_attnpool_forward(const float* x, const long* lens, const float* w, const float* bias, float* weight, float* out,
+                         int B, int L, int D, void* stream);
+int tag_attnpool_backward(const float* x, const float* w, const float* weight, const float* dout, float* dx, float* gw,
+                          float* gb, int B, int L, int D, void* stream);
+int tag_upsample_linear_forward(const float* x, float* out, long R, int T, int ratio, void* stream);
+int tag_upsample_linear_backward(const float* dout, float* dx, long R, int T, int ratio, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * General similarity pooling: models/utils.py:22-105 (mean/max/linear_softmax/exp_softmax _with_lens), all twelve reducers
  * of models/sim_pooling.py:6-204 and the pooling modes of MultiTextBiEncoder (models/audio_text_model.py:205-215).
  * sim (R,T,N) fp32, T frames, N tokens/phrases innermost; alen indexed by r / a_div, tlen by r % t_mod.

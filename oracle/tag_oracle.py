@@ -711,6 +711,19 @@ def linear_softmax_with_lens(features, lens):
     return (features * features * mask).sum(1) / (features * mask).sum(1)
 
 
+def attention_pooling(x, lens, w, b):
+    """AttentionPooling (models/text_encoder.py:46-58): fc = Linear(D,1); -1e10 fill beyond the length; softmax; weighted sum."""
+    score = F.linear(x, w, b).squeeze(-1)
+    mask = length_mask(torch.as_tensor(lens), x.size(1)).to(torch.bool)
+    score = score.masked_fill(~mask, -1e10)
+    return (x * torch.softmax(score, dim=1).unsqueeze(-1)).sum(1)
+
+
+def upsample_linear(frame_sim, ratio):
+    """BiEncoder(upsample=True) (models/audio_text_model.py:90-97)."""
+    return F.interpolate(frame_sim.unsqueeze(1), frame_sim.size(1) * ratio, mode="linear", align_corners=False).squeeze(1)
+
+
 def sum_with_lens(features, lens):
     """models/utils.py:33-46."""
     mask = length_mask(torch.as_tensor(lens), features.size(1)).to(features.dtype)

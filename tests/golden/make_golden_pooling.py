@@ -58,5 +58,23 @@ for name in ("MultiTextLinearSoft", "MultiTextMax"):
     y = getattr(ref_pool, name)()({"sim": s, "audio_len": audio_len})
     y.backward(dclip)
     out[f"{name}/out"], out[f"{name}/dsim"] = y.detach().numpy(), s.grad.numpy()
+# EmbeddingAgg(aggregation="attention"): the reference's AttentionPooling (models/text_encoder.py:46-58)
+from models.text_encoder import AttentionPooling  # noqa: E402  (the reference; sentence_transformers stubbed)
+D, L = 96, 5
+torch.manual_seed(3)
+ap = AttentionPooling(D).double()
+with torch.no_grad():
+    ap.fc.weight.mul_(8.0)
+x = torch.randn(B, L, D, generator=g, dtype=torch.float64).requires_grad_(True)
+lens = torch.tensor([5, 1, 3, 4])
+dpool = torch.randn(B, D, generator=g, dtype=torch.float64)
+y = ap(x, lens)
+y.backward(dpool)
+out.update({"attnpool/x": x.detach().numpy(), "attnpool/lens": lens.numpy(), "attnpool/w": ap.fc.weight.detach().numpy(),
+            "attnpool/b": ap.fc.bias.detach().numpy(), "attnpool/dout": dpool.numpy(), "attnpool/out": y.detach().numpy(),
+            "attnpool/dx": x.grad.numpy(), "attnpool/dw": ap.fc.weight.grad.numpy(), "attnpool/db": ap.fc.bias.grad.numpy()})
+err = (O.attention_pooling(x.detach(), lens, ap.fc.weight.detach(), ap.fc.bias.detach()) - y.detach()).abs().max().item()
+print(f"{'AttentionPooling':26s} oracle vs reference {err:.1e}")
+assert err < 1e-13
 np.savez_compressed(os.path.join(HERE, "sim_pooling.npz"), **out)
 print("wrote sim_pooling.npz", os.path.getsize(os.path.join(HERE, "sim_pooling.npz")))

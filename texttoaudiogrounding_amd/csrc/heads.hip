@@ -594,6 +594,126 @@ __global__ __launch_bounds__(256) void sim_pool_bwd_kernel(const float* __restri
         }
     }
 }
+// ------------------------------------------------------------------------------------------------------------------
+// EmbeddingAgg(aggregation="attention") = AttentionPooling (models/text_encoder.py:46-58): score_l = x_l . w + b,
+// masked_fill(-1e10) beyond text_len, softmax over the tokens, out = sum_l weight_l x_l.  One wave per phrase.
+// backward: dx_l = weight_l dout + ds_l w with ds_l = weight_l (x_l . dout - sum_j weight_j x_j . dout);
+// gw (B,D) = sum_l ds_l x_l and gb (B) = sum_l ds_l are per-phrase terms folded by tag_colsum (fixed order).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attnpool_fwd_kernel(const float* __restrict__ x, const long* __restrict__ lens,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ weight, float* __restrict__ out, int B, int L,
+                                                           int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int len = (int)lens[b];
+    Row wr;
+    load_row(wr, w, D, lane);
+    // scores are recomputed in each of the three passes (L * D FMAs per pass: a few thousand) -- nothing round-trips
+    auto score = [&](int l) {
+        Row xr;
+        load_row(xr, x + ((size_t)b * L + l) * D, D, lane);
+        const float sc = dot_rows(xr, wr) + bias[0];
+        return l >= len ? -1e10f : sc;
+    };
+    float mx = -3.0e38f;
+    for (int l = 0; l < L; ++l) mx = fmaxf(mx, score(l));
+    float den = 0.0f;
+    for (int l = 0; l < L; ++l) den += expf(score(l) - mx);
+    Row acc;
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) acc.v[i] = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        const float wt = expf(score(l) - mx) / den;
+        Row xr;
+        load_row(xr, x + ((size_t)b * L + l) * D, D, lane);
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) acc.v[i] = fmaf(wt, xr.v[i], acc.v[i]);
+        if (lane == 0) weight[(size_t)b * L + l] = wt;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) { const int d = lane + 64 * i; if (d < D) out[(size_t)b * D + d] = acc.v[i]; }
+}
+__global__ __launch_bounds__(256) void attnpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ weight, const float* __restrict__ dout,
+                                                           float* __restrict__ dx, float* __restrict__ gw,
+                                                           float* __restrict__ gb, int B, int L, int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    Row wr, dr, gacc;
+    load_row(wr, w, D, lane);
+    load_row(dr, dout + (size_t)b * D, D, lane);
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) gacc.v[i] = 0.0f;
+    float dot_all = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        Row xr;
+        load_row(xr, x + ((size_t)b * L + l) * D, D, lane);
+        dot_all = fmaf(weight[(size_t)b * L + l], dot_rows(xr, dr), dot_all);
+    }
+    float gbs = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        Row xr;
+        load_row(xr, x + ((size_t)b * L + l) * D, D, lane);
+        const float wt = weight[(size_t)b * L + l];
+        const float ds = wt * (dot_rows(xr, dr) - dot_all);          // masked tokens: weight = 0 -> no gradient
+        gbs += ds;
+#pragma unroll
+        for (int i = 0; i < MAXD_PER_LANE; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) dx[((size_t)b * L + l) * D + d] = fmaf(wt, dr.v[i], ds * wr.v[i]);
+            gacc.v[i] = fmaf(ds, xr.v[i], gacc.v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXD_PER_LANE; ++i) { const int d = lane + 64 * i; if (d < D) gw[(size_t)b * D + d] = gacc.v[i]; }
+    if (lane == 0) gb[b] = gbs;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BiEncoder(upsample=True) (models/audio_text_model.py:90-97): F.interpolate(frame_sim, T * ratio, mode="linear",
+// align_corners=False).  out[i] = (1 - lam) x[i0] + lam x[i1], src = max((i + 0.5) / ratio - 0.5, 0), i0 = floor(src),
+// i1 = min(i0 + 1, T - 1).  backward gathers: input t collects the outputs that read it (no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_src(int i, int ratio, int T, int& i0, int& i1, float& lam) {
+    float src = ((float)i + 0.5f) / (float)ratio - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < T - 1 ? 1 : 0);
+    lam = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample_lin_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long R,
+                                                               int T, int ratio) {
+    const long total = R * T * ratio;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / ((long)T * ratio);
+        const int i = (int)(e % ((long)T * ratio));
+        int i0, i1; float lam;
+        lin_src(i, ratio, T, i0, i1, lam);
+        out[e] = (1.0f - lam) * x[r * T + i0] + lam * x[r * T + i1];
+    }
+}
+__global__ __launch_bounds__(256) void upsample_lin_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, long R,
+                                                               int T, int ratio) {
+    const long total = R * T;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / T;
+        const int t = (int)(e % T);
+        float g = 0.0f;
+        const int lo = max(0, (t - 1) * ratio - 1), hi = min(T * ratio - 1, (t + 2) * ratio);
+        for (int i = lo; i <= hi; ++i) {
+            int i0, i1; float lam;
+            lin_src(i, ratio, T, i0, i1, lam);
+            const float d = dout[r * T * ratio + i];
+            if (i0 == t) g = fmaf(1.0f - lam, d, g);
+            if (i1 == t) g = fmaf(lam, d, g);
+        }
+        dx[e] = g;
+    }
+}
+
 // loss = mean over i != j of relu(m - (x_ii - x_ij)) and relu(m - (x_ii - lam x_ji))   (fix_norm = True)
 __global__ __launch_bounds__(256) void maxmargin_fwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
                                                             float* __restrict__ loss) {
@@ -809,6 +929,38 @@ extern "C" int tag_meanmean_pool_backward(const float* dout, const long* alen, c
     const long total = (long)B * B * T * N;
     hipLaunchKernelGGL(meanmean_pool_bwd_kernel, dim3(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256)), dim3(256), 0,
                        as_stream(stream), dout, alen, tlen, dsim, B, T, N);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_attnpool_forward(const float* x, const long* lens, const float* w, const float* bias, float* weight,
+                                    float* out, int B, int L, int D, void* stream) {
+    TAG_CHECK_ARG(x && lens && w && bias && weight && out && B > 0 && L > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
+    hipLaunchKernelGGL(attnpool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), x, lens, w, bias, weight, out,
+                       B, L, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_attnpool_backward(const float* x, const float* w, const float* weight, const float* dout, float* dx,
+                                     float* gw, float* gb, int B, int L, int D, void* stream) {
+    TAG_CHECK_ARG(x && w && weight && dout && dx && gw && gb && B > 0 && L > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
+    hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), x, w, weight, dout, dx, gw, gb,
+                       B, L, D);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_upsample_linear_forward(const float* x, float* out, long R, int T, int ratio, void* stream) {
+    TAG_CHECK_ARG(x && out && R > 0 && T > 0 && ratio >= 1);
+    const long n = R * T * ratio;
+    hipLaunchKernelGGL(upsample_lin_fwd_kernel, dim3(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256)), dim3(256), 0,
+                       as_stream(stream), x, out, R, T, ratio);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_upsample_linear_backward(const float* dout, float* dx, long R, int T, int ratio, void* stream) {
+    TAG_CHECK_ARG(dout && dx && R > 0 && T > 0 && ratio >= 1);
+    const long n = R * T;
+    hipLaunchKernelGGL(upsample_lin_bwd_kernel, dim3(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256)), dim3(256), 0,
+                       as_stream(stream), dout, dx, R, T, ratio);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -121,6 +121,10 @@ _SIGS = {
     "tag_resln_head_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_float, c_uint64, P]),
     "tag_sim_pool_forward": (c_int, [P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_sim_pool_backward": (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_attnpool_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_attnpool_backward": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "tag_upsample_linear_forward": (c_int, [P, P, c_long, c_int, c_int, P]),
+    "tag_upsample_linear_backward": (c_int, [P, P, c_long, c_int, c_int, P]),
     "tag_sumsq_ws_bytes": (c_size_t, [c_long]),
     "tag_sumsq": (c_int, [P, c_long, P, P, P]),
     "tag_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P, c_float, c_float, P]),

@@ -13,8 +13,6 @@ class BiEncoder(nn.Module):
                  freeze_audio_encoder: bool = False, freeze_text_encoder: bool = False,
                  pretrained: Optional[str] = None):
         super().__init__()
-        if upsample:
-            raise NotImplementedError("upsample=True is off in every strong eg_config and not on the HIP path")
         self.audio_encoder = audio_encoder
         self.text_encoder = text_encoder
         self.match_fn = match_fn
@@ -63,7 +61,12 @@ class BiEncoder(nn.Module):
                                                                  self.text_proj.bias)
             # without a cross-encoder token_emb is not projected: no head consumes it (text_level='seq')
         frame_sim = self.match_fn(forward_dict)
-        return {"frame_sim": frame_sim, "length": audio_output["length"]}
+        length = audio_output["length"]
+        if self.interpolate_ratio != 1 and self.upsample:
+            # F.interpolate(mode="linear", align_corners=False) x interpolate_ratio (models/audio_text_model.py:90-97)
+            frame_sim = ops.UpsampleLinearFunction.apply(frame_sim, self.interpolate_ratio)
+            length = length * self.interpolate_ratio
+        return {"frame_sim": frame_sim, "length": length}
 
 
 class MultiTextBiEncoder(BiEncoder):
@@ -115,8 +118,45 @@ class MultiTextBiEncoder(BiEncoder):
         # linear_softmax / max / mean / exp_softmax _with_lens over the valid frames (models/audio_text_model.py:205-215)
         clip_sim = ops.SimPoolFunction.apply(sim.view(B * N, -1, 1), len_dev, None, N, 1, ops.POOL_MODES[self.pooling],
                                              -1).view(B, N)
+        if self.interpolate_ratio != 1 and self.upsample:                                    # models/audio_text_model.py:216-224
+            sim = ops.UpsampleLinearFunction.apply(sim, self.interpolate_ratio)
+            length = length * self.interpolate_ratio
         frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
         return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}
+
+
+class AudioTextAlignByWord(nn.Module):
+    """Word-level weak alignment (mirror of models/audio_text_model.py:843-904): every clip's frames against every clip's
+    WORD embeddings -- (projected) token_emb -> align.DotProduct (B,B,T',n_word) -> sim_pooling -> (B,B)."""
+
+    def __init__(self, audio_encoder, text_encoder, match_fn, sim_pooling, shared_dim, add_proj=False,
+                 freeze_audio_encoder=False, freeze_text_encoder=False):
+        super().__init__()
+        self.audio_encoder, self.text_encoder, self.match_fn, self.sim_pooling = audio_encoder, text_encoder, match_fn, sim_pooling
+        if audio_encoder.embed_dim != text_encoder.embed_dim or add_proj:
+            self.audio_proj = nn.Linear(audio_encoder.embed_dim, shared_dim)
+            self.text_proj = nn.Linear(text_encoder.embed_dim, shared_dim)
+        if freeze_audio_encoder:
+            for p in self.audio_encoder.parameters():
+                p.requires_grad = False
+        if freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad = False
+
+    def forward(self, input_dict):
+        audio_output = self.audio_encoder(input_dict)
+        audio_emb = audio_output["embedding"]
+        if hasattr(self, "audio_proj"):
+            audio_emb = ops.LinearFunction.apply(audio_emb, self.audio_proj.weight, self.audio_proj.bias)
+        word_emb = self.text_encoder(input_dict)["token_emb"]
+        if hasattr(self, "text_proj"):
+            word_emb = ops.LinearFunction.apply(word_emb, self.text_proj.weight, self.text_proj.bias)
+        sim_matrix = self.match_fn(audio_emb, word_emb.contiguous())
+        sim = self.sim_pooling({"sim": sim_matrix, "audio_len": audio_output["length"], "text_len": input_dict["text_len"]})
+        output = {"sim": sim}
+        if input_dict.get("output_matrix", False):
+            output["sim_matrix"] = sim_matrix
+        return output
 
 
 class AudioTextAlignByPhrase(nn.Module):

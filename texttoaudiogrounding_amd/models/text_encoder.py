@@ -29,6 +29,18 @@ class EmbeddingLayer(nn.Module):
         raise RuntimeError("EmbeddingLayer is evaluated inside EmbeddingAgg's fused gather+mean kernel")
 
 
+class AttentionPooling(nn.Module):
+    """Parameter container with the reference's layout (models/text_encoder.py:46-58): ``fc = Linear(emb_dim, 1)``."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.fc = nn.Linear(emb_dim, 1)
+
+    def forward(self, x, lens):
+        lens = torch.as_tensor(lens).long().to(x.device).contiguous()
+        return ops.AttnPoolFunction.apply(x, lens, self.fc.weight, self.fc.bias)
+
+
 class EmbeddingAgg(nn.Module):
     def __init__(self, vocab_size, embed_dim, pretrained_embedding: str = None, freeze_embedding: bool = False,
                  aggregation: str = "mean"):
@@ -36,8 +48,10 @@ class EmbeddingAgg(nn.Module):
         self.embedding = EmbeddingLayer(vocab_size, embed_dim, pretrained_embedding, freeze_embedding)
         self.embed_dim = self.embedding.embed_dim
         self.agg = aggregation
-        if aggregation != "mean":
-            raise Exception(f"{aggregation} not supported by the HIP path (hot path uses 'mean')")
+        if aggregation == "attention":
+            self.attn = AttentionPooling(embed_dim)
+        elif aggregation != "mean":
+            raise Exception(f"{aggregation} not supported")            # as the reference (models/text_encoder.py:87-88)
 
     def forward(self, input_dict):
         table = self.embedding.core.weight
@@ -45,4 +59,6 @@ class EmbeddingAgg(nn.Module):
         text = input_dict["text"].long().to(dev).contiguous()
         lens = torch.as_tensor(input_dict["text_len"]).long().to(dev).contiguous()
         seq, tok = ops.EmbedMeanFunction.apply(table, text, lens, True)
+        if self.agg == "attention":
+            seq = self.attn(tok, lens)
         return {"token_emb": tok, "seq_emb": seq}

@@ -1279,6 +1279,54 @@ class MeanMeanPoolFunction(torch.autograd.Function):
         return dsim, None, None
 
 
+class AttnPoolFunction(torch.autograd.Function):
+    """AttentionPooling (models/text_encoder.py:46-58): softmax(fc(x)) over the valid tokens, weighted sum -> (B,D)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, w, b):
+        xs = _chk(x, "token_emb")
+        B, L, D = xs.shape
+        w_, b_ = _chk(w.detach(), "fc.weight").view(-1), _chk(b.detach(), "fc.bias")
+        weight, out = _empty(B, L, like=xs), _empty(B, D, like=xs)
+        call("tag_attnpool_forward", ptr(xs), ptr(lens), ptr(w_), ptr(b_), ptr(weight), ptr(out), B, L, D)
+        ctx.save_for_backward(xs, w_, weight)
+        ctx.sinks = _sinks([w, b])
+        ctx.params = [w, b] if DIRECT_GRADS else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, w_, weight = ctx.saved_tensors
+        B, L, D = xs.shape
+        dx, gw, gb = torch.empty_like(xs), _empty(B, D, like=xs), _empty(B, like=xs)
+        call("tag_attnpool_backward", ptr(xs), ptr(w_), ptr(weight), ptr(_chk(dout, "grad")), ptr(dx), ptr(gw), ptr(gb), B, L, D)
+        g = [colsum(gw, B, D).view(1, D), colsum(gb, B, 1)]
+        for i in range(2):
+            _deliver(g, ctx.sinks, i, g[i])
+        _ready(ctx.params)
+        return dx, None, g[0], g[1]
+
+
+class UpsampleLinearFunction(torch.autograd.Function):
+    """F.interpolate(x.unsqueeze(1), T * ratio, mode="linear", align_corners=False).squeeze(1) on (R,T) frame scores."""
+
+    @staticmethod
+    def forward(ctx, x, ratio):
+        xs = _chk(x, "frame_sim")
+        R, T = xs.shape
+        out = _empty(R, T * ratio, like=xs)
+        call("tag_upsample_linear_forward", ptr(xs), ptr(out), R, T, int(ratio))
+        ctx.cfg = (R, T, int(ratio))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        R, T, ratio = ctx.cfg
+        dx = torch.empty(R, T, device=dout.device, dtype=F32)
+        call("tag_upsample_linear_backward", ptr(_chk(dout, "grad")), ptr(dx), R, T, ratio)
+        return dx, None
+
+
 class SimPoolFunction(torch.autograd.Function):
     """General similarity pooling (tag_sim_pool_*): sim (R,T,N) -> (R) or, with tmode = -1, (R,N).
     amode 0 mean / 1 max / 2 linear_softmax / 3 exp_softmax over the frames < alen[r // a_div];

@@ -86,8 +86,9 @@ def test_attention_pooling_golden(dev, golden_dir):
     out = ops.AttnPoolFunction.apply(x, torch.from_numpy(gold["attnpool/lens"]).long().to(dev), w, b)
     out.backward(torch.from_numpy(gold["attnpool/dout"]).float().to(dev))
     e = (relerr(out, gold["attnpool/out"]), relerr(x.grad, gold["attnpool/dx"]), relerr(w.grad, gold["attnpool/dw"]))
-    print(f"AttentionPooling: out {e[0]:.2e} dx {e[1]:.2e} dw {e[2]:.2e}; db {float(b.grad.reshape(-1)[0]):.2e} (reference {float(np.asarray(gold["attnpool/db"]).reshape(-1)[0]):.2e})")
-    assert max(e) < 5e-6 and abs(float(b.grad.reshape(-1)[0]) - float(np.asarray(gold["attnpool/db"]).reshape(-1)[0])) < 1e-5
+    db, db_ref = b.grad.reshape(-1)[0].item(), np.asarray(gold["attnpool/db"]).reshape(-1)[0].item()
+    print(f"AttentionPooling: out {e[0]:.2e} dx {e[1]:.2e} dw {e[2]:.2e}; db {db:.2e} (reference {db_ref:.2e})")
+    assert max(e) < 5e-6 and abs(db - db_ref) < 1e-5
 
 
 def test_embedding_agg_attention_module(dev):

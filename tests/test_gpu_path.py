@@ -558,3 +558,26 @@ def test_training_step_is_bitwise_deterministic(dev, math_):
     assert res[0][0] == res[1][0]
     same = res[0][1] == res[1][1]
     assert bool(same.all()), f"{int((~same).sum())} gradient elements differ between two identical runs"
+
+
+def test_device_segments_to_th_auc_and_psds(dev):
+    """Scores -> device segments (tag_segments, 50 thresholds) -> operating-point tables -> threshold-AUC / PSDS: identical
+    to the same evaluation over the CPU oracle's segments (the segments are bit-exact, so the metrics are equal)."""
+    from texttoaudiogrounding_amd.utils import eval_util, grounding_eval as GE
+    g = torch.Generator().manual_seed(17)
+    B, T, res = 12, 250, 0.04
+    base = torch.rand(B, 1, generator=g) * 0.5 + 0.2
+    fs = (base + 0.35 * torch.sin(torch.arange(T)[None, :] / (3.0 + 5.0 * torch.rand(B, 1, generator=g))) +
+          0.05 * torch.randn(B, T, generator=g)).clamp(1e-7, 1.0)
+    th = eval_util.eval_thresholds(50)
+    names = [f"clip{i}_0" for i in range(B)]
+    gt = {n: np.array([[1.0 + 0.3 * i, 3.5 + 0.3 * i], [6.0, 7.0 + 0.1 * i]]) for i, n in enumerate(names)}
+    dur = {n: 10.0 for n in names}
+    seg_dev = eval_util.segments_for_thresholds(fs.to(dev), th, 1, eval_util.n_connect_for(res))
+    seg_cpu = [[O.segments(fs[b].numpy(), t, 1, 13) for t in th] for b in range(B)]
+    t_dev = GE.tables_from_segments(seg_dev, names, th, res)
+    t_cpu = GE.tables_from_segments(seg_cpu, names, th, res)
+    a_dev, a_cpu = GE.compute_th_auc(t_dev, gt), GE.compute_th_auc(t_cpu, gt)
+    p_dev, p_cpu = GE.psds_intersection(t_dev, gt, dur, max_efpr=800.0), GE.psds_intersection(t_cpu, gt, dur, max_efpr=800.0)
+    print(f"th_auc {a_dev:.6f} (cpu {a_cpu:.6f}); psds {p_dev:.6f} (cpu {p_cpu:.6f})")
+    assert a_dev == a_cpu and p_dev == p_cpu and 0.0 < a_dev < 1.0 and 0.0 < p_dev <= 1.0

@@ -259,7 +259,7 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
 FUSE_BN_BWD_SUMS = os.environ.get("TAG_FUSE_BN_BWD", "1") != "0"
 
 
-def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=None, db_out=None):
+def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=None, db_out=None, after_conv=None):
     """The dgrad convolution da = conv(dy_in, wpack) followed by the backward of relu(bn(yref)):
     returns (dy_ref, dgamma, dbeta) with dy_ref = dL/d yref (written in place over da).  Exact-fp32 halo-tile shapes
     fold the per-channel sums into the conv epilogue; other shapes / arithmetics run the conv and tag_bnrelu_backward."""
@@ -269,6 +269,8 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
              and query("tag_conv3x3_stats_rows", B, H, W, C) > 0)
     if not fused:
         da = conv3x3(dy_in, wpack, C)
+        if after_conv is not None:
+            after_conv()
         return bnrelu_backward(yref, st, gamma, da, dg_out=dg_out, db_out=db_out)
     P = query("tag_conv3x3_stats_rows", B, H, W, C)
     da = _empty(B, H, W, C, like=dy_in)
@@ -276,6 +278,8 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     with _timed(("conv3x3_halo_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
         call("tag_conv3x3_dgrad_bnsums", ptr(dy_in), ptr(wpack), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
              ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C)
+    if after_conv is not None:
+        after_conv()
     dg = dg_out if dg_out is not None else _empty(C, like=da)
     db = db_out if db_out is not None else _empty(C, like=da)
     ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), da)
@@ -593,6 +597,13 @@ def side_streams(device):
     return [_side_streams[key]] if key in _side_streams else []
 
 
+#: the side stream's wgrad of a layer is RELEASED one kernel late -- when the dgrad conv that consumes the same dy has been
+#: enqueued -- so that it starts together with the HBM-bound BatchNorm / pool backward passes that follow that dgrad
+#: instead of beside the dgrad itself (two MFMA-bound kernels of equal length co-running finish together and leave the
+#: bandwidth-bound passes alone on the chip; lagged, every such pass has MFMA work to hide under).
+WGRAD_LAG = _os.environ.get("TAG_WGRAD_LAG", "1") != "0"
+
+
 class _SideWgrad:
     """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them."""
 
@@ -600,21 +611,34 @@ class _SideWgrad:
         self.on = WGRAD_SIDE_STREAM
         self.main = torch.cuda.current_stream(device)
         self.side = _side_stream(device) if self.on else None
+        self.pending = []
 
     def wgrad(self, x, dy, prologue=0, scale=None, shift=None, out=None):
         if not self.on:
             return conv3x3_wgrad(x, dy, prologue, scale, shift, out=out)
+        dw = out if out is not None else _empty(dy.shape[3], x.shape[3], 3, 3, like=x)
+        self.pending.append((x, dy, prologue, scale, shift, dw))
+        if not WGRAD_LAG:
+            self.release()
+        return dw
+
+    def release(self):
+        """Launch the queued wgrads on the side stream, ordered after everything enqueued on the main stream so far."""
+        if not self.pending:
+            return
         self.side.wait_stream(self.main)                 # x, dy (and the BN constants) are ready
         with torch.cuda.stream(self.side):
-            dw = conv3x3_wgrad(x, dy, prologue, scale, shift, out=out)
-        for t in (x, dy, scale, shift):
-            if t is not None:
-                t.record_stream(self.side)               # the caching allocator must not recycle them early
-        dw.record_stream(self.main)
-        return dw
+            for x, dy, prologue, scale, shift, dw in self.pending:
+                conv3x3_wgrad(x, dy, prologue, scale, shift, out=dw)
+        for x, dy, prologue, scale, shift, dw in self.pending:
+            for t in (x, dy, scale, shift, dw):
+                if t is not None:
+                    t.record_stream(self.side)           # the caching allocator must not recycle them early
+        self.pending = []
 
     def join(self):
         if self.on:
+            self.release()
             self.main.wait_stream(self.side)
 
 
@@ -718,13 +742,15 @@ class Cnn8RnnFunction(torch.autograd.Function):
             _deliver(grads, sk, o + 5, db2)
             del dx
             _deliver(grads, sk, o + 3, sw.wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift, out=sk[o + 3]))
-            dy1, dg1, db1 = conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1, dg_out=sk[o + 1], db_out=sk[o + 2])
+            dy1, dg1, db1 = conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1, dg_out=sk[o + 1], db_out=sk[o + 2],
+                                                          after_conv=sw.release)
             del dy2
             _deliver(grads, sk, o + 1, dg1)
             _deliver(grads, sk, o + 2, db1)
             if i > 0:
                 _deliver(grads, sk, o, sw.wgrad(x_in, dy1, out=sk[o]))
                 dx = conv3x3(dy1, wd1, x_in.shape[3])
+                sw.release()
             else:
                 dw0, dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift, out=sk[2])   # dbn0: (B,F,64) grad wrt bn0 output
                 _deliver(grads, sk, 2, dw0)
@@ -734,6 +760,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 _deliver(grads, sk, 1, db0)
             del dy1
             sv["acts"][i] = None
+            sw.release()                           # every gradient kernel of this block is enqueued before _ready
             if prm is not None:
                 _ready(prm[o:o + 6] + ((prm[0], prm[1]) if i == 0 else ()))
                 _flush()

@@ -1,0 +1,334 @@
+"""``torch.library`` registration of the hot-path kernels (namespace ``tag``) -- the op list SURVEY.md section 8(b) asks a
+native replacement to export, with schemas, fake (meta) kernels for shape inference / tracing and autograd formulas, on top
+of the SAME C ABI (libtag_hip.so through ctypes, texttoaudiogrounding_amd.lib): PyTorch sees these as first-class operators
+(``torch.ops.tag.logmel`` ...), the reference-shaped modules keep calling the autograd nodes of ``ops.py``, which run the very
+same entry points.
+
+    import texttoaudiogrounding_amd.torch_ops          # registers torch.ops.tag.*
+
+Every op takes contiguous fp32 device tensors on the current stream and raises on CPU tensors (no fallback).  Backward passes
+are ops themselves (``tag::*_backward``), so a graph captured through these operators contains only ``tag::`` nodes for the
+path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.library import custom_op, register_autograd
+
+from . import ops
+
+__all__ = ["OP_NAMES"]
+
+
+# ------------------------------------------------------------------------------------------------ F1/F2 log-mel
+@custom_op("tag::logmel", mutates_args=())
+def logmel(waveform: Tensor, n_fft: int, win_length: int, hop: int, window: Tensor, fb: Tensor) -> Tensor:
+    """(B,S) -> (B, S//hop + 1, n_mels) dB log-mel, time-major (rows F1/F2)."""
+    return ops.logmel(waveform, n_fft, win_length, hop, window, fb)
+
+
+@logmel.register_fake
+def _(waveform, n_fft, win_length, hop, window, fb):
+    return waveform.new_empty(waveform.shape[0], waveform.shape[1] // hop + 1, fb.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------ A1 conv 3x3
+@custom_op("tag::conv3x3", mutates_args=())
+def conv3x3(x: Tensor, weight: Tensor, prologue: int, scale: Optional[Tensor], shift: Optional[Tensor]) -> Tensor:
+    """y = conv3x3(prologue(x)), channels-last (B,H,W,Cin) x (Cout,Cin,3,3) -> (B,H,W,Cout); prologue 1 folds the producer's
+    BatchNorm + ReLU (relu(x * scale + shift)) into the operand load."""
+    wf, _ = ops.pack_conv_weight(weight, want_dgrad=False, W=x.shape[2])
+    return ops.conv3x3(x, wf, weight.shape[0], prologue, scale, shift)
+
+
+@conv3x3.register_fake
+def _(x, weight, prologue, scale, shift):
+    return x.new_empty(x.shape[0], x.shape[1], x.shape[2], weight.shape[0])
+
+
+@custom_op("tag::conv3x3_dgrad", mutates_args=())
+def conv3x3_dgrad(dy: Tensor, weight: Tensor) -> Tensor:
+    """Gradient of conv3x3 (prologue 0) with respect to its input: (B,H,W,Cout) -> (B,H,W,Cin)."""
+    _, wd = ops.pack_conv_weight(weight, want_dgrad=True, W=dy.shape[2])
+    return ops.conv3x3(dy, wd, weight.shape[1])
+
+
+@conv3x3_dgrad.register_fake
+def _(dy, weight):
+    return dy.new_empty(dy.shape[0], dy.shape[1], dy.shape[2], weight.shape[1])
+
+
+@custom_op("tag::conv3x3_wgrad", mutates_args=())
+def conv3x3_wgrad(x: Tensor, dy: Tensor, prologue: int, scale: Optional[Tensor], shift: Optional[Tensor]) -> Tensor:
+    """Weight gradient (Cout,Cin,3,3) of y = conv3x3(prologue(x))."""
+    return ops.conv3x3_wgrad(x, dy, prologue, scale, shift)
+
+
+@conv3x3_wgrad.register_fake
+def _(x, dy, prologue, scale, shift):
+    return x.new_empty(dy.shape[3], x.shape[3], 3, 3)
+
+
+def _conv_setup(ctx, inputs, output):
+    x, weight, prologue, scale, shift = inputs
+    if prologue != 0 and (x.requires_grad or (scale is not None and scale.requires_grad)):
+        raise RuntimeError("tag::conv3x3: the autograd formula covers prologue = 0 (the fused BatchNorm prologue is "
+                           "differentiated by ops.Cnn8RnnFunction, which owns the batch statistics)")
+    ctx.save_for_backward(x, weight)
+    ctx.pro = (prologue, scale, shift)
+
+
+def _conv_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    prologue, scale, shift = ctx.pro
+    dy = dy.contiguous()
+    dx = torch.ops.tag.conv3x3_dgrad(dy, weight) if ctx.needs_input_grad[0] else None
+    dw = torch.ops.tag.conv3x3_wgrad(x, dy, prologue, scale, shift) if ctx.needs_input_grad[1] else None
+    return dx, dw, None, None, None
+
+
+register_autograd("tag::conv3x3", _conv_backward, setup_context=_conv_setup)
+
+
+# ------------------------------------------------------------------------------------------------ A4 BiGRU
+@custom_op("tag::gru_bidir", mutates_args=())
+def gru_bidir(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor, w_ih_r: Tensor, w_hh_r: Tensor,
+              b_ih_r: Tensor, b_hh_r: Tensor) -> Tuple[Tensor, Tensor]:
+    """nn.GRU(I, H, bidirectional=True, batch_first=True), h0 = 0: x (B,T,I) -> y (B,T,2H) and the saved gates (B,T,2,4H)."""
+    B, T, I = x.shape
+    y, sv = ops.gru_bidir_forward(x.reshape(B * T, I), [w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r], B, T, True)
+    return y, sv["gates"]
+
+
+@gru_bidir.register_fake
+def _(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    return x.new_empty(B, T, 2 * H), x.new_empty(B, T, 2, 4 * H)
+
+
+@custom_op("tag::gru_bidir_backward", mutates_args=())
+def gru_bidir_backward(dy: Tensor, x: Tensor, y: Tensor, gates: Tensor, w_ih: Tensor, w_hh: Tensor, w_ih_r: Tensor,
+                       w_hh_r: Tensor) -> List[Tensor]:
+    """-> [dx, dw_ih, dw_hh, db_ih, db_hh, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r]."""
+    B, T, I = x.shape
+    H = w_hh.shape[1]
+    sv = dict(Hh=H, y=y, gates=gates, w_ih=torch.cat([w_ih, w_ih_r], 0), w_hh=torch.stack([w_hh, w_hh_r], 0).contiguous())
+    dx, g = ops.gru_bidir_backward(dy.contiguous(), x.reshape(B * T, I), sv)
+    return [dx.view(B, T, I)] + [t.clone() for t in g]          # bias slices share storage: operators may not return aliases
+
+
+@gru_bidir_backward.register_fake
+def _(dy, x, y, gates, w_ih, w_hh, w_ih_r, w_hh_r):
+    H = w_hh.shape[1]
+    b = x.new_empty(3 * H)
+    return [torch.empty_like(x), torch.empty_like(w_ih), torch.empty_like(w_hh), b, torch.empty_like(b),
+            torch.empty_like(w_ih_r), torch.empty_like(w_hh_r), torch.empty_like(b), torch.empty_like(b)]
+
+
+def _gru_setup(ctx, inputs, output):
+    x, w_ih, w_hh, _, _, w_ih_r, w_hh_r, _, _ = inputs
+    ctx.save_for_backward(x, output[0], output[1], w_ih, w_hh, w_ih_r, w_hh_r)
+
+
+def _gru_backward(ctx, dy, _dgates):
+    x, y, gates, w_ih, w_hh, w_ih_r, w_hh_r = ctx.saved_tensors
+    g = torch.ops.tag.gru_bidir_backward(dy, x, y, gates, w_ih, w_hh, w_ih_r, w_hh_r)
+    return tuple(g)
+
+
+register_autograd("tag::gru_bidir", _gru_backward, setup_context=_gru_setup)
+
+
+# ------------------------------------------------------------------------------------------------ T1/T2 embedding + mean
+@custom_op("tag::embed_mean", mutates_args=())
+def embed_mean(table: Tensor, text: Tensor, text_len: Tensor) -> Tuple[Tensor, Tensor]:
+    """nn.Embedding gather + mean over the valid tokens: -> seq_emb (B,D), token_emb (B,L,D)."""
+    table = ops._chk(table, "embedding table")
+    if not text.is_cuda:
+        raise RuntimeError("tag::embed_mean: token ids must live on the device (no CPU fallback)")
+    B, L = text.shape
+    V, D = table.shape
+    seq, tok = table.new_empty(B, D), table.new_empty(B, L, D)
+    ops.call("tag_embed_check_ids", ops.ptr(text), B * L, V, ops.ptr(ops._embed_flag(table)))
+    ops.call("tag_embed_mean_forward", ops.ptr(text), ops.ptr(text_len), ops.ptr(table), ops.ptr(tok), ops.ptr(seq), B, L, D, V)
+    return seq, tok
+
+
+@embed_mean.register_fake
+def _(table, text, text_len):
+    B, L = text.shape
+    return table.new_empty(B, table.shape[1]), table.new_empty(B, L, table.shape[1])
+
+
+@custom_op("tag::embed_mean_backward", mutates_args=())
+def embed_mean_backward(dseq: Optional[Tensor], dtok: Optional[Tensor], text: Tensor, text_len: Tensor, V: int, D: int) -> Tensor:
+    """Deterministic scatter of the seq_emb / token_emb gradients into a zeroed (V,D) table gradient."""
+    B, L = text.shape
+    dtab = torch.zeros(V, D, device=text.device, dtype=torch.float32)
+    if dseq is not None:
+        ops.call("tag_embed_mean_backward", ops.ptr(dseq.contiguous()), ops.ptr(text), ops.ptr(text_len), ops.ptr(dtab), B, L, D, V)
+    if dtok is not None:
+        ops.call("tag_embed_tokens_backward", ops.ptr(dtok.contiguous()), ops.ptr(text), ops.ptr(dtab), B, L, D, V)
+    return dtab
+
+
+@embed_mean_backward.register_fake
+def _(dseq, dtok, text, text_len, V, D):
+    return torch.empty(V, D, device=text.device, dtype=torch.float32)
+
+
+def _embed_setup(ctx, inputs, output):
+    table, text, text_len = inputs
+    ctx.save_for_backward(text, text_len)
+    ctx.vd = tuple(table.shape)
+
+
+def _embed_backward(ctx, dseq, dtok):
+    text, text_len = ctx.saved_tensors
+    return torch.ops.tag.embed_mean_backward(dseq, dtok, text, text_len, ctx.vd[0], ctx.vd[1]), None, None
+
+
+register_autograd("tag::embed_mean", _embed_backward, setup_context=_embed_setup)
+
+
+# ------------------------------------------------------------------------------------------------ M1/M2 frame x phrase heads
+@custom_op("tag::frame_match", mutates_args=())
+def frame_match(audio: Tensor, text: Tensor, kind: int, l2norm: bool, scale: bool) -> Tensor:
+    """kind 0 = match.DotProduct (sigmoid(a.t [/sqrt D]).clamp(1e-7,1)), 1 = match.ExpNegL2 (exp(-||a - t||)): (B,T,D),(B,D) -> (B,T)."""
+    audio, text = ops._chk(audio, "audio_emb"), ops._chk(text, "text_emb")
+    B, T, D = audio.shape
+    sim = audio.new_empty(B, T)
+    ops.call("tag_match_forward", ops.ptr(audio), ops.ptr(text), ops.ptr(sim), kind, int(l2norm), int(scale), B, T, D)
+    return sim
+
+
+@frame_match.register_fake
+def _(audio, text, kind, l2norm, scale):
+    return audio.new_empty(audio.shape[0], audio.shape[1])
+
+
+@custom_op("tag::frame_match_backward", mutates_args=())
+def frame_match_backward(audio: Tensor, text: Tensor, sim: Tensor, dsim: Tensor, kind: int, l2norm: bool,
+                         scale: bool) -> Tuple[Tensor, Tensor]:
+    B, T, D = audio.shape
+    da, dt = torch.empty_like(audio), torch.empty_like(text)
+    ops.call("tag_match_backward", ops.ptr(audio), ops.ptr(text), ops.ptr(sim), ops.ptr(dsim.contiguous()), ops.ptr(da), ops.ptr(dt),
+             kind, int(l2norm), int(scale), B, T, D)
+    return da, dt
+
+
+@frame_match_backward.register_fake
+def _(audio, text, sim, dsim, kind, l2norm, scale):
+    return torch.empty_like(audio), torch.empty_like(text)
+
+
+def _match_setup(ctx, inputs, output):
+    audio, text, kind, l2norm, scale = inputs
+    ctx.save_for_backward(audio, text, output)
+    ctx.cfg = (kind, l2norm, scale)
+
+
+def _match_backward(ctx, dsim):
+    audio, text, sim = ctx.saved_tensors
+    da, dt = torch.ops.tag.frame_match_backward(audio, text, sim, dsim, *ctx.cfg)
+    return da, dt, None, None, None
+
+
+register_autograd("tag::frame_match", _match_backward, setup_context=_match_setup)
+
+
+# ------------------------------------------------------------------------------------------------ M3 align.DotProduct
+@custom_op("tag::align_dot", mutates_args=())
+def align_dot(audio: Tensor, text: Tensor, l2norm: bool, scaled: bool) -> Tensor:
+    """align.DotProduct: (B,T,D),(B,N,D) -> (B,B,T,N) on the MFMA GEMM with the sigmoid/clamp/scatter epilogue."""
+    return ops.align_dot(audio, text, l2norm, scaled)
+
+
+@align_dot.register_fake
+def _(audio, text, l2norm, scaled):
+    B, T, _ = audio.shape
+    return audio.new_empty(B, B, T, text.shape[1])
+
+
+def _align_setup(ctx, inputs, output):
+    ctx.inputs = inputs
+
+
+def _align_backward(ctx, dout):
+    audio, text, l2norm, scaled = ctx.inputs
+    with torch.enable_grad():                       # the autograd node of ops.py already owns the exact formula
+        a, t = audio.detach().requires_grad_(True), text.detach().requires_grad_(True)
+        out = ops.AlignDotFunction.apply(a, t, l2norm, scaled)
+        da, dt = torch.autograd.grad(out, (a, t), dout.contiguous())
+    return da, dt, None, None
+
+
+register_autograd("tag::align_dot", _align_backward, setup_context=_align_setup)
+
+
+# ------------------------------------------------------------------------------------------------ L1 frame BCE
+@custom_op("tag::frame_bce", mutates_args=())
+def frame_bce(frame_sim: Tensor, label: Tensor, length: Tensor, Tt: int) -> Tensor:
+    """FrameBceLoss over the first Tt frames, masked by clamp(length, 1, Tt): -> 0-dim loss."""
+    frame_sim, label = ops._chk(frame_sim, "frame_sim"), ops._chk(label, "label")
+    loss = frame_sim.new_empty(1)
+    ops.call("tag_frame_bce_forward", ops.ptr(frame_sim), frame_sim.shape[1], ops.ptr(label), label.shape[1], ops.ptr(length),
+             frame_sim.shape[0], Tt, ops.ptr(loss))
+    return loss.view(())
+
+
+@frame_bce.register_fake
+def _(frame_sim, label, length, Tt):
+    return frame_sim.new_empty(())
+
+
+@custom_op("tag::frame_bce_backward", mutates_args=())
+def frame_bce_backward(frame_sim: Tensor, label: Tensor, length: Tensor, Tt: int, dloss: Tensor) -> Tensor:
+    ds = torch.empty_like(frame_sim)
+    ops.call("tag_frame_bce_backward", ops.ptr(frame_sim), frame_sim.shape[1], ops.ptr(label), label.shape[1], ops.ptr(length),
+             frame_sim.shape[0], Tt, ops.ptr(dloss.reshape(1).contiguous()), ops.ptr(ds))
+    return ds
+
+
+@frame_bce_backward.register_fake
+def _(frame_sim, label, length, Tt, dloss):
+    return torch.empty_like(frame_sim)
+
+
+def _bce_setup(ctx, inputs, output):
+    frame_sim, label, length, Tt = inputs
+    ctx.save_for_backward(frame_sim, label, length)
+    ctx.Tt = Tt
+
+
+def _bce_backward(ctx, dloss):
+    frame_sim, label, length = ctx.saved_tensors
+    return torch.ops.tag.frame_bce_backward(frame_sim, label, length, ctx.Tt, dloss), None, None, None
+
+
+register_autograd("tag::frame_bce", _bce_backward, setup_context=_bce_setup)
+
+
+# ------------------------------------------------------------------------------------------------ P1 segments
+@custom_op("tag::segments", mutates_args=())
+def segments(frame_sim: Tensor, thresholds: Tensor, window_size: int, n_connect: int) -> Tuple[Tensor, Tensor]:
+    """binarize -> median filter -> connect clusters -> contiguous regions for every (clip, threshold):
+    regions (B,NT,ceil(T/2),2) int64 rows [onset, offset), counts (B,NT) int32."""
+    return ops.segments(frame_sim, thresholds, window_size, n_connect)
+
+
+@segments.register_fake
+def _(frame_sim, thresholds, window_size, n_connect):
+    B, T = frame_sim.shape
+    NT = thresholds.numel()
+    return (torch.empty(B, NT, (T + 1) // 2, 2, device=frame_sim.device, dtype=torch.int64),
+            torch.empty(B, NT, device=frame_sim.device, dtype=torch.int32))
+
+
+OP_NAMES = ["logmel", "conv3x3", "conv3x3_dgrad", "conv3x3_wgrad", "gru_bidir", "gru_bidir_backward", "embed_mean",
+            "embed_mean_backward", "frame_match", "frame_match_backward", "align_dot", "frame_bce", "frame_bce_backward",
+            "segments"]

@@ -84,8 +84,10 @@ def test_logmel_known_answers(ops, dev, golden_dir):
         window, fb = O.frontend_tables(kind)
         db = ops.logmel(x.to(dev), p["n_fft"], p["win_length"], p["hop_length"], window.to(dev), fb.to(dev))
         ref = torch.from_numpy(gold[f"sine_{kind}"]).transpose(1, 2)          # (1,F,64)
-        strong = ref > -40.0
-        assert (db.cpu() - ref)[strong].abs().max().item() < 2e-3
+        # bins within 60 dB of the clip's peak: further down a single-precision FFT of any factorisation sits on its own
+        # rounding floor (the fp32 CPU oracle itself is 1e-3 dB off its fp64 twin at 80 dB below the peak)
+        strong = ref > ref.max() - 60.0
+        assert (db.cpu() - ref)[strong].abs().max().item() < 5e-4
     # SURVEY appendix A known answers (Cnn8Rnn set): frame 50 peak bin 17 = 23.6652 dB
     p = O.FRONTEND["cnn8rnn"]
     window, fb = O.frontend_tables("cnn8rnn")

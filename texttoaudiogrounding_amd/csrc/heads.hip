@@ -94,7 +94,7 @@ __device__ __forceinline__ float dot_rows(const Row& a, const Row& b) {
     return wave_sum(s);
 }
 
-// grid = B, block = 256: wave w handles t = w, w+4, ...
+// grid = (B, frame chunks), block = 256: wave w of chunk c handles t = 4c + w, 4c + w + 4 gridDim.y, ...
 // group = phrases per clip (MultiTextBiEncoder): text row b pairs with audio clip b / group
 __global__ __launch_bounds__(256) void match_fwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
                                                         float* __restrict__ sim, int kind, int l2norm, int scale,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(const float* __restrict_
         for (int i = 0; i < MAXD_PER_LANE; ++i) tx.v[i] *= tinv;
     }
     const float rs = scale ? 1.0f / sqrtf((float)D) : 1.0f;
-    for (int t = wid; t < T; t += 4) {
+    for (int t = blockIdx.y * 4 + wid; t < T; t += 4 * gridDim.y) {
         Row a;
         load_row(a, audio + ((size_t)b * T + t) * D, D, lane);
         if (l2norm) {
@@ -134,11 +134,12 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(const float* __restrict_
 }
 
 // backward: daudio rows directly; dtext accumulated per wave in registers, reduced through LDS
-__global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
-                                                        const float* __restrict__ dsim, float* __restrict__ daudio,
-                                                        float* __restrict__ dtext, int kind, int l2norm, int scale,
-                                                        int T, int D) {
-    __shared__ float red[4][64 * MAXD_PER_LANE];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void match_bwd_kernel(const float* __restrict__ audio, const float* __restrict__ text,
+                                                            const float* __restrict__ dsim, float* __restrict__ daudio,
+                                                            float* __restrict__ dtext, int kind, int l2norm, int scale,
+                                                            int T, int D) {
+    __shared__ float red[NW][64 * MAXD_PER_LANE];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     Row traw, tx;
     load_row(traw, text + (size_t)b * D, D, lane);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
     Row dtn;   // gradient wrt the (normalised) text vector
 #pragma unroll
     for (int i = 0; i < MAXD_PER_LANE; ++i) dtn.v[i] = 0.0f;
-    for (int t = wid; t < T; t += 4) {
+    for (int t = wid; t < T; t += NW) {
         Row araw, a;
         load_row(araw, audio + ((size_t)b * T + t) * D, D, lane);
         a = araw;
@@ -204,8 +205,12 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
     __syncthreads();
     if (wid == 0) {
 #pragma unroll
-        for (int i = 0; i < MAXD_PER_LANE; ++i)
-            dtn.v[i] = red[0][lane + 64 * i] + red[1][lane + 64 * i] + red[2][lane + 64 * i] + red[3][lane + 64 * i];
+        for (int i = 0; i < MAXD_PER_LANE; ++i) {
+            float acc = red[0][lane + 64 * i];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) acc += red[w][lane + 64 * i];      // fixed order: deterministic
+            dtn.v[i] = acc;
+        }
         if (l2norm) {
             const float ud = dot_rows(tx, dtn);
 #pragma unroll
@@ -222,14 +227,14 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
 // ---------------------------------------------------------------- frame BCE
 __device__ __forceinline__ int clamp_len(int64_t l, int Tt) { return (int)(l < 1 ? 1 : (l > Tt ? Tt : l)); }
 
-__global__ __launch_bounds__(256) void frame_bce_fwd_kernel(const float* __restrict__ sim, int ld_sim,
-                                                            const float* __restrict__ label, int ld_label,
-                                                            const int64_t* __restrict__ length, int B, int Tt,
-                                                            float* __restrict__ loss) {
-    __shared__ double sred[4];
-    __shared__ double dred[4];
+__global__ __launch_bounds__(1024) void frame_bce_fwd_kernel(const float* __restrict__ sim, int ld_sim,
+                                                             const float* __restrict__ label, int ld_label,
+                                                             const int64_t* __restrict__ length, int B, int Tt,
+                                                             float* __restrict__ loss) {
+    __shared__ double sred[16];
+    __shared__ double dred[16];
     double s = 0.0, den = 0.0;
-    for (int i = threadIdx.x; i < B * Tt; i += 256) {
+    for (int i = threadIdx.x; i < B * Tt; i += 1024) {
         const int b = i / Tt, t = i % Tt;
         if (t < clamp_len(length[b], Tt)) {
             const float p = sim[(size_t)b * ld_sim + t], y = label[(size_t)b * ld_label + t];
@@ -237,13 +242,16 @@ __global__ __launch_bounds__(256) void frame_bce_fwd_kernel(const float* __restr
             s += (double)((y - 1.0f) * lq - y * lp);
         }
     }
-    for (int b = threadIdx.x; b < B; b += 256) den += (double)clamp_len(length[b], Tt);
+    for (int b = threadIdx.x; b < B; b += 1024) den += (double)clamp_len(length[b], Tt);
     s = wave_sum_d(s);
     den = wave_sum_d(den);
     if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = s; dred[threadIdx.x >> 6] = den; }
     __syncthreads();
-    if (threadIdx.x == 0)
-        loss[0] = (float)((sred[0] + sred[1] + sred[2] + sred[3]) / (dred[0] + dred[1] + dred[2] + dred[3]));
+    if (threadIdx.x == 0) {
+        double st = 0.0, dt = 0.0;
+        for (int w = 0; w < 16; ++w) { st += sred[w]; dt += dred[w]; }
+        loss[0] = (float)(st / dt);
+    }
 }
 __global__ __launch_bounds__(256) void frame_bce_bwd_kernel(const float* __restrict__ sim, int ld_sim,
                                                             const float* __restrict__ label, int ld_label,
@@ -794,7 +802,9 @@ extern "C" int tag_match_forward(const float* audio, const float* text, float* s
                                  int B, int T, int D, void* stream) {
     TAG_CHECK_ARG(audio && text && sim && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
     TAG_CHECK_ARG(kind == 0 || kind == 1);
-    hipLaunchKernelGGL(match_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), audio, text, sim, kind, l2norm,
+    int chunks = 1;                              // enough workgroups to fill the chip: ~4 frames per wave
+    while (chunks < 16 && (long)B * chunks < 1024 && chunks * 16 < T) chunks *= 2;
+    hipLaunchKernelGGL(match_fwd_kernel, dim3(B, chunks), dim3(256), 0, as_stream(stream), audio, text, sim, kind, l2norm,
                        scale, T, D, 1);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -805,8 +815,12 @@ extern "C" int tag_match_backward(const float* audio, const float* text, const f
     (void)sim;
     TAG_CHECK_ARG(audio && text && dsim && daudio && dtext && B > 0 && T > 0 && D > 0 && D <= 64 * MAXD_PER_LANE);
     TAG_CHECK_ARG(kind == 0 || kind == 1);
-    hipLaunchKernelGGL(match_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), audio, text, dsim, daudio, dtext,
-                       kind, l2norm, scale, T, D);
+    if (T >= 32)
+        hipLaunchKernelGGL(match_bwd_kernel<8>, dim3(B), dim3(512), 0, as_stream(stream), audio, text, dsim, daudio, dtext,
+                           kind, l2norm, scale, T, D);
+    else
+        hipLaunchKernelGGL(match_bwd_kernel<4>, dim3(B), dim3(256), 0, as_stream(stream), audio, text, dsim, daudio, dtext,
+                           kind, l2norm, scale, T, D);
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -814,7 +828,7 @@ extern "C" int tag_match_backward(const float* audio, const float* text, const f
 extern "C" int tag_frame_bce_forward(const float* sim, int ld_sim, const float* label, int ld_label,
                                      const int64_t* length, int B, int Tt, float* loss, void* stream) {
     TAG_CHECK_ARG(sim && label && length && loss && B > 0 && Tt > 0 && ld_sim >= Tt && ld_label >= Tt);
-    hipLaunchKernelGGL(frame_bce_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), sim, ld_sim, label, ld_label,
+    hipLaunchKernelGGL(frame_bce_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), sim, ld_sim, label, ld_label,
                        length, B, Tt, loss);
     TAG_LAUNCH_CHECK();
     return 0;

@@ -2,16 +2,118 @@
 // torchaudio MelSpectrogram(power=2, center=True, pad_mode="reflect") -> AmplitudeToDB("power")
 // as called by models/audio_encoder.py:113-124,183-184 (Cnn8Rnn) and :29-37,68-69 (CrnnEncoder).
 //
-// One wave (64 lanes) per STFT frame, four frames per workgroup.  A frame of n_fft real samples
-// is gathered straight from the waveform (reflect padding resolved per sample, coalesced reads),
-// windowed, packed into n_fft/2 complex points, transformed by a radix-2 Stockham FFT in LDS
-// (ping-pong buffers, twiddles in an LDS table), unpacked to the n_fft/2+1 one-sided bins, squared,
-// projected on the mel filterbank (each lane owns one mel bin and walks only its non-zero band)
-// and written as dB, time-major (B, F, n_mels).  HBM traffic = waveform read once (hop/n_fft
-// re-reads hit L2) + 256 B per frame written: the kernel is bound by LDS/VALU, not by HBM.
+// One wave (64 lanes) per STFT frame, four independent frames per workgroup, NO workgroup barrier inside the frame loop:
+// every wave owns its LDS buffer and DS operations of a wave execute in order.
+//   * a frame of n_fft real samples is read straight from the waveform as coalesced 8-byte loads (two consecutive samples
+//     = one complex point; reflect padding only on the frames that touch a clip edge), multiplied by the window values the
+//     lane keeps in registers (the lane -> sample map is the same for every frame);
+//   * NC = n_fft/2 complex points go through a Stockham autosort FFT of radix-8 / radix-4 stages (512 = 8.8.8,
+//     1024 = 8.8.4.4): a lane holds its 8 / 16 points in registers, the first stage needs no LDS read, the others exchange
+//     through the wave's buffer (index padded by i/8 so that the strided scatter of the early stages is conflict-free);
+//   * real-FFT unpack -> |X|^2 -> mel projection: lane = mel bin, the non-zero band of every filter is compacted once per
+//     workgroup into LDS as fbc[i][mel] (zero padded to the widest band), so the projection is a fixed-trip loop of two
+//     conflict-free LDS reads + one FMA (terms in ascending-frequency order, like the dense sum) -> dB, time-major.
+// HBM traffic = waveform read once (hop/n_fft re-reads hit L2) + 256 B per frame written: the kernel is LDS/VALU-bound.
 #include "tag_common.h"
 
 namespace {
+
+struct c32 {
+    float x, y;
+};
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) { return {fmaf(a.x, w.x, -(a.y * w.y)), fmaf(a.x, w.y, a.y * w.x)}; }
+__device__ __forceinline__ c32 mul_mi(c32 a) { return {a.y, -a.x}; }            // a * (-i)
+
+template <int R>
+__device__ __forceinline__ void dft(c32* v);
+template <>
+__device__ __forceinline__ void dft<2>(c32* v) {
+    const c32 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft<4>(c32* v) {
+    const c32 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]), s1 = cadd(v[1], v[3]), d1 = mul_mi(csub(v[1], v[3]));
+    v[0] = cadd(s0, s1);
+    v[1] = cadd(d0, d1);
+    v[2] = csub(s0, s1);
+    v[3] = csub(d0, d1);
+}
+template <>
+__device__ __forceinline__ void dft<8>(c32* v) {
+    c32 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft<4>(e);
+    dft<4>(o);
+    const float h = 0.70710678118654752440f;
+    o[1] = {h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)};                       // * (1 - i)/sqrt2
+    o[2] = mul_mi(o[2]);
+    o[3] = {h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)};                      // * (-1 - i)/sqrt2
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        v[m] = cadd(e[m], o[m]);
+        v[m + 4] = csub(e[m], o[m]);
+    }
+}
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+
+// One Stockham stage of radix R after NS = (product of the earlier radices) points are already combined.  v[b][r] holds
+// in[j + r NC/R] for the lane's butterflies j = lane + 64 b; the results go to z (padded natural Stockham order).
+template <int NC, int R, int NS>
+__device__ __forceinline__ void stage_from_regs(c32 (*v)[R], c32* z, const c32* twn, int lane) {
+    constexpr int NB = NC / R / 64;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b;
+        const int k = j & (NS - 1);
+        if (NS > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[b][r] = cmul(v[b][r], twn[r * k * (NC / (NS * R))]);
+        }
+        dft<R>(v[b]);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) z[padi(j0 + r * NS)] = v[b][r];
+    }
+}
+
+template <int NC, int R, int NS>
+__device__ __forceinline__ void stage(c32* z, const c32* twn, int lane) {
+    constexpr int NB = NC / R / 64;
+    c32 v[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[b][r] = z[padi(lane + 64 * b + r * (NC / R))];
+    __builtin_amdgcn_wave_barrier();                    // every read of this stage precedes its writes (one buffer)
+    stage_from_regs<NC, R, NS>(v, z, twn, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NFFT>
+struct Plan;
+template <>
+struct Plan<1024> {
+    static constexpr int R0 = 8, WCAP = 96;
+    template <int NC>
+    static __device__ __forceinline__ void rest(c32* z, const c32* twn, int lane) {
+        stage<NC, 8, 8>(z, twn, lane);
+        stage<NC, 8, 64>(z, twn, lane);
+    }
+};
+template <>
+struct Plan<2048> {
+    static constexpr int R0 = 8, WCAP = 192;
+    template <int NC>
+    static __device__ __forceinline__ void rest(c32* z, const c32* twn, int lane) {
+        stage<NC, 8, 8>(z, twn, lane);
+        stage<NC, 4, 64>(z, twn, lane);
+        stage<NC, 4, 256>(z, twn, lane);
+    }
+};
 
 template <int NFFT>
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wave, int B, int S, int F,
@@ -20,123 +122,144 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                                                      const float* __restrict__ fb, int n_mels,
                                                      float* __restrict__ out_db,
                                                      float* __restrict__ power_out) {
-    constexpr int NC = NFFT / 2;      // complex points
-    constexpr int LOGNC = (NFFT == 1024) ? 9 : 10;
-    __shared__ float2 tw[NC];         // tw[k] = exp(-2 pi i k / NFFT), k < NFFT/2
-    __shared__ float2 buf[4][2][NC];  // per wave ping-pong
+    constexpr int NC = NFFT / 2;                        // complex points
+    constexpr int R0 = Plan<NFFT>::R0, NB0 = NC / R0 / 64, WCAP = Plan<NFFT>::WCAP;
+    constexpr int ZP = NC + NC / 8 + 8;                 // padded buffer length
+    __shared__ c32 twn[NC];                             // exp(-2 pi i m / NC)
+    __shared__ c32 twh[NC];                             // exp(-2 pi i k / NFFT) (real-FFT unpack)
+    __shared__ c32 zbuf[4][ZP];
+    __shared__ float fbc[WCAP][64];
+    __shared__ int band[2][64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
 
     for (int k = threadIdx.x; k < NC; k += 256) {
         float s, c;
+        sincospif(-2.0f * (float)k / (float)NC, &s, &c);
+        twn[k] = {c, s};
         sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
-        tw[k] = make_float2(c, s);
+        twh[k] = {c, s};
     }
-    // non-zero band of this lane's mel filter (data-driven: scan the column once per workgroup)
-    int lo = NC + 1, hi = -1;
-    if (lane < n_mels) {
-        for (int k = 0; k <= NC; ++k) {
-            if (fb[(size_t)k * n_mels + lane] != 0.0f) {
-                if (lo > k) lo = k;
-                hi = k;
+    if (threadIdx.x < 64) {
+        band[0][threadIdx.x] = NC + 1;
+        band[1][threadIdx.x] = -1;
+    }
+    __syncthreads();
+    // non-zero band of every mel filter (data-driven): wave w scans the rows k = w (mod 4), lanes = mel bins
+    {
+        int lo = NC + 1, hi = -1;
+        if (lane < n_mels) {
+            for (int k = wid; k <= NC; k += 4) {
+                if (fb[(size_t)k * n_mels + lane] != 0.0f) {
+                    lo = min(lo, k);
+                    hi = max(hi, k);
+                }
             }
+            atomicMin(&band[0][lane], lo);
+            atomicMax(&band[1][lane], hi);
         }
     }
     __syncthreads();
+    const int lo = band[0][lane], hi = band[1][lane];
+    for (int i = wid; i < WCAP; i += 4)
+        fbc[i][lane] = (lane < n_mels && lo + i <= hi) ? fb[(size_t)(lo + i) * n_mels + lane] : 0.0f;
+    // widest band of the workgroup's filterbank (uniform trip count of the projection loop)
+    int wmax = (lane < n_mels) ? hi - lo + 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    const int wloop = min(wmax, WCAP);
+    __syncthreads();
+
+    // the lane's window values and real-FFT unpack twiddle indices are the same for every frame
+    const int left = (NFFT - win_length) / 2;
+    float wv[NB0][R0][2];
+#pragma unroll
+    for (int b = 0; b < NB0; ++b)
+#pragma unroll
+        for (int r = 0; r < R0; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int wi = 2 * (lane + 64 * b + r * (NC / R0)) + e - left;
+                wv[b][r][e] = (wi >= 0 && wi < win_length) ? window[wi] : 0.0f;
+            }
 
     const long total = (long)B * F;
     const long stride = (long)gridDim.x * 4;
-    const long iters = (total + stride - 1) / stride;
-    const int left = (NFFT - win_length) / 2;
-    float2* z0 = buf[wid][0];
-    float2* z1 = buf[wid][1];
+    c32* z = zbuf[wid];
+    float* P = reinterpret_cast<float*>(z);             // NC + 1 floats, written after the last read of z
 
-    for (long it = 0; it < iters; ++it) {
-        const long frame = (long)blockIdx.x * 4 + wid + it * stride;
-        const bool valid = frame < total;
-        const int b = valid ? (int)(frame / F) : 0;
-        const int t = valid ? (int)(frame % F) : 0;
+    for (long frame = (long)blockIdx.x * 4 + wid; frame < total; frame += stride) {
+        const int b = (int)(frame / F);
+        const int t = (int)(frame % F);
         const float* x = wave + (size_t)b * S;
         const int start = t * hop - NFFT / 2;
-        // gather + window + pack two real samples per complex point
+        c32 v[NB0][R0];
+        if (start >= 0 && start + NFFT <= S && ((((size_t)b * S + start) & 1) == 0)) {
+            const float2* x2 = reinterpret_cast<const float2*>(x + start);
 #pragma unroll
-        for (int j = 0; j < NC / 64; ++j) {
-            const int m = lane + 64 * j;
-            float v[2];
+            for (int bb = 0; bb < NB0; ++bb)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int n = 2 * m + e;
-                int s = start + n;
-                if (s < 0) s = -s;
-                if (s >= S) s = 2 * (S - 1) - s;
-                const int wi = n - left;
-                const float w = (wi >= 0 && wi < win_length) ? window[wi] : 0.0f;
-                v[e] = valid ? x[s] * w : 0.0f;
-            }
-            z0[m] = make_float2(v[0], v[1]);
+                for (int r = 0; r < R0; ++r) {
+                    const float2 q = x2[lane + 64 * bb + r * (NC / R0)];
+                    v[bb][r] = {q.x * wv[bb][r][0], q.y * wv[bb][r][1]};
+                }
+        } else {
+#pragma unroll
+            for (int bb = 0; bb < NB0; ++bb)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    float q[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        int s = start + 2 * (lane + 64 * bb + r * (NC / R0)) + e;
+                        if (s < 0) s = -s;
+                        if (s >= S) s = 2 * (S - 1) - s;
+                        q[e] = x[s];
+                    }
+                    v[bb][r] = {q[0] * wv[bb][r][0], q[1] * wv[bb][r][1]};
+                }
         }
-        __syncthreads();
-        // radix-2 Stockham autosort FFT, LOGNC passes
-        float2* src = z0;
-        float2* dst = z1;
-#pragma unroll
-        for (int pass = 0; pass < LOGNC; ++pass) {
-            const int p = 1 << pass;
-#pragma unroll
-            for (int j = 0; j < NC / 128; ++j) {
-                const int i = lane + 64 * j;          // butterfly index < NC/2
-                const int k = i & (p - 1);
-                const int o = ((i - k) << 1) + k;
-                const float2 w = tw[k * (NC / p)];     // exp(-i pi k / p) = exp(-2 pi i k (NC/p) / NFFT)
-                const float2 u0 = src[i];
-                const float2 u1r = src[i + NC / 2];
-                const float2 u1 = make_float2(u1r.x * w.x - u1r.y * w.y, u1r.x * w.y + u1r.y * w.x);
-                dst[o] = make_float2(u0.x + u1.x, u0.y + u1.y);
-                dst[o + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
-            }
-            __syncthreads();
-            float2* tmp = src;
-            src = dst;
-            dst = tmp;
-        }
-        // src holds Z[0..NC); unpack to the one-sided spectrum and take the power.
+        stage_from_regs<NC, R0, 1>(v, z, twn, lane);
+        __builtin_amdgcn_wave_barrier();
+        Plan<NFFT>::template rest<NC>(z, twn, lane);
+        // z holds Z[0..NC) in natural order; unpack to the one-sided spectrum and take the power.
         // X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[NC-k]) / 2,  O = (Z[k] - conj Z[NC-k]) / (2i)
-        float* P = reinterpret_cast<float*>(dst);     // NC+1 floats fit in NC float2
         float pw[NC / 64 + 1];
 #pragma unroll
         for (int j = 0; j <= NC / 64; ++j) {
             const int k = lane + 64 * j;
             float val = 0.0f;
             if (k <= NC) {
-                const float2 a = src[k & (NC - 1)];
-                const float2 bq = src[(NC - k) & (NC - 1)];
+                const c32 a = z[padi(k & (NC - 1))];
+                const c32 bq = z[padi((NC - k) & (NC - 1))];
                 const float er = 0.5f * (a.x + bq.x), ei = 0.5f * (a.y - bq.y);
                 const float orr = 0.5f * (a.y + bq.y), oi = -0.5f * (a.x - bq.x);
-                float2 w = (k == NC) ? make_float2(-1.0f, 0.0f) : tw[k];
-                const float xr = er + (w.x * orr - w.y * oi);
-                const float xi = ei + (w.x * oi + w.y * orr);
-                val = xr * xr + xi * xi;
+                const c32 w = (k == NC) ? c32{-1.0f, 0.0f} : twh[k];
+                const c32 wo = cmul(c32{orr, oi}, w);
+                const float xr = er + wo.x;
+                const float xi = ei + wo.y;
+                val = fmaf(xr, xr, xi * xi);
             }
             pw[j] = val;
         }
-        __syncthreads();   // all reads of src/dst done before P overwrites dst
+        __builtin_amdgcn_wave_barrier();                // all reads of z done before P overwrites it
 #pragma unroll
         for (int j = 0; j <= NC / 64; ++j) {
             const int k = lane + 64 * j;
             if (k <= NC) P[k] = pw[j];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int i = 0; i < wloop; ++i) acc = fmaf(P[min(lo + i, NC)], fbc[i][lane], acc);
         if (lane < n_mels) {
-            float acc = 0.0f;
-            for (int k = lo; k <= hi; ++k) acc = fmaf(P[k], fb[(size_t)k * n_mels + lane], acc);
-            if (valid) {
-                const size_t o = (size_t)frame * n_mels + lane;
-                if (power_out) power_out[o] = acc;
-                // clamp(x, 1e-10) then 10 log10: the floor is exactly -100 dB (as on the CPU path)
-                out_db[o] = acc <= 1e-10f ? -100.0f : 10.0f * log10f(acc);
-            }
+            for (int k = lo + WCAP; k <= hi; ++k) acc = fmaf(P[k], fb[(size_t)k * n_mels + lane], acc);   // bands wider than WCAP
+            const size_t o = (size_t)frame * n_mels + lane;
+            if (power_out) power_out[o] = acc;
+            // clamp(x, 1e-10) then 10 log10: the floor is exactly -100 dB (as on the CPU path)
+            out_db[o] = acc <= 1e-10f ? -100.0f : 10.0f * log10f(acc);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                // P is read before the next frame's stage writes z
     }
 }
 
@@ -153,7 +276,9 @@ extern "C" int tag_logmel_forward(const float* wave, int B, int S, int n_fft, in
     const int F = S / hop + 1;
     const long total = (long)B * F;
     int grid = (int)((total + 3) / 4);
-    if (grid > 2048) grid = 2048;
+    int cus = tag_device_cu_count();
+    const int cap = 3 * (cus > 0 ? cus : 256);       // persistent workgroups: the per-workgroup table set-up is amortised
+    if (grid > cap) grid = cap;
     if (n_fft == 1024)
         hipLaunchKernelGGL(logmel_kernel<1024>, dim3(grid), dim3(256), 0, as_stream(stream), wave, B, S, F,
                            win_length, hop, window, fb, n_mels, out_db, power_out);

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Times the small (non-conv) kernels of the B=64 training step in isolation with HIP events (GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from texttoaudiogrounding_amd import ops
+from oracle import tag_oracle as O
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+which = sys.argv[1:] or ["logmel"]
+if "logmel" in which:
+    for kind, S in (("cnn8rnn", 320000), ("crnn", 320000)):
+        p = O.FRONTEND[kind]
+        window, fb = O.frontend_tables(kind)
+        wave = 0.1 * torch.randn(64, S, device=dev)
+        w, f = window.to(dev), fb.to(dev)
+        us = timeit(lambda: ops.logmel(wave, p["n_fft"], p["win_length"], p["hop_length"], w, f))
+        print(f"logmel[{kind}] B=64 x 10 s: {us:.1f} us")

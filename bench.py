@@ -286,7 +286,8 @@ def main():
                 traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
                                "measured_in_this_run": False,
                                "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
-                               "algorithmic_lower_bound_GB_per_step": round(0.164 * args.batch, 2)}
+                               "algorithmic_lower_bound_GB_per_step": round((0.082 if args.dtype == "bf16" else 0.164)
+                                                                            * args.batch, 2)}
         # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
         nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(args.conv_math, 6.0)
         peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / nprod, 1)
@@ -314,7 +315,8 @@ def main():
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math},
                "loss": round(runner.loss_value(loss), 6),
-               "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 / PEAK_FP32_MFMA, 4),
+               "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /
+                                             (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4),
                "roofline": roof}
         if alt:
             out["alt_conv_math"] = alt

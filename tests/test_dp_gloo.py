@@ -167,7 +167,7 @@ def _bf16_wire_worker(rank, world, port, out):
         from texttoaudiogrounding_amd.runner import GradBuckets
         model = _toy()
         flat = FlatParams(model)
-        bk = GradBuckets(flat, bucket_bytes=256, comm_dtype=torch.bfloat16)       # several small buckets
+        bk = GradBuckets(flat, bucket_bytes=64, comm_dtype=torch.bfloat16)        # several small buckets
         g = torch.Generator().manual_seed(7 + rank)
         local = torch.randn(flat.numel, generator=g)
         flat.grad.copy_(local)

@@ -69,8 +69,8 @@ class FlatParams:
 class GradBuckets:
     """Bucketed data-parallel gradient exchange over the flat gradient buffer.
 
-    Buckets are contiguous slices of ``flat.grad`` holding whole parameters, in parameter order, cut whenever a slice
-    reaches ``bucket_bytes``.  The autograd nodes call ``ready(params)`` when the kernels producing those gradients are
+    Buckets are contiguous slices of ``flat.grad`` holding whole parameters, in parameter order, cut (walking from the
+    last parameter to the first) whenever a slice reaches ``bucket_bytes``.  The autograd nodes call ``ready(params)`` when the kernels producing those gradients are
     enqueued and ``flush()`` at points where a collective may start; ``flush`` launches ONE asynchronous all-reduce(sum)
     per complete bucket on a communication stream that waits for the compute stream (and the wgrad side stream) as of
     that moment, so the exchange of conv_block4 runs beside the backward of conv_block3...1.  ``finish()`` (after
@@ -87,14 +87,17 @@ class GradBuckets:
         self.comm_dtype = comm_dtype
         self.cuda = flat.grad.is_cuda
         self.bounds: List[tuple] = []          # (start element, end element, first param index, last param index + 1)
-        start, first, acc = 0, 0, 0
-        for i, p in enumerate(flat.params):
-            acc += p.numel() * 4
-            last = i == len(flat.params) - 1
-            if acc >= bucket_bytes or last:
-                end = flat.offsets[i] + p.numel()
-                self.bounds.append((start, end, first, i + 1))
-                start, first, acc = end, i + 1, 0
+        # cut walking the parameters from the LAST to the first: backward produces gradients roughly in reverse parameter
+        # order, so the bucket that completes last (the first conv blocks: tiny tensors) is the small remainder and the
+        # exposed tail of the exchange is ~1 MB instead of a full bucket
+        n = len(flat.params)
+        end_i, acc = n, 0
+        for i in range(n - 1, -1, -1):
+            acc += flat.params[i].numel() * 4
+            if acc >= bucket_bytes or i == 0:
+                self.bounds.append((flat.offsets[i], flat.offsets[end_i - 1] + flat.params[end_i - 1].numel(), i, end_i))
+                end_i, acc = i, 0
+        self.bounds.reverse()
         self.bucket_of = {}
         for b, (_, _, i0, i1) in enumerate(self.bounds):
             for i in range(i0, i1):

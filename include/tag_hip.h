@@ -363,6 +363,13 @@ int tag_gate_backward(const float* dout, const float* x, const float* g, float* 
 int tag_rowdot_sigmoid_forward(const float* a, const float* b, float* sim, long rows, int D, int scale, void* stream);
 int tag_rowdot_sigmoid_backward(const float* a, const float* b, const float* dsim, float* da, float* db, long rows,
                                 int D, int scale, void* stream);
+/* Both heads with text_level="token" in general (models/match.py:16-33, 43-60): rows r = (clip, frame), one text vector per
+ * frame.  kind 0 = DotProduct (sigmoid(u.w [/sqrt(D)]).clamp(1e-7,1)), kind 1 = ExpNegL2 (exp(-||u - w||)); l2norm:
+ * u = a/max(||a||,1e-12), w likewise (F.normalize). */
+int tag_rowpair_forward(const float* a, const float* b, float* sim, long rows, int D, int kind, int l2norm, int scale,
+                        void* stream);
+int tag_rowpair_backward(const float* a, const float* b, const float* dsim, float* da, float* db, long rows, int D,
+                         int kind, int l2norm, int scale, void* stream);
 /* dtable[text[b,l]] += dtok[b,l,:] (token_emb gradient of EmbeddingLayer, models/text_encoder.py:37-43) */
 int tag_embed_tokens_backward(const float* dtok, const long* text, float* dtable, int B, int L, int D, int V,
                               void* stream);
@@ -389,8 +396,11 @@ int tag_meanmean_pool_forward(const float* sim, const long* audio_len, const lon
                               int T, int N, void* stream);
 int tag_meanmean_pool_backward(const float* dout, const long* audio_len, const long* text_len, float* dsim, int B, int T,
                                int N, void* stream);
-int tag_maxmargin_forward(const float* x /*(n,n)*/, int n, float margin, float lamda1, float* loss, void* stream);
-int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, const float* dloss, float* dx,
+/* fix_norm != 0 (the reference's default): mean over the 2 n (n-1) off-diagonal pairs; 0: the diagonal pairs stay in
+ * (losses.py:249-264) */
+int tag_maxmargin_forward(const float* x /*(n,n)*/, int n, float margin, float lamda1, int fix_norm, float* loss,
+                          void* stream);
+int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, int fix_norm, const float* dloss, float* dx,
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -407,6 +417,10 @@ int tag_attnpool_backward(const float* x, const float* w, const float* weight, c
                           float* gb, int B, int L, int D, void* stream);
 int tag_upsample_linear_forward(const float* x, float* out, long R, int T, int ratio, void* stream);
 int tag_upsample_linear_backward(const float* dout, float* dx, long R, int T, int ratio, void* stream);
+/* MultiTextBiEncoder with a cross-encoder (models/audio_text_model.py:165-168, audio_emb.unsqueeze(1).expand(-1, text_num,
+ * -1, -1).reshape): out[(b*N + n)][0..R) = x[b][0..R); backward = sum over the N copies in ascending order. */
+int tag_group_expand_forward(const float* x, float* out, long B, int N, long R, void* stream);
+int tag_group_expand_backward(const float* dout, float* dx, long B, int N, long R, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * General similarity pooling: models/utils.py:22-105 (mean/max/linear_softmax/exp_softmax _with_lens), all twelve reducers

@@ -96,6 +96,56 @@ def test_multitext_biencoder_whole_model(dev):
         assert rel(p.grad, s64[name].grad) < 1e-4, name
 
 
+def test_multitext_biencoder_with_cross_encoder(dev):
+    """MultiTextBiEncoder(cross_encoder=CrossAttentionGating, match.DotProduct(text_level='token'), pooling='max'): the
+    reference's own data flow (models/audio_text_model.py:148-215: audio repeated per phrase, (B*N)-row cross-encoder and
+    head) against the composition of the oracle pieces that the imported reference pins (cross_encoder.npz, sim_pooling.npz)."""
+    from texttoaudiogrounding_amd.losses import ClipBceLoss
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
+    from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
+    st = O.init_state(seed=23, logit_gain=30.0)
+    st.update(O.init_cross_state(7, 512))
+    batch = O.synthetic_batch(2, 48000, seed=6, ragged=True)
+    N, L = 3, 4
+    g = torch.Generator().manual_seed(2)
+    text = torch.randint(2, 5221, (2, N, L), generator=g)
+    text_len = torch.randint(1, L + 1, (2, N), generator=g)
+    for b in range(2):
+        for n in range(N):
+            text[b, n, text_len[b, n]:] = 0
+    label = (torch.rand(2, N, generator=g) < 0.5).float()
+    model = audio_text_model.MultiTextBiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                                match.DotProduct(text_level="token"), 512, text_forward_keys=["text"],
+                                                cross_encoder=CrossAttentionGating(512), pooling="max")
+    missing = model.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys and all("melspec" in k for k in missing.missing_keys)
+    model = model.to(dev).eval()
+    out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"], "text": text,
+                 "text_len": text_len, "specaug": False})
+    loss = ClipBceLoss()({"clip_sim": out["clip_sim"], "label": label})
+    loss.backward()
+    s64 = O.state_to(st, torch.float64, requires_grad=True)
+    ao = O.cnn8rnn_forward(s64, batch["waveform"].double(), batch["waveform_len"], training=False)
+    emb = s64["text_encoder.embedding.core.weight"]
+    tok = emb[text.reshape(2 * N, L)]                                                   # (B*N, L, D)
+    a_exp = ao["embedding"].unsqueeze(1).expand(-1, N, -1, -1).reshape(2 * N, *ao["embedding"].shape[1:])
+    a_len = torch.as_tensor(ao["length"]).repeat_interleave(N)
+    a2, t2 = O.cross_attention_gating(s64, a_exp, tok, a_len, text_len.reshape(-1))
+    fs = O.match_dot_product_token(a2, t2).reshape(2, N, -1).transpose(1, 2)            # (B, T', N)
+    co = O.max_with_lens(fs, torch.as_tensor(ao["length"]))
+    lo = O.clip_bce_loss(co, label.double())
+    lo.backward()
+    e_fs = (out["frame_sim"].cpu().double() - fs.detach()).abs().max().item()
+    e_cs = (out["clip_sim"].cpu().double() - co.detach()).abs().max().item()
+    print(f"MultiTextBiEncoder + CrossAttentionGating: frame_sim err {e_fs:.1e}, clip_sim err {e_cs:.1e}, "
+          f"loss {loss.item():.6f} vs {lo.item():.6f}")
+    assert e_fs < 1e-4 and e_cs < 1e-4 and abs(loss.item() - lo.item()) < 2e-5
+    for name in ("text_encoder.embedding.core.weight", "audio_encoder.fc1.weight", "audio_encoder.rnn.weight_ih_l0",
+                 "cross_encoder.attn.h2attn.weight", "cross_encoder.gating.fc_s.weight", "cross_encoder.attn.v"):
+        p = dict(model.named_parameters())[name]
+        assert rel(p.grad, s64[name].grad) < 1e-4, (name, rel(p.grad, s64[name].grad))
+
+
 def align_chain(audio, text, audio_len, text_len, margin, dev):
     from texttoaudiogrounding_amd.losses import MaxMarginRankingLoss
     from texttoaudiogrounding_amd.models import align, sim_pooling

@@ -218,6 +218,85 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
         db[r * D + d] = ds * a[r * D + d];
     }
 }
+
+// Token-level heads after a cross-encoder (models/match.py:16-33, 43-60 with text_level = "token"): one text vector per
+// frame, rows r = (clip, frame).  kind 0: sigmoid(u.w * scale).clamp(1e-7, 1); kind 1: exp(-||u - w||); u, w = the rows,
+// L2-normalised (F.normalize, eps 1e-12) when l2norm.  One wave per row; everything follows from aa, bb, ab.
+struct RowPair {
+    float ia, ib, uu, ww, uw;
+};
+__device__ __forceinline__ RowPair rowpair_sums(const float* a, const float* b, int D, int lane, int l2norm) {
+    float aa = 0.0f, bb = 0.0f, ab = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        const float x = a[d], y = b[d];
+        aa = fmaf(x, x, aa);
+        bb = fmaf(y, y, bb);
+        ab = fmaf(x, y, ab);
+    }
+    aa = wave_sum(aa);
+    bb = wave_sum(bb);
+    ab = wave_sum(ab);
+    RowPair r;
+    r.ia = l2norm ? 1.0f / fmaxf(sqrtf(aa), 1e-12f) : 1.0f;
+    r.ib = l2norm ? 1.0f / fmaxf(sqrtf(bb), 1e-12f) : 1.0f;
+    r.uu = aa * r.ia * r.ia;
+    r.ww = bb * r.ib * r.ib;
+    r.uw = ab * r.ia * r.ib;
+    return r;
+}
+__global__ __launch_bounds__(256) void rowpair_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ sim, long rows, int D, int kind, int l2norm,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const RowPair q = rowpair_sums(a + r * D, b + r * D, D, lane, l2norm);
+    float out;
+    if (kind == 0) {
+        const float p = 1.0f / (1.0f + expf(-q.uw * scale));
+        out = fminf(fmaxf(p, 1e-7f), 1.0f);
+    } else {
+        float d2 = 0.0f;                                    // sum of squared differences directly (no cancellation)
+        for (int d = lane; d < D; d += 64) { const float df = a[r * D + d] * q.ia - b[r * D + d] * q.ib; d2 = fmaf(df, df, d2); }
+        out = expf(-sqrtf(wave_sum(d2)));
+    }
+    if (lane == 0) sim[r] = out;
+}
+__global__ __launch_bounds__(256) void rowpair_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ dsim, float* __restrict__ da,
+                                                          float* __restrict__ db, long rows, int D, int kind, int l2norm,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* ar = a + r * D;
+    const float* br = b + r * D;
+    const RowPair q = rowpair_sums(ar, br, D, lane, l2norm);
+    const float g = dsim[r];
+    // du = cu_u * u + cu_w * w, dw = cw_u * u + cw_w * w
+    float cu_u, cu_w, cw_u, cw_w;
+    if (kind == 0) {
+        const float p = 1.0f / (1.0f + expf(-q.uw * scale));
+        const float pass = (p >= 1e-7f && p <= 1.0f) ? 1.0f : 0.0f;
+        const float ds = g * pass * p * (1.0f - p) * scale;
+        cu_u = 0.0f; cu_w = ds; cw_u = ds; cw_w = 0.0f;
+    } else {
+        float d2 = 0.0f;
+        for (int d = lane; d < D; d += 64) { const float df = ar[d] * q.ia - br[d] * q.ib; d2 = fmaf(df, df, d2); }
+        const float rr = sqrtf(wave_sum(d2));
+        const float k = rr > 0.0f ? -g * expf(-rr) / rr : 0.0f;
+        cu_u = k; cu_w = -k; cw_u = -k; cw_w = k;
+    }
+    // F.normalize backward: dx = (du - u (u.du)) / ||x||
+    const float u_du = cu_u * q.uu + cu_w * q.uw, w_dw = cw_u * q.uw + cw_w * q.ww;
+    for (int d = lane; d < D; d += 64) {
+        const float u = ar[d] * q.ia, w = br[d] * q.ib;
+        float du = cu_u * u + cu_w * w, dw = cw_u * u + cw_w * w;
+        if (l2norm) { du = (du - u * u_du) * q.ia; dw = (dw - w * w_dw) * q.ib; }
+        da[r * D + d] = du;
+        db[r * D + d] = dw;
+    }
+}
 }  // namespace
 
 extern "C" int tag_addattn_forward(const float* aq, const float* ak, const float* v, const float* kv, const long* qlen,
@@ -305,3 +384,20 @@ extern "C" int tag_rowdot_sigmoid_backward(const float* a, const float* b, const
     return 0;
 }
 
+
+extern "C" int tag_rowpair_forward(const float* a, const float* b, float* sim, long rows, int D, int kind, int l2norm,
+                                   int scale, void* stream) {
+    TAG_CHECK_ARG(a && b && sim && rows > 0 && D > 0 && (kind == 0 || kind == 1));
+    hipLaunchKernelGGL(rowpair_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), a, b, sim, rows, D, kind,
+                       l2norm, scale ? 1.0f / sqrtf((float)D) : 1.0f);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_rowpair_backward(const float* a, const float* b, const float* dsim, float* da, float* db, long rows,
+                                    int D, int kind, int l2norm, int scale, void* stream) {
+    TAG_CHECK_ARG(a && b && dsim && da && db && rows > 0 && D > 0 && (kind == 0 || kind == 1));
+    hipLaunchKernelGGL(rowpair_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), a, b, dsim, da, db, rows, D,
+                       kind, l2norm, scale ? 1.0f / sqrtf((float)D) : 1.0f);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

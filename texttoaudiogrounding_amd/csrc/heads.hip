@@ -722,31 +722,35 @@ __global__ __launch_bounds__(256) void upsample_lin_bwd_kernel(const float* __re
     }
 }
 
-// loss = mean over i != j of relu(m - (x_ii - x_ij)) and relu(m - (x_ii - lam x_ji))   (fix_norm = True)
+// loss = mean over i != j of relu(m - (x_ii - x_ij)) and relu(m - (x_ii - lam x_ji))   (fix_norm = True);
+// fix_norm = False keeps the diagonal pairs (i,i) too: relu(m) and relu(m - (1 - lam) x_ii), mean over 2 n^2
 __global__ __launch_bounds__(256) void maxmargin_fwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
-                                                            float* __restrict__ loss) {
+                                                            int fix_norm, float* __restrict__ loss) {
     __shared__ double sred[4];
     double s = 0.0;
     for (int e = threadIdx.x; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
-        if (i == j) continue;
+        if (i == j && fix_norm) continue;
         const float d = x[i * n + i];
         s += (double)fmaxf(margin - (d - x[i * n + j]), 0.0f) + (double)fmaxf(margin - (d - lam * x[j * n + i]), 0.0f);
     }
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (float)(((sred[0] + sred[1]) + (sred[2] + sred[3])) / (2.0 * n * (n - 1)));
+    if (threadIdx.x == 0)
+        loss[0] = (float)(((sred[0] + sred[1]) + (sred[2] + sred[3])) / (fix_norm ? 2.0 * n * (n - 1) : 2.0 * n * n));
 }
 // one wave per row i: off-diagonal dx_ij written by the owner of element (i,j); the diagonal collects its row's terms
 __global__ __launch_bounds__(256) void maxmargin_bwd_kernel(const float* __restrict__ x, int n, float margin, float lam,
-                                                            const float* __restrict__ dloss, float* __restrict__ dx) {
+                                                            int fix_norm, const float* __restrict__ dloss,
+                                                            float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    const float c = dloss[0] / (2.0f * n * (n - 1));
+    const float c = dloss[0] / (fix_norm ? 2.0f * n * (n - 1) : 2.0f * n * n);
     const float di = x[i * n + i];
     float dd = 0.0f;
+    if (!fix_norm && lane == 0 && (margin - (di - lam * di)) > 0.0f) dd = -c * (1.0f - lam);   // pair (i,i), second term
     for (int j = lane; j < n; j += 64) {
         if (j == i) continue;
         const float xij = x[i * n + j], xji = x[j * n + i], dj = x[j * n + j];
@@ -765,6 +769,28 @@ int sumsq_blocks(long n) {
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 
+
+// ---------------------------------------------------------------- MultiTextBiEncoder with a cross-encoder: audio rows x N phrases
+// out[(b*N + n)][j] = x[b][j] (the reference's unsqueeze(1).expand(-1, N, ...).reshape, models/audio_text_model.py:165-168)
+__global__ __launch_bounds__(256) void group_expand_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long B, int N,
+                                                               long R) {
+    const long total = B * N * R;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long j = i % R, b = i / (R * N);
+        out[i] = x[b * R + j];
+    }
+}
+// dx[b][j] = sum over n (ascending: deterministic) of dout[(b*N + n)][j]
+__global__ __launch_bounds__(256) void group_expand_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, long B, int N,
+                                                               long R) {
+    const long total = B * R;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long j = i % R, b = i / R;
+        float s = 0.0f;
+        for (int n = 0; n < N; ++n) s += dout[(b * N + n) * R + j];
+        dx[i] = s;
+    }
+}
 }  // namespace
 
 extern "C" int tag_embed_mean_forward(const int64_t* text, const int64_t* text_len, const float* table,
@@ -978,6 +1004,22 @@ extern "C" int tag_upsample_linear_backward(const float* dout, float* dx, long R
     TAG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int tag_group_expand_forward(const float* x, float* out, long B, int N, long R, void* stream) {
+    TAG_CHECK_ARG(x && out && B > 0 && N > 0 && R > 0);
+    const long n = B * N * R;
+    hipLaunchKernelGGL(group_expand_fwd_kernel, dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                       x, out, B, N, R);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_group_expand_backward(const float* dout, float* dx, long B, int N, long R, void* stream) {
+    TAG_CHECK_ARG(dout && dx && B > 0 && N > 0 && R > 0);
+    const long n = B * R;
+    hipLaunchKernelGGL(group_expand_bwd_kernel, dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                       dout, dx, B, N, R);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int tag_sim_pool_forward(const float* sim, const long* alen, const long* tlen, float* out, long R, int T, int N,
                                     int a_div, int t_mod, int amode, int tmode, void* stream) {
     TAG_CHECK_ARG(sim && alen && out && R > 0 && T > 0 && N > 0 && a_div > 0 && amode >= 0 && amode <= 3);
@@ -996,17 +1038,18 @@ extern "C" int tag_sim_pool_backward(const float* sim, const long* alen, const l
     TAG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int tag_maxmargin_forward(const float* x, int n, float margin, float lamda1, float* loss, void* stream) {
+extern "C" int tag_maxmargin_forward(const float* x, int n, float margin, float lamda1, int fix_norm, float* loss,
+                                     void* stream) {
     TAG_CHECK_ARG(x && loss && n > 1);
-    hipLaunchKernelGGL(maxmargin_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, loss);
+    hipLaunchKernelGGL(maxmargin_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, fix_norm, loss);
     TAG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, const float* dloss, float* dx,
-                                      void* stream) {
+extern "C" int tag_maxmargin_backward(const float* x, int n, float margin, float lamda1, int fix_norm, const float* dloss,
+                                      float* dx, void* stream) {
     TAG_CHECK_ARG(x && dloss && dx && n > 1);
-    hipLaunchKernelGGL(maxmargin_bwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, dloss,
-                       dx);
+    hipLaunchKernelGGL(maxmargin_bwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, as_stream(stream), x, n, margin, lamda1, fix_norm,
+                       dloss, dx);
     TAG_LAUNCH_CHECK();
     return 0;
 }

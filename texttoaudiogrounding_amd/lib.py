@@ -91,6 +91,8 @@ _SIGS = {
     "tag_gate_backward": (c_int, [P, P, P, P, c_int, P, c_long, P]),
     "tag_rowdot_sigmoid_forward": (c_int, [P, P, P, c_long, c_int, c_int, P]),
     "tag_rowdot_sigmoid_backward": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
+    "tag_rowpair_forward": (c_int, [P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
+    "tag_rowpair_backward": (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
     "tag_embed_tokens_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_match_group_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_match_group_backward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -98,8 +100,8 @@ _SIGS = {
     "tag_linear_softmax_pool_backward": (c_int, [P, P, P, P, c_long, c_int, c_int, P]),
     "tag_meanmean_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "tag_meanmean_pool_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
-    "tag_maxmargin_forward": (c_int, [P, c_int, c_float, c_float, P, P]),
-    "tag_maxmargin_backward": (c_int, [P, c_int, c_float, c_float, P, P, P]),
+    "tag_maxmargin_forward": (c_int, [P, c_int, c_float, c_float, c_int, P, P]),
+    "tag_maxmargin_backward": (c_int, [P, c_int, c_float, c_float, c_int, P, P, P]),
     "tag_frame_bce_forward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
     "tag_frame_bce_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),
@@ -125,6 +127,8 @@ _SIGS = {
     "tag_attnpool_backward": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_upsample_linear_forward": (c_int, [P, P, c_long, c_int, c_int, P]),
     "tag_upsample_linear_backward": (c_int, [P, P, c_long, c_int, c_int, P]),
+    "tag_group_expand_forward": (c_int, [P, P, c_long, c_int, c_long, P]),
+    "tag_group_expand_backward": (c_int, [P, P, c_long, c_int, c_long, P]),
     "tag_sumsq_ws_bytes": (c_size_t, [c_long]),
     "tag_sumsq": (c_int, [P, c_long, P, P, P]),
     "tag_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P, c_float, c_float, P]),

@@ -40,12 +40,10 @@ class MaxMarginRankingLoss(nn.Module):
 
     def __init__(self, margin=1, fix_norm=True, lamda1=1, sim_key="sim"):
         super().__init__()
-        if not fix_norm:
-            raise NotImplementedError("the HIP path implements fix_norm=True (the reference's default)")
         self.fix_norm, self.margin, self.lamda1, self.sim_key = fix_norm, margin, lamda1, sim_key
 
     def forward(self, x):
-        return ops.MaxMarginFunction.apply(x[self.sim_key], self.margin, self.lamda1)
+        return ops.MaxMarginFunction.apply(x[self.sim_key], self.margin, self.lamda1, self.fix_norm)
 
 
 class ClipFrameBceLoss(nn.Module):

@@ -79,10 +79,8 @@ class MultiTextBiEncoder(BiEncoder):
                  add_proj: bool = False, upsample: bool = False, freeze_audio_encoder: bool = False,
                  freeze_text_encoder: bool = False, safe_size: Optional[int] = None, pretrained: Optional[str] = None,
                  output_fn=print):
-        if cross_encoder is not None:
-            raise NotImplementedError("MultiTextBiEncoder with a cross-encoder is not on the HIP path yet")
         super().__init__(audio_encoder=audio_encoder, text_encoder=text_encoder, match_fn=match_fn, shared_dim=shared_dim,
-                         cross_encoder=None, add_proj=add_proj, upsample=upsample,
+                         cross_encoder=cross_encoder, add_proj=add_proj, upsample=upsample,
                          freeze_audio_encoder=freeze_audio_encoder, freeze_text_encoder=freeze_text_encoder)
         self.text_forward_keys = list(text_forward_keys)
         if "text_len" not in self.text_forward_keys:
@@ -94,10 +92,51 @@ class MultiTextBiEncoder(BiEncoder):
         if pretrained is not None and type(self) is MultiTextBiEncoder:
             self.load_pretrained(pretrained, output_fn)
 
+    def _pool(self, sim, B, N, length):
+        len_dev = torch.as_tensor(length).long().to(sim.device).contiguous()
+        # linear_softmax / max / mean / exp_softmax _with_lens over the valid frames (models/audio_text_model.py:205-215)
+        clip_sim = ops.SimPoolFunction.apply(sim.view(B * N, -1, 1), len_dev, None, N, 1, ops.POOL_MODES[self.pooling],
+                                             -1).view(B, N)
+        if self.interpolate_ratio != 1 and self.upsample:                                    # models/audio_text_model.py:216-224
+            sim = ops.UpsampleLinearFunction.apply(sim, self.interpolate_ratio)
+            length = length * self.interpolate_ratio
+        frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
+        return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}
+
+    def _forward_general(self, input_dict):
+        """The reference's own data flow (models/audio_text_model.py:148-203): the audio embedding repeated for the N phrases
+        of its clip, (B*N)-row cross-encoder and head.  Taken with a cross-encoder or a head other than the grouped
+        DotProduct; ``safe_size`` chunking is unnecessary (the heads are row kernels, nothing is materialised per chunk)."""
+        audio_output = self.audio_encoder(input_dict)
+        audio_emb = audio_output["embedding"]
+        if hasattr(self, "audio_proj"):
+            audio_emb = ops.LinearFunction.apply(audio_emb, self.audio_proj.weight, self.audio_proj.bias)
+        B = audio_emb.size(0)
+        N = input_dict[self.text_forward_keys[0]].shape[1]
+        text_forward_dict = {}
+        for key in self.text_forward_keys:
+            x = torch.as_tensor(input_dict[key])
+            text_forward_dict[key] = x.reshape(x.shape[0] * x.shape[1], *x.shape[2:])
+        text_emb = self.text_encoder(text_forward_dict)
+        length = audio_output["length"]
+        forward_dict = {"audio_emb": ops.GroupExpandFunction.apply(audio_emb, N), "text_emb": text_emb,
+                        "audio_len": torch.as_tensor(length).repeat_interleave(N),
+                        "text_len": text_forward_dict["text_len"]}
+        if self.cross_encoder is not None:
+            forward_dict.update(self.cross_encoder(forward_dict))
+        if hasattr(self, "text_proj"):
+            text_emb = forward_dict["text_emb"]
+            for k in ("seq_emb", "token_emb"):
+                if k in text_emb:
+                    text_emb[k] = ops.LinearFunction.apply(text_emb[k], self.text_proj.weight, self.text_proj.bias)
+        sim = self.match_fn(forward_dict)                                                     # (B*N, T')
+        return self._pool(sim.contiguous(), B, N, length)
+
     def forward(self, input_dict):
         from .match import DotProduct
-        if not isinstance(self.match_fn, DotProduct) or self.match_fn.l2norm or self.match_fn.text_level != "seq":
-            raise NotImplementedError("MultiTextBiEncoder on the HIP path: match.DotProduct(l2norm=False, text_level='seq')")
+        if (self.cross_encoder is not None or not isinstance(self.match_fn, DotProduct) or self.match_fn.l2norm
+                or self.match_fn.text_level != "seq"):
+            return self._forward_general(input_dict)
         audio_output = self.audio_encoder(input_dict)
         audio_emb = audio_output["embedding"]
         if hasattr(self, "audio_proj"):
@@ -113,16 +152,7 @@ class MultiTextBiEncoder(BiEncoder):
         if hasattr(self, "text_proj"):
             seq = ops.LinearFunction.apply(seq, self.text_proj.weight, self.text_proj.bias)
         sim = ops.MatchGroupFunction.apply(audio_emb, seq, N, self.match_fn.scale)            # (B*N, T')
-        length = audio_output["length"]
-        len_dev = torch.as_tensor(length).long().to(sim.device).contiguous()
-        # linear_softmax / max / mean / exp_softmax _with_lens over the valid frames (models/audio_text_model.py:205-215)
-        clip_sim = ops.SimPoolFunction.apply(sim.view(B * N, -1, 1), len_dev, None, N, 1, ops.POOL_MODES[self.pooling],
-                                             -1).view(B, N)
-        if self.interpolate_ratio != 1 and self.upsample:                                    # models/audio_text_model.py:216-224
-            sim = ops.UpsampleLinearFunction.apply(sim, self.interpolate_ratio)
-            length = length * self.interpolate_ratio
-        frame_sim = sim.view(B, N, -1).transpose(1, 2)                                       # (B, T', N)
-        return {"frame_sim": frame_sim, "clip_sim": clip_sim, "length": length}
+        return self._pool(sim, B, N, audio_output["length"])
 
 
 class AudioTextAlignByWord(nn.Module):
@@ -166,10 +196,8 @@ class AudioTextAlignByPhrase(nn.Module):
     def __init__(self, audio_encoder, text_encoder, match_fn, sim_pooling, shared_dim, cross_encoder=None, add_proj=False,
                  freeze_audio_encoder=False, freeze_text_encoder=False):
         super().__init__()
-        if cross_encoder is not None:
-            raise NotImplementedError("AudioTextAlignByPhrase with a cross-encoder is not on the HIP path")
         self.audio_encoder, self.text_encoder, self.match_fn = audio_encoder, text_encoder, match_fn
-        self.cross_encoder, self.sim_pooling = None, sim_pooling
+        self.cross_encoder, self.sim_pooling = cross_encoder, sim_pooling        # stored and never applied, as in the reference (:925, :936-976)
         if audio_encoder.embed_dim != text_encoder.embed_dim or add_proj:
             self.audio_proj = nn.Linear(audio_encoder.embed_dim, shared_dim)
             self.text_proj = nn.Linear(text_encoder.embed_dim, shared_dim)

@@ -4,10 +4,14 @@ import torch.nn as nn
 from .. import ops
 
 
-def _seq_text(input_dict, text_level):
-    if text_level != "seq":
-        raise NotImplementedError("the HIP heads implement text_level='seq' (the strong/BiEncoder path)")
-    return input_dict["text_emb"]["seq_emb"]
+def _token_text(input_dict):
+    """text_level='token': the reference broadcasts audio (B,T,D) against token_emb, which only type-checks when there is one
+    text vector per frame (the cross-encoder's output, (B,T,D)) -- the same restriction holds here, loudly."""
+    text = input_dict["text_emb"]["token_emb"]
+    if text.shape != input_dict["audio_emb"].shape:
+        raise RuntimeError(f"text_level='token' needs one text vector per audio frame (a cross-encoder output): audio "
+                           f"{tuple(input_dict['audio_emb'].shape)} vs token_emb {tuple(text.shape)}")
+    return text
 
 
 class ExpNegL2(nn.Module):
@@ -17,8 +21,9 @@ class ExpNegL2(nn.Module):
         self.text_level = text_level
 
     def forward(self, input_dict):
-        return ops.MatchFunction.apply(input_dict["audio_emb"], _seq_text(input_dict, self.text_level), 1,
-                                       self.l2norm, False)
+        if self.text_level == "token":
+            return ops.RowPairFunction.apply(input_dict["audio_emb"], _token_text(input_dict), 1, self.l2norm, False)
+        return ops.MatchFunction.apply(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 1, self.l2norm, False)
 
 
 class DotProduct(nn.Module):
@@ -31,13 +36,11 @@ class DotProduct(nn.Module):
     def forward(self, input_dict):
         if self.text_level == "token":
             # after a cross-encoder the text is one vector per frame (B,T,D): (audio * text).sum(-1)  (models/match.py:53-59)
-            text = input_dict["text_emb"]["token_emb"]
-            if self.l2norm or text.shape != input_dict["audio_emb"].shape:
-                raise NotImplementedError("token-level DotProduct is implemented for the cross-encoder output "
-                                          "(text (B,T,D), l2norm=False)")
+            text = _token_text(input_dict)
+            if self.l2norm:
+                return ops.RowPairFunction.apply(input_dict["audio_emb"], text, 0, True, self.scale)
             return ops.RowDotFunction.apply(input_dict["audio_emb"], text, self.scale)
-        return ops.MatchFunction.apply(input_dict["audio_emb"], _seq_text(input_dict, self.text_level), 0,
-                                       self.l2norm, self.scale)
+        return ops.MatchFunction.apply(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 0, self.l2norm, self.scale)
 
 
 class CrossAttention(nn.Module):

@@ -1235,6 +1235,29 @@ class RowDotFunction(torch.autograd.Function):
         return da, dt, None
 
 
+class RowPairFunction(torch.autograd.Function):
+    """Either head with text_level='token' in general (models/match.py:16-33, 43-60): text (B,T,D) holds one vector per frame.
+    kind 0 = DotProduct, 1 = ExpNegL2; optional F.normalize of both operands."""
+
+    @staticmethod
+    def forward(ctx, audio, text, kind, l2norm, scale):
+        a, t = _chk(audio, "audio_emb"), _chk(text, "token_emb")
+        B, T, D = a.shape
+        sim = _empty(B, T, like=a)
+        call("tag_rowpair_forward", ptr(a), ptr(t), ptr(sim), B * T, D, int(kind), int(bool(l2norm)), int(bool(scale)))
+        ctx.save_for_backward(a, t)
+        ctx.cfg = (int(kind), int(bool(l2norm)), int(bool(scale)))
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, t = ctx.saved_tensors
+        B, T, D = a.shape
+        da, dt = torch.empty_like(a), torch.empty_like(t)
+        call("tag_rowpair_backward", ptr(a), ptr(t), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), B * T, D, *ctx.cfg)
+        return da, dt, None, None, None
+
+
 class MatchGroupFunction(torch.autograd.Function):
     """DotProduct head of MultiTextBiEncoder (models/audio_text_model.py:150-190): N phrases per clip scored against the
     same audio embedding.  audio (B,T,D), text (B*N,D) -> sim (B*N,T)."""
@@ -1354,6 +1377,28 @@ class UpsampleLinearFunction(torch.autograd.Function):
         return dx, None
 
 
+class GroupExpandFunction(torch.autograd.Function):
+    """(B, ...) -> (B*N, ...): every clip's rows repeated for its N phrases (MultiTextBiEncoder with a cross-encoder,
+    models/audio_text_model.py:165-168); backward sums the N copies in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        xs = _chk(x, "audio_emb")
+        B = xs.shape[0]
+        R = xs.numel() // B
+        out = _empty(B * n, *xs.shape[1:], like=xs)
+        call("tag_group_expand_forward", ptr(xs), ptr(out), B, int(n), R)
+        ctx.cfg = (xs.shape, int(n), R)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, n, R = ctx.cfg
+        dx = torch.empty(shape, device=dout.device, dtype=F32)
+        call("tag_group_expand_backward", ptr(_chk(dout, "grad")), ptr(dx), shape[0], n, R)
+        return dx, None
+
+
 class SimPoolFunction(torch.autograd.Function):
     """General similarity pooling (tag_sim_pool_*): sim (R,T,N) -> (R) or, with tmode = -1, (R,N).
     amode 0 mean / 1 max / 2 linear_softmax / 3 exp_softmax over the frames < alen[r // a_div];
@@ -1385,21 +1430,22 @@ TEXT_MODES = {"mean": 0, "sum": 1, "max": 2, "mean_sum": 3}
 
 
 class MaxMarginFunction(torch.autograd.Function):
-    """MaxMarginRankingLoss(fix_norm=True) (losses.py:226-264) on an (n,n) similarity matrix."""
+    """MaxMarginRankingLoss (losses.py:226-264) on an (n,n) similarity matrix; fix_norm drops the diagonal pairs."""
 
     @staticmethod
-    def forward(ctx, x, margin, lamda1):
+    def forward(ctx, x, margin, lamda1, fix_norm=True):
         xs = _chk(x, "sim")
         n = xs.shape[0]
         loss = _empty(1, like=xs)
-        call("tag_maxmargin_forward", ptr(xs), n, float(margin), float(lamda1), ptr(loss))
+        call("tag_maxmargin_forward", ptr(xs), n, float(margin), float(lamda1), int(bool(fix_norm)), ptr(loss))
         ctx.save_for_backward(xs)
-        ctx.cfg = (float(margin), float(lamda1))
+        ctx.cfg = (float(margin), float(lamda1), int(bool(fix_norm)))
         return loss.view(())
 
     @staticmethod
     def backward(ctx, dloss):
         (xs,) = ctx.saved_tensors
         dx = torch.empty_like(xs)
-        call("tag_maxmargin_backward", ptr(xs), xs.shape[0], ctx.cfg[0], ctx.cfg[1], ptr(_chk(dloss.reshape(1), "grad")), ptr(dx))
-        return dx, None, None
+        call("tag_maxmargin_backward", ptr(xs), xs.shape[0], ctx.cfg[0], ctx.cfg[1], ctx.cfg[2],
+             ptr(_chk(dloss.reshape(1), "grad")), ptr(dx))
+        return dx, None, None, None

@@ -1534,8 +1534,8 @@ extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, flo
 
 static bool wgrad_alltaps_ok(int W) { return conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64); }
 // all-taps kernel: K slices (in chunks of 32 pixels) so that ~1024 workgroups (2 rounds of 2 per CU) are launched
-static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split) {
-    const int cw = W >= 32 ? 32 : W, ch = 32 / cw;
+static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split, int chunk_px = 32) {
+    const int cw = W >= 32 ? 32 : W, ch = chunk_px / cw;
     const int chunks = B * ((H + ch - 1) / ch) * (W / cw);
     const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64);
     int s = 1024 / tiles;
@@ -1546,8 +1546,8 @@ static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_pe
 }
 
 // shared with conv_x3.hip (same K split and the same deterministic reduction)
-int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split) {
-    return alltaps_splits(B, H, W, Cin, Cout, chunks_per_split);
+int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split, int chunk_px) {
+    return alltaps_splits(B, H, W, Cin, Cout, chunks_per_split, chunk_px);
 }
 int tag_launch_wgrad_reduce(const float* partial, int splits, int Cin, int Cout, float* dw, hipStream_t st) {
     const long nred = (long)9 * Cin * Cout;

@@ -23,6 +23,14 @@
 #ifndef TAG_WX3_PIN
 #define TAG_WX3_PIN 0
 #endif
+// k16 steps per chunk of the bf16-storage wgrad kernel (chunk = 16 x this many pixels)
+#ifndef TAG_WX3_KS16
+#define TAG_WX3_KS16 4
+#endif
+// depth of the weight-fragment ring of the ONE-product (plain bf16) forward/dgrad kernels (3, 6, 9 or 18)
+#ifndef TAG_X3_RING1
+#define TAG_X3_RING1 9
+#endif
 
 namespace {
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     constexpr int QSH = HS16 ? 2 : 3;
     constexpr int ITEMS = (G::PH * (TW + 2) * QPP + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* Ss = reinterpret_cast<float*>(smem + 3 * G::PLANE);    // [2][Cin]
+    float* Ss = reinterpret_cast<float*>(smem + NSPL * G::PLANE); // [2][Cin]  (one-product kernels allocate ONE plane)
 
     const int n_tiles = Cout / BN_;
     const int row_tiles = (H + G::TH - 1) / G::TH;
@@ -217,8 +225,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // weight fragments: ring of 3 k16 steps (18 steps per chunk = 6 turns of the ring), loaded 2 steps ahead
-    u32x4 bq[3][NSPL];
+    // weight fragments: ring of RING k16 steps (18 steps per chunk = a whole number of turns), loaded RING-1 steps ahead.
+    // With six products a step lasts ~770 MFMA cycles and 2 steps of distance cover the L2 latency; with ONE product a step is
+    // 128 cycles, so the one-product kernels keep 8 steps (~1000 cycles) in flight.
+    constexpr int RING = NP == 1 ? TAG_X3_RING1 : 3;
+    static_assert(18 % RING == 0, "ring must divide the 18 steps of a chunk");
+    u32x4 bq[RING][NSPL];
     auto issue_b = [&](int cc, int step, int slot) {              // step = tap*2 + ks inside chunk cc
         const int tap = step >> 1, ks = step & 1;
         const u32x4* p = wlane + ((size_t)(tap * KK + cc * 2 + ks) * NBK) * 192;
@@ -228,8 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
 
     const int cchunks = Cin / KC;
     issue_patch(0);
-    issue_b(0, 0, 0);
-    issue_b(0, 1, 1);
+#pragma unroll
+    for (int st = 0; st < RING - 1; ++st) issue_b(0, st, st);
     __syncthreads();                                              // Ss visible
     store_patch(0);
     __syncthreads();
@@ -261,11 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int hidx = 0; hidx < NH; ++hidx) {
-            const int step = hidx / HS, hb = (hidx % HS) * 2, slot = step % 3;
+            const int step = hidx / HS, hb = (hidx % HS) * 2, slot = step % RING;
             const bool newstep = hidx % HS == 0;
-            if (newstep) {                                        // weights of step+2 (possibly of the next chunk)
-                if (step + 2 < 18) issue_b(cc, step + 2, (step + 2) % 3);
-                else if (more) issue_b(cc + 1, step + 2 - 18, (step + 2) % 3);
+            if (newstep) {                                        // weights of step+RING-1 (possibly of the next chunk)
+                constexpr int D = RING - 1;
+                if (step + D < 18) issue_b(cc, step + D, (step + D) % RING);
+                else if (more) issue_b(cc + 1, step + D - 18, (step + D) % RING);
             }
             if (hidx + 1 < NH) load_a(hidx + 1, afb[(hidx + 1) & 1]);
 #pragma unroll
@@ -388,15 +401,18 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __rest
 // LDS image: X planes [split 3][ci block 2][ring row][PW pixels][32 ch bf16 = 64 B]; dY planes [2 buffers][split 3]
 // [co block 2][32 pixels][64 B]: the 4 pixels x 64 B of a transposing read are contiguous -> conflict-free.
 // ------------------------------------------------------------------------------------------
-template <int TW>
+// KS = k16 MFMA steps per chunk (chunk = 16 KS pixels): 2 for the split arithmetics; the one-product kernels take 4 (a chunk
+// then carries 36 MFMAs per wave instead of 18 between two barriers / two rounds of index arithmetic -- with one product
+// per operand pair the 32-pixel chunk was barrier- and VALU-bound: MFMA busy 0.28).  NSP = split planes held in LDS.
+template <int TW, int KS = 2, int NSP = 3>
 struct WX3Geom {
-    static constexpr int CW = TW >= 32 ? 32 : TW, CH = 32 / CW, PW = CW + 2, R = 2 * CH + 2;
+    static constexpr int CPX = 16 * KS;
+    static constexpr int CW = TW >= 32 ? 32 : TW, CH = CPX / CW, PW = CW + 2, R = 2 * CH + 2;
     static constexpr int XROWB = PW * 64;                                       // bytes of one ring row in one plane
     static constexpr int XPL = R * XROWB + ((R * XROWB) % 256 == 0 ? 128 : 0);  // plane stride = 128 (mod 256)
-    static constexpr int YPL = 32 * 64;
-    static constexpr int XBYTES = 6 * XPL, YBYTES = 6 * YPL;                    // per dY buffer
+    static constexpr int YPL = CPX * 64;
+    static constexpr int XBYTES = 2 * NSP * XPL, YBYTES = 2 * NSP * YPL;        // per dY buffer
     static constexpr int LDS_BYTES = XBYTES + 2 * YBYTES;
-    static constexpr int XITEMS = (CH * PW * 16 + 255) / 256;                   // (pixel, channel quad) items of CH new rows
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -413,13 +429,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
                                                                   const TS* __restrict__ dy,
                                                                   float* __restrict__ partial, int B, int H, int W,
                                                                   int Cin, int Cout, int splits, int chunks_per_split) {
-    using G = WX3Geom<TW>;
-    constexpr int CW = G::CW, CH = G::CH, PW = G::PW, R = G::R;
     constexpr int NSPL = NP == 1 ? 1 : 3;
     constexpr bool HS16 = Act<TS>::is_bf16;                      // bf16 tensors: items are (pixel, channel OCTET) of 16 B
+    constexpr int KS = HS16 ? TAG_WX3_KS16 : 2;                  // k16 steps per chunk (fp32 staging registers do not fit more)
+    using G = WX3Geom<TW, KS, NSPL>;
+    constexpr int CW = G::CW, CH = G::CH, PW = G::PW, R = G::R;
     static_assert(!HS16 || NP == 1, "bf16 storage goes with the one-product arithmetic");
     constexpr int QPP = HS16 ? 8 : 16, QSH = HS16 ? 3 : 4;       // items per pixel (64 channels)
-    constexpr int XITEMS = (CH * PW * QPP + 255) / 256, DITEMS = 32 * QPP / 256;
+    constexpr int XITEMS = (CH * PW * QPP + 255) / 256, DITEMS = G::CPX * QPP / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Xs = smem;
     unsigned char* Ys = smem + G::XBYTES;
@@ -601,38 +618,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
             rowb[j] = (unsigned)(sl * G::XROWB);
         }
         const unsigned char* yb = Ys + ((c - cbeg) & 1) * G::YBYTES + vb;
-        constexpr int NQ = NSPL == 1 ? 6 : 18;
+        constexpr int NQ = (NSPL == 1 ? 3 : 9) * KS;
         auto plane_of = [](int q) { return NSPL == 1 ? 0 : 2 - (q % 3); };          // lo (2), mid (1), hi (0)
         auto load_a = [&](int q, u32x4 (&af)[3]) {
             const int g = NSPL == 1 ? q : q / 3, s = g / 3, ky = g % 3, sp = plane_of(q);
-            unsigned arow;
+            unsigned arow;                                        // k16 step s = pixels 16 s .. 16 s + 15 of the chunk
             if (CW == 8) arow = kl ? rowb[2 * s + 1 + ky] : rowb[2 * s + ky];
             else if (CW == 16) arow = rowb[s + ky];
-            else arow = rowb[ky];
+            else arow = rowb[(s >> 1) + ky];
             const unsigned char* xa = Xs + va + arow;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int imm = sp * 2 * G::XPL + (kx + (CW == 32 ? s * 16 : 0)) * 64;
+                const int imm = sp * 2 * G::XPL + (kx + (CW == 32 ? (s & 1) * 16 : 0)) * 64;
                 const u32x2 t0 = lds_tr_read(xa + imm);
                 const u32x2 t1 = lds_tr_read(xa + imm + 256);
                 af[kx] = (u32x4){t0.x, t0.y, t1.x, t1.y};
             }
         };
+        // dY fragments of k16 step s: two live sets (this step's and the next one's, read while this step's MFMAs run)
         u32x4 bf[2][NSPL];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
+        auto load_b = [&](int s, u32x4 (&b)[NSPL]) {
 #pragma unroll
             for (int sp = 0; sp < NSPL; ++sp) {
                 const u32x2 t0 = lds_tr_read(yb + sp * 2 * G::YPL + s * 1024);
                 const u32x2 t1 = lds_tr_read(yb + sp * 2 * G::YPL + s * 1024 + 256);
-                bf[s][sp] = (u32x4){t0.x, t0.y, t1.x, t1.y};
+                b[sp] = (u32x4){t0.x, t0.y, t1.x, t1.y};
             }
+        };
+        load_b(0, bf[0]);
         u32x4 afb[2][3];
         load_a(0, afb[0]);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int QPS = NQ / KS;                              // plane-steps per k16 step
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int g = NSPL == 1 ? q : q / 3, s = g / 3, ky = g % 3, sp = plane_of(q);
+            if (q % QPS == 0 && s + 1 < KS) load_b(s + 1, bf[(s + 1) & 1]);
             if (q + 1 < NQ) load_a(q + 1, afb[(q + 1) & 1]);
             // b planes paired with this a plane, smallest product first
             int nb = 0, bl[3] = {0, 0, 0};
@@ -647,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
                 if (b >= nb) continue;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    acc[ky * 3 + kx] = mfma_bf16(afb[q & 1][kx], bf[s][bl[b]], acc[ky * 3 + kx]);
+                    acc[ky * 3 + kx] = mfma_bf16(afb[q & 1][kx], bf[s & 1][bl[b]], acc[ky * 3 + kx]);
             }
             // pin: the 6 transposing reads of the next plane-step are spread over this step's MFMAs
             const int nm = 3 * nb;
@@ -727,7 +748,7 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
     using G = X3Geom<TW>;
     constexpr int BN_ = MB == 4 ? 128 : 64;
     const int grid = B * ((H + G::TH - 1) / G::TH) * (Cout / BN_);
-    const size_t lds = G::LDS_BYTES;
+    const size_t lds = (NP == 1 ? 1 : 3) * G::PLANE + 2 * 512 * 4;
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
@@ -760,7 +781,7 @@ void launch_x3_w(const TS* x, const u32x4* wp, int pro, const float* s, const fl
 template <int TW, int NP, class TS = float>
 void launch_wgrad_x3(const TS* x, int pro, const float* s, const float* t, const TS* dy, float* partial, int B,
                      int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
-    using G = WX3Geom<TW>;
+    using G = WX3Geom<TW, Act<TS>::is_bf16 ? TAG_WX3_KS16 : 2, NP == 1 ? 1 : 3>;
     const int grid = (Cin / 64) * (Cout / 64) * splits;
     const size_t lds = G::LDS_BYTES;
 #define LAUNCH_PRO(P)                                                                                                \
@@ -857,7 +878,8 @@ extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int
 
 extern "C" size_t tag_conv3x3_wgrad_x3_ws_bytes(int B, int H, int W, int Cin, int Cout) {
     int cps;
-    return (size_t)tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps) * 9 * Cin * Cout * sizeof(float);
+    const int s32 = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps, 32), s64 = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps, 64);
+    return (size_t)(s32 > s64 ? s32 : s64) * 9 * Cin * Cout * sizeof(float);
 }
 
 extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* in_scale, const float* in_shift,
@@ -872,8 +894,8 @@ extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* i
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);
     int cps;
-    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps);
     const int np = x3_products(products);
+    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps, 32);
     if (np == 6) launch_wgrad_x3_w<6>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else if (np == 9) launch_wgrad_x3_w<9>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
     else launch_wgrad_x3_w<1>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
@@ -893,7 +915,7 @@ extern "C" int tag_conv3x3_wgrad_x3_bf16(const void* x, int prologue, const floa
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);
     int cps;
-    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps);
+    const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps, 16 * TAG_WX3_KS16);
     launch_wgrad_x3_w<1, bf16_t>(static_cast<const bf16_t*>(x), prologue, in_scale, in_shift, static_cast<const bf16_t*>(dy),
                                  partial, B, H, W, Cin, Cout, sp, cps, st);
     TAG_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ void tag_set_error(const char* fmt, ...);
     } while (0)
 
 // conv.hip internals shared with conv_x3.hip (not part of the C ABI)
-int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split);
+int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_per_split, int chunk_px = 32);
 int tag_launch_wgrad_reduce(const float* partial, int splits, int Cin, int Cout, float* dw, hipStream_t st);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -470,11 +470,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
 
     u32x4 rx[XITEMS], rd[DITEMS];
     unsigned xok = 0, dok = 0;
-    // chunk index -> (img, h0, w0); row blocks run fastest so that consecutive chunks walk down a strip
-    auto origin = [&](int c, int& img, int& h0, int& w0) {
+    // chunk index -> (img, h0, w0); row blocks run fastest so that consecutive chunks walk down a strip.  The main loop touches
+    // chunks c, c+1, c+2 per iteration: their origins are kept in a 3-entry window advanced by increments (two runtime integer
+    // divisions per call were a visible share of the one-product kernel's issue time); anything else divides.
+    auto origin_div = [&](int c, int& img, int& h0, int& w0) {
         const int rbk = c % rb_per_img; const int t = c / rb_per_img;
         const int cbk = t % cb_per_row; img = t / cb_per_row;
         h0 = rbk * CH; w0 = cbk * CW;
+    };
+    int ob = -4, o_img[3] = {0, 0, 0}, o_h[3] = {0, 0, 0}, o_w[3] = {0, 0, 0};
+    auto origin_next = [&](int img, int h0, int w0, int& img2, int& h2, int& w2) {
+        h2 = h0 + CH; w2 = w0; img2 = img;
+        if (h2 >= rb_per_img * CH) {
+            h2 = 0; w2 = w0 + CW;
+            if (w2 >= TW) { w2 = 0; img2 = img + 1; }
+        }
+    };
+    auto window_set = [&](int c) {
+        ob = c;
+        origin_div(c, o_img[0], o_h[0], o_w[0]);
+        origin_next(o_img[0], o_h[0], o_w[0], o_img[1], o_h[1], o_w[1]);
+        origin_next(o_img[1], o_h[1], o_w[1], o_img[2], o_h[2], o_w[2]);
+    };
+    auto window_advance = [&]() {
+        ++ob;
+        o_img[0] = o_img[1]; o_h[0] = o_h[1]; o_w[0] = o_w[1];
+        o_img[1] = o_img[2]; o_h[1] = o_h[2]; o_w[1] = o_w[2];
+        origin_next(o_img[1], o_h[1], o_w[1], o_img[2], o_h[2], o_w[2]);
+    };
+    auto origin = [&](int c, int& img, int& h0, int& w0) {
+        const int d = c - ob;
+        if (d == 0) { img = o_img[0]; h0 = o_h[0]; w0 = o_w[0]; }
+        else if (d == 1) { img = o_img[1]; h0 = o_h[1]; w0 = o_w[1]; }
+        else if (d == 2) { img = o_img[2]; h0 = o_h[2]; w0 = o_w[2]; }
+        else origin_div(c, img, h0, w0);
     };
     auto load_rows = [&](int img, int first_row, int w0) {       // CH input rows [first_row, first_row+CH), PW columns
         const long ibase = (long)img * H * W;
@@ -691,8 +720,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
         }
     };
 
-    auto fresh = [&](int c) { return c % rb_per_img == 0; };
+    auto fresh = [&](int c) { int i_, h_, w_; origin(c, i_, h_, w_); return h_ == 0; };   // first chunk of a strip
     if (cbeg < cend) {
+        window_set(cbeg);
         prime(cbeg);
         issue_chunk(cbeg);
         store_chunk(cbeg);
@@ -715,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
             __syncthreads();
             if (c + 2 < cend && !fresh(c + 2)) issue_chunk(c + 2);
         }
+        window_advance();
     }
     // partial[split][tap][ci][co]
 #pragma unroll

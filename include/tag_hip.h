@@ -488,6 +488,15 @@ int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, const float
                                   const float* invstd, const float* gamma, const void* dout, void* dy, float* dgamma,
                                   float* dbeta, int B, int H, int W, int C, int ph, int pw, float drop_p, uint64_t seed,
                                   int bn_train, void* ws, void* stream);
+/* bf16 twins of tag_conv3x3_dgrad_bnsums / tag_bnrelu_backward_apply (BASELINE configs[2] mode): the sums are taken from the
+ * fp32 accumulators of the dgrad conv before its output is rounded to bf16; bnpart rows [P][2][Cout],
+ * P = tag_conv3x3_x3_stats_rows(B,H,W,Cout). */
+int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, void* da, const void* yref, const float* bn_scale,
+                                  const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart,
+                                  int B, int H, int W, int Cin, int Cout, void* stream);
+int tag_bnrelu_backward_apply_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const float* gamma, const void* da, void* dy,
+                                   const float* dgamma, const float* dbeta, long rows, int C, int bn_train, void* stream);
 int tag_bnrelu_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
                              const float* invstd, const float* gamma, const void* da, void* dy, float* dgamma,
                              float* dbeta, long rows, int C, int bn_train, void* ws, void* stream);

@@ -531,6 +531,42 @@ def test_conv_dgrad_fused_bnrelu_backward(ops, dev, B, H, W, Cin, C):
     assert relerr(dy, dy2) < 2e-6 and relerr(dg, dg2) < 2e-6 and relerr(db, db2) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cin,C", [(2, 9, 8, 64, 128), (1, 17, 16, 128, 64), (2, 21, 32, 64, 64), (2, 33, 64, 64, 64),
+                                         (3, 250, 8, 512, 512)])
+def test_conv_dgrad_fused_bnrelu_backward_bf16(ops, dev, monkeypatch, B, H, W, Cin, C):
+    """BASELINE configs[2] mode: tag_conv3x3_dgrad_bnsums_bf16 (sums from the fp32 accumulators of the bf16 dgrad conv) +
+    tag_bnrelu_backward_apply_bf16 against (a) the unfused bf16 kernels and (b) the fp64 chain on the same bf16 tensors."""
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    g = torch.Generator().manual_seed(H * W + C + 1)
+    bf = lambda t: t.bfloat16().float()
+    y = bf(torch.randn(B, C, H, W, generator=g) * (1.0 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.3)
+    w = bf(torch.randn(Cin, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    du = bf(torch.randn(B, Cin, H, W, generator=g))
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.1, 1e-5))
+    F.conv2d(a, w.double(), padding=1).backward(du.double())
+    yh = nhwc(y).to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gamma.to(dev), beta.to(dev), None, None, True)
+    _, wd = ops.pack_conv_weight(w.to(dev), W=W)
+    assert wd.dtype == torch.uint8 and wd.products == 1
+    yb, dub = yh.bfloat16(), nhwc(du).to(dev).bfloat16()
+    dy, dg, db = ops.conv3x3_dgrad_bnrelu_backward(dub, wd, yb, st, gamma.to(dev))
+    assert dy.dtype == torch.bfloat16
+    monkeypatch.setattr(ops, "FUSE_BN_BWD_SUMS", False)
+    dy2, dg2, db2 = ops.conv3x3_dgrad_bnrelu_backward(dub, wd, yb, st, gamma.to(dev))
+    e_un = (relerr(dy.float(), dy2.float()), relerr(dg, dg2), relerr(db, db2))
+    e_64 = (relerr(nchw(dy.float()), yd.grad), relerr(dg, gd.grad), relerr(db, bd.grad))
+    e_64u = (relerr(nchw(dy2.float()), yd.grad), relerr(dg2, gd.grad), relerr(db2, bd.grad))
+    print(f"bf16 fused dgrad+BN backward vs unfused {e_un[0]:.1e} {e_un[1]:.1e} {e_un[2]:.1e}; vs fp64: fused "
+          f"{e_64[0]:.1e} {e_64[1]:.1e} {e_64[2]:.1e}, unfused {e_64u[0]:.1e} {e_64u[1]:.1e} {e_64u[2]:.1e}")
+    # dgamma / dbeta: sums over >= 1000 pixels of values whose bf16 rounding (2^-9) the fused path skips -> it must be at least
+    # as close to fp64 as the unfused path (up to noise), and both agree to a few 1e-3; dy carries one bf16 rounding
+    assert e_64[1] < max(2 * e_64u[1], 2e-3) and e_64[2] < max(2 * e_64u[2], 2e-3)
+    assert e_un[1] < 1e-2 and e_un[2] < 1e-2 and e_64[0] < 2e-2 and e_un[0] < 2e-2
+
+
 @pytest.mark.parametrize("pre", [0, 1])
 def test_bn_act_backward(ops, dev, pre):
     """BatchNorm in front of a conv (CrnnEncoder cdur_block): u = bn(pre(x)), pre = identity | leaky_relu(0.1)."""

@@ -958,6 +958,18 @@ extern "C" int tag_bnrelu_backward_apply(const float* y, const float* scale, con
     return 0;
 }
 
+extern "C" int tag_bnrelu_backward_apply_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                              const float* invstd, const float* gamma, const void* da, void* dy,
+                                              const float* dgamma, const float* dbeta, long rows, int C, int bn_train,
+                                              void* stream) {
+    TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && da && dy && dgamma && dbeta && vec_ok(C));
+    BnReluBwdFnT<bf16_t> fn{static_cast<const bf16_t*>(y), scale, shift, mean, invstd, static_cast<const bf16_t*>(da), C};
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(apply_blocks(rows, C)), dim3(256), 0, as_stream(stream), fn,
+                       gamma, dgamma, dbeta, bn_train, rows, static_cast<bf16_t*>(dy));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream) {
     TAG_CHECK_ARG(mask && n > 0);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), seed, n, p, mask);

@@ -105,12 +105,22 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // TS = activation storage of x and y: float, or bf16_t (BASELINE configs[2]: bf16 tensors; NP == 1 only) -- then the
 // patch is staged as (pixel, channel OCTET) items of 16 B, copied to LDS as they are when there is no prologue, and the
 // output is rounded to bf16 (nearest-even) and stored as channel pairs.
-template <int MB, int PRO, int TW, int NP, class TS = float>
+// Epilogue operands of the bf16 dgrad launches (EPI == 1), as in conv.hip: the tensor whose BatchNorm+ReLU the gradient
+// flows into next; the epilogue then writes the per-tile sums of g = da*[bn(yref) > 0] and g*xhat instead of output statistics.
+struct BnBwdEpiX {
+    const bf16_t* yref;     // (B,H,W,Cout) raw conv output saved by the forward pass (= BatchNorm input), bf16
+    const float* scale;     // gamma * invstd
+    const float* shift;     // beta - mean * gamma * invstd
+    const float* mean;
+    const float* invstd;
+};
+
+template <int MB, int PRO, int TW, int NP, class TS = float, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict__ x, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, TS* __restrict__ y,
-                                                            float* __restrict__ stats, int B, int H, int W, int Cin,
-                                                            int Cout) {
+                                                            float* __restrict__ stats, BnBwdEpiX epi, int B, int H, int W,
+                                                            int Cin, int Cout) {
     using G = X3Geom<TW>;
     constexpr bool HS16 = Act<TS>::is_bf16;
     static_assert(!HS16 || NP == 1, "bf16 storage goes with the one-product arithmetic");
@@ -325,8 +335,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                 if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
             }
         }
+    // ---- EPI == 1: the reduction half of the BatchNorm+ReLU backward this gradient flows into (conv.hip, EPI == 1): per wave
+    // M-group and channel sum(g) and sum(g * xhat), g taken from the fp32 accumulators; rows [prow][2][Cout] ----
+    if (EPI == 1) {
+        constexpr int MG = MB == 4 ? 1 : 2;
+        const int prow = mt * MG + wm;
+        float* ps = stats + (size_t)prow * 2 * Cout;
+        const float sc = epi.scale[n], sh = epi.shift[n], mu = epi.mean[n], is = epi.invstd[n];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            float yv[16];                                         // 16 loads in flight, then their arithmetic
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ty, tx;
+                pix_to_yx<TW>((wm * MB + i) * 32 + row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl), ty, tx);
+                const int h = h0 + ty, hc = h < H ? h : H - 1;
+                yv[r] = Act<bf16_t>::ld1(epi.yref + (((size_t)img * H + hc) * W + tx) * Cout + n);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float g = (okrow[i][r] && fmaf(yv[r], sc, sh) > 0.0f) ? acc[i][r] : 0.0f;
+                s1 += g;
+                s2 = fmaf(g, (yv[r] - mu) * is, s2);
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (kl == 0) { ps[n] = s1; ps[Cout + n] = s2; }
+    }
     // ---- fused BatchNorm statistics (see conv.hip): one partial row per wave M-group (MB * 32 pixels) ----
-    if (stats) {
+    if (EPI == 0 && stats) {
         constexpr int MG = MB == 4 ? 1 : 2;
         const int prow = mt * MG + wm;
         float* ps = stats + (size_t)prow * 3 * Cout;
@@ -775,7 +814,7 @@ static int x3_products(int requested) {
 
 template <int MB, int TW, int NP, class TS = float>
 void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
-               int H, int W, int Cin, int Cout, hipStream_t st) {
+               int H, int W, int Cin, int Cout, hipStream_t st, const BnBwdEpiX* epi = nullptr) {
     using G = X3Geom<TW>;
     constexpr int BN_ = MB == 4 ? 128 : 64;
     const int grid = B * ((H + G::TH - 1) / G::TH) * (Cout / BN_);
@@ -789,7 +828,20 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
             attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP, TS>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
-                           B, H, W, Cin, Cout);                                                                     \
+                           BnBwdEpiX{}, B, H, W, Cin, Cout);                                                        \
+    }
+    if constexpr (NP == 1 && Act<TS>::is_bf16) {
+        if (epi) {                                                // dgrad + BatchNorm-backward sums (prologue 0 only)
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats,
+                               *epi, B, H, W, Cin, Cout);
+            return;
+        }
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;
@@ -802,11 +854,11 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
 
 template <int MB, int NP, class TS = float>
 void launch_x3_w(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
-                 int H, int W, int Cin, int Cout, hipStream_t st) {
-    if (W == 8) launch_x3<MB, 8, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else if (W == 16) launch_x3<MB, 16, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else if (W == 32) launch_x3<MB, 32, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
-    else launch_x3<MB, 64, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st);
+                 int H, int W, int Cin, int Cout, hipStream_t st, const BnBwdEpiX* epi = nullptr) {
+    if (W == 8) launch_x3<MB, 8, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else if (W == 16) launch_x3<MB, 16, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else if (W == 32) launch_x3<MB, 32, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else launch_x3<MB, 64, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
 }
 
 template <int TW, int NP, class TS = float>
@@ -903,6 +955,27 @@ extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int
     bf16_t* yo = static_cast<bf16_t*>(y);
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
     else launch_x3_w<2, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16 dgrad + the reduction half of the BatchNorm+ReLU backward its output flows into (the bf16 twin of
+// tag_conv3x3_dgrad_bnsums): bnpart rows [P][2][Cout], P = tag_conv3x3_x3_stats_rows; fold with tag_bn_grad_from_partials.
+extern "C" int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, void* da, const void* yref,
+                                             const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                             const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
+                                             void* stream) {
+    TAG_CHECK_ARG(dy && wpack && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && B > 0 && H > 0);
+    TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
+    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
+    TAG_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32));
+    hipStream_t st = as_stream(stream);
+    const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
+    const bf16_t* xi = static_cast<const bf16_t*>(dy);
+    bf16_t* yo = static_cast<bf16_t*>(da);
+    const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd};
+    if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
+    else launch_x3_w<2, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
     TAG_LAUNCH_CHECK();
     return 0;
 }

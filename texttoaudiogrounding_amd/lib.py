@@ -114,6 +114,8 @@ _SIGS = {
     "tag_bnrelu_pool_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                               c_float, c_uint64, c_int, P, P]),
     "tag_bnrelu_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
+    "tag_conv3x3_dgrad_bnsums_bf16": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_bnrelu_backward_apply_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P]),
     "tag_mean_w_forward_bf16": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_mean_w_backward_bf16": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_mha_cross_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),

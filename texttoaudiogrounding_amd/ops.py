@@ -267,6 +267,24 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     C = yref.shape[3]
     fused = (FUSE_BN_BWD_SUMS and wpack.dtype != torch.uint8 and st.train and W in (8, 16, 32, 64)
              and query("tag_conv3x3_stats_rows", B, H, W, C) > 0)
+    if (FUSE_BN_BWD_SUMS and dy_in.dtype == BF16 and wpack.dtype == torch.uint8 and wpack.products == 1 and st.train
+            and yref.dtype == BF16 and W in (8, 16, 32, 64)):
+        # BASELINE configs[2] mode: the same fusion on the one-product bf16 kernels (sums from the fp32 accumulators)
+        P = query("tag_conv3x3_x3_stats_rows", B, H, W, C)
+        da = _empty(B, H, W, C, like=dy_in, dtype=BF16)
+        part = _empty(P * 2 * C, like=dy_in)
+        with _timed(("conv3x3_x3_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+            call("tag_conv3x3_dgrad_bnsums_bf16", ptr(dy_in), ptr(wpack.blob), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
+                 ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C)
+        if after_conv is not None:
+            after_conv()
+        dg = dg_out if dg_out is not None else _empty(C, like=da)
+        db = db_out if db_out is not None else _empty(C, like=da)
+        ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), da)
+        call("tag_bn_grad_from_partials", ptr(part), P, C, ptr(dg), ptr(db), ptr(ws))
+        call("tag_bnrelu_backward_apply_bf16", ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+             ptr(gamma), ptr(da), ptr(da), ptr(dg), ptr(db), B * H * W, C, int(st.train))
+        return da, dg, db
     if not fused:
         da = conv3x3(dy_in, wpack, C)
         if after_conv is not None:

@@ -246,7 +246,9 @@ def main():
                 "bf16": "BASELINE configs[2] as a mode (python bench.py --dtype bf16): conv operands bf16, one product, f32 "
                         "accumulate; raw conv outputs, pooled activations and their gradients STORED as bf16; BatchNorm "
                         "statistics, GRU, heads, loss, Adam and master weights f32"}
-        for mode in ("x3", "bf16"):
+        desc["x9"] = ("fp32 operands split exactly into 3 bf16 terms, ALL 9 partial products on v_mfma_f32_32x32x16_bf16 (every "
+                      "partial product exact, f32 accumulate; forward, dgrad and wgrad convs; opt-in TAG_CONV_MATH=x9)")
+        for mode in ("x3", "x9", "bf16"):
             ops.CONV_MATH = mode
             ops.ACT_DTYPE = "bf16" if mode == "bf16" else "fp32"
             runner.train_step(dict(batch))

@@ -108,7 +108,9 @@ size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout);
  * made with products == 1 must only be used with products == 1 (its hi plane is rounded, not truncated). */
 int tag_pack_conv_weight_x3(const float* w /*(Cout,Cin,3,3)*/, void* wfwd, void* wdgrad, int Cin, int Cout,
                             int products, void* stream);
-int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout);      /* same contract as tag_conv3x3_stats_rows */
+int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout);
+/* the same for the bf16-storage entry points (*_x3_bf16, tag_conv3x3_dgrad_bnsums_bf16): their 64-cout layers use 256-pixel tiles */
+int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cout);      /* same contract as tag_conv3x3_stats_rows */
 int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                            const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
                            int products, void* stream);
@@ -215,6 +217,11 @@ int tag_mean_w_backward(const float* dout, long rows, int W, int C, float drop_p
  * MxN tile count cannot fill the chip (weight gradients: K = B*T); 0 bytes = not needed. */
 size_t tag_gemm_ws_bytes(int M, int N, int K);
 int tag_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C,
+             int ldc, int M, int N, int K, const float* bias, int act, int accumulate, void* ws,
+             void* stream);
+/* tag_gemm with both operands rounded to bf16 (nearest-even) on v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32 tensors:
+ * what autocast does to nn.Linear / the GRU projections in BASELINE configs[2] (bf16).  Same arguments, same workspace. */
+int tag_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C,
              int ldc, int M, int N, int K, const float* bias, int act, int accumulate, void* ws,
              void* stream);
 /* out[n] = sum_m x[m, n] (bias gradients); x (M,N) ld; ws >= tag_colsum_ws_bytes */

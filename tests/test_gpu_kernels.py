@@ -648,6 +648,28 @@ def test_gemm(ops, dev, M, N, K, ta, tb):
     assert relerr(cs, out2.cpu().double().sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(750, 512, 512, False, True), (300, 1536, 512, False, True), (768, 512, 4000, True, False),
+                                         (100, 96, 40, False, False), (129, 65, 33, True, True)])
+def test_gemm_bf16_mode(ops, dev, monkeypatch, M, N, K, ta, tb):
+    """tag_gemm_bf16 (BASELINE configs[2] mode): equal to the fp64 product of the bf16-ROUNDED operands up to fp32 accumulation
+    (products of bf16 values are exact in fp32), and within bf16 rounding of the fp32 product."""
+    monkeypatch.setattr(ops, "GEMM_MATH", "bf16")
+    g = torch.Generator().manual_seed(M + N + 1)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    r = lambda t: t.bfloat16().double()
+    ref = (r(A).t() if ta else r(A)) @ (r(Bm).t() if tb else r(Bm))
+    out = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb)
+    assert relerr(out, ref) < 2e-6
+    out2 = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb, bias=bias.to(dev), act=1)
+    assert relerr(out2, F.relu(ref + bias.double())) < 2e-6
+    exact = (A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double())
+    assert relerr(out, exact) < 2e-2 * math.sqrt(K) / math.sqrt(K)          # one bf16 rounding per operand
+    monkeypatch.setattr(ops, "GEMM_MATH", "fp32")
+    assert relerr(ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb), exact) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (18, 6, 512, 256), (64, 40, 512, 256), (5, 33, 128, 128),
                                      (130, 5, 64, 256)])

@@ -27,6 +27,12 @@
 #ifndef TAG_WX3_KS16
 #define TAG_WX3_KS16 4
 #endif
+// 32-pixel MFMA blocks per wave of the bf16-storage launches on the 64-cout layers: 2 = 128 px x 64 co tiles, 4 = 256 px x 64 co.
+// Measured at B = 64: 4 is SLOWER (conv forward+dgrad 5.24 vs 4.84 ms per step: the prologue variants need 176 VGPRs and lose
+// a residency level), so 2 stays the default.
+#ifndef TAG_X3_BF16_MB64
+#define TAG_X3_BF16_MB64 2
+#endif
 // depth of the weight-fragment ring of the ONE-product (plain bf16) forward/dgrad kernels (3, 6, 9 or 18)
 #ifndef TAG_X3_RING1
 #define TAG_X3_RING1 9
@@ -41,9 +47,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int KC = 32;            // channels per LDS chunk (2 k16 MFMA steps)
 constexpr int PIXB = 80;          // bytes per pixel per plane in LDS
 
-template <int TW>
+template <int TW, int TP = 128>                                   // TP = output pixels per workgroup tile
 struct X3Geom {
-    static constexpr int TH = 128 / TW, PH = TH + 2;
+    static constexpr int TH = TP / TW, PH = TH + 2;
     static constexpr int S = TW == 8 ? 12 : TW + 2;               // patch row stride in pixels
     static constexpr int PP = PH * S;
     static constexpr int PLANE = PP * PIXB;                       // bytes per plane
@@ -115,16 +121,20 @@ struct BnBwdEpiX {
     const float* invstd;
 };
 
-template <int MB, int PRO, int TW, int NP, class TS = float, int EPI = 0>
+// WM = waves along M: 1 (4 waves side by side along N: tile MB*32 px x 128 co) or 2 (2 x 2 waves: tile 2*MB*32 px x 64 co).
+// MB = 2, WM = 2 is the 128 px x 64 co tile of the 64-cout layers; the bf16-storage launches take MB = 4, WM = 2
+// (256 px x 64 co) there: with one product per operand pair a 128 x 64 tile is 2 chunks x 18 short steps of work behind a
+// full HBM round trip (MFMA busy 0.17-0.20), the larger tile halves the fixed cost per output and the weight re-reads.
+template <int MB, int PRO, int TW, int NP, class TS = float, int EPI = 0, int WM = (MB == 4 ? 1 : 2)>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict__ x, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, TS* __restrict__ y,
                                                             float* __restrict__ stats, BnBwdEpiX epi, int B, int H, int W,
                                                             int Cin, int Cout) {
-    using G = X3Geom<TW>;
+    using G = X3Geom<TW, WM * MB * 32>;
     constexpr bool HS16 = Act<TS>::is_bf16;
     static_assert(!HS16 || NP == 1, "bf16 storage goes with the one-product arithmetic");
-    constexpr int BN_ = MB == 4 ? 128 : 64;
+    constexpr int BN_ = (4 / WM) * 32;
     constexpr int NSPL = NP == 1 ? 1 : 3;                         // planes actually read
     constexpr int QPP = HS16 ? 4 : 8;                             // staging items per pixel: octets (16 B bf16) | quads (16 B fp32)
     constexpr int QSH = HS16 ? 2 : 3;
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     const int img = mt / row_tiles, h0 = (mt % row_tiles) * G::TH;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = MB == 4 ? 0 : (wid >> 1);                      // M group of the wave
-    const int wn = MB == 4 ? wid : (wid & 1);                     // 32-cout block of the wave
+    const int wm = WM == 1 ? 0 : (wid >> 1);                      // M group of the wave
+    const int wn = WM == 1 ? wid : (wid & 1);                     // 32-cout block of the wave
     const int kl = lane >> 5, ml = lane & 31;
     if (PRO != 0)
         for (int c = tid; c < Cin; c += 256) { Ss[c] = in_scale[c]; Ss[Cin + c] = in_shift[c]; }
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     // ---- EPI == 1: the reduction half of the BatchNorm+ReLU backward this gradient flows into (conv.hip, EPI == 1): per wave
     // M-group and channel sum(g) and sum(g * xhat), g taken from the fp32 accumulators; rows [prow][2][Cout] ----
     if (EPI == 1) {
-        constexpr int MG = MB == 4 ? 1 : 2;
+        constexpr int MG = WM;
         const int prow = mt * MG + wm;
         float* ps = stats + (size_t)prow * 2 * Cout;
         const float sc = epi.scale[n], sh = epi.shift[n], mu = epi.mean[n], is = epi.invstd[n];
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     }
     // ---- fused BatchNorm statistics (see conv.hip): one partial row per wave M-group (MB * 32 pixels) ----
     if (EPI == 0 && stats) {
-        constexpr int MG = MB == 4 ? 1 : 2;
+        constexpr int MG = WM;
         const int prow = mt * MG + wm;
         float* ps = stats + (size_t)prow * 3 * Cout;
         float cnt = 0.0f, s1 = 0.0f;
@@ -812,33 +822,33 @@ static int x3_products(int requested) {
     return v;
 }
 
-template <int MB, int TW, int NP, class TS = float>
+template <int MB, int TW, int NP, class TS = float, int WM = (MB == 4 ? 1 : 2)>
 void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
                int H, int W, int Cin, int Cout, hipStream_t st, const BnBwdEpiX* epi = nullptr) {
-    using G = X3Geom<TW>;
-    constexpr int BN_ = MB == 4 ? 128 : 64;
+    using G = X3Geom<TW, WM * MB * 32>;
+    constexpr int BN_ = (4 / WM) * 32;
     const int grid = B * ((H + G::TH - 1) / G::TH) * (Cout / BN_);
     const size_t lds = (NP == 1 ? 1 : 3) * G::PLANE + 2 * 512 * 4;
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, P, TW, NP, TS>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, P, TW, NP, TS, 0, WM>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP, TS>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
+        hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP, TS, 0, WM>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
                            BnBwdEpiX{}, B, H, W, Cin, Cout);                                                        \
     }
     if constexpr (NP == 1 && Act<TS>::is_bf16) {
         if (epi) {                                                // dgrad + BatchNorm-backward sums (prologue 0 only)
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1, WM>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set = true;
             }
-            hipLaunchKernelGGL((conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats,
+            hipLaunchKernelGGL((conv3x3_x3_kernel<MB, 0, TW, NP, TS, 1, WM>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats,
                                *epi, B, H, W, Cin, Cout);
             return;
         }
@@ -852,13 +862,13 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
 #undef LAUNCH_PRO
 }
 
-template <int MB, int NP, class TS = float>
+template <int MB, int NP, class TS = float, int WM = (MB == 4 ? 1 : 2)>
 void launch_x3_w(const TS* x, const u32x4* wp, int pro, const float* s, const float* t, TS* y, float* stats, int B,
                  int H, int W, int Cin, int Cout, hipStream_t st, const BnBwdEpiX* epi = nullptr) {
-    if (W == 8) launch_x3<MB, 8, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
-    else if (W == 16) launch_x3<MB, 16, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
-    else if (W == 32) launch_x3<MB, 32, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
-    else launch_x3<MB, 64, NP, TS>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    if (W == 8) launch_x3<MB, 8, NP, TS, WM>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else if (W == 16) launch_x3<MB, 16, NP, TS, WM>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else if (W == 32) launch_x3<MB, 32, NP, TS, WM>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
+    else launch_x3<MB, 64, NP, TS, WM>(x, wp, pro, s, t, y, stats, B, H, W, Cin, Cout, st, epi);
 }
 
 template <int TW, int NP, class TS = float>
@@ -917,6 +927,13 @@ extern "C" int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout) {
     return B * ((H + th - 1) / th) * (Cout % 128 == 0 ? 1 : 2);
 }
 
+// rows of the statistics / BatchNorm-backward partials written by the bf16-STORAGE launches (256-pixel tiles on the 64-cout layers)
+extern "C" int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cout) {
+    if (!(W == 8 || W == 16 || W == 32 || W == 64)) return 0;
+    const int th = (Cout % 128 == 0 ? 128 : 64 * TAG_X3_BF16_MB64) / W;
+    return B * ((H + th - 1) / th) * (Cout % 128 == 0 ? 1 : 2);
+}
+
 extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                                       const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin,
                                       int Cout, int products, void* stream) {
@@ -954,7 +971,7 @@ extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int
     const bf16_t* xi = static_cast<const bf16_t*>(x);
     bf16_t* yo = static_cast<bf16_t*>(y);
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
-    else launch_x3_w<2, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
+    else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
     TAG_LAUNCH_CHECK();
     return 0;
 }
@@ -975,7 +992,7 @@ extern "C" int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, 
     bf16_t* yo = static_cast<bf16_t*>(da);
     const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd};
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
-    else launch_x3_w<2, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
+    else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -82,7 +82,13 @@ struct Epilogue {
     int sc_T, sc_N, sc_B;
 };
 
-template <bool AKC, bool BKC, int T>
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+
+// BF = false: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  BF = true (BASELINE configs[2] mode, tag_gemm_bf16): the same fp32
+// tensors and the same LDS image, but the fragments are rounded to bf16 (nearest-even) on their way from LDS to the registers
+// and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what autocast does to nn.Linear / the GRU projections.
+template <bool AKC, bool BKC, int T, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                    Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
@@ -127,6 +133,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             sb.load(B, ldb, n0, N, kbeg + (it + 1) * GK, kend, b_al);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BF) {
+            // lane (kl, ml) of a 32x32x16 fragment holds k = 8 kl .. 8 kl + 7 of row ml: eight LDS words, packed pairwise
+            const float* a = As + buf * ASZ + 8 * kl * LDSA + wm0 + ml;
+            const float* b = Bs + buf * BSZ + 8 * kl * LDSB + wn0 + ml;
+#pragma unroll
+            for (int ks = 0; ks < GK / 16; ++ks) {
+                gemm_u32x4 af[TT], bfr[TT];
+#pragma unroll
+                for (int i = 0; i < TT; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = a[(16 * ks + e) * LDSA + i * 32];
+                    af[i] = (gemm_u32x4){tag_pack_bf16(v[0], v[1]), tag_pack_bf16(v[2], v[3]), tag_pack_bf16(v[4], v[5]),
+                                         tag_pack_bf16(v[6], v[7])};
+                }
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = b[(16 * ks + e) * LDSB + j * 32];
+                    bfr[j] = (gemm_u32x4){tag_pack_bf16(v[0], v[1]), tag_pack_bf16(v[2], v[3]), tag_pack_bf16(v[4], v[5]),
+                                          tag_pack_bf16(v[6], v[7])};
+                }
+#pragma unroll
+                for (int i = 0; i < TT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gemm_bf16x8, af[i]),
+                                                                            __builtin_bit_cast(gemm_bf16x8, bfr[j]), acc[i][j],
+                                                                            0, 0, 0);
+            }
+        } else {
         const float* a = As + buf * ASZ + kl * LDSA + wm0 + ml;
         const float* b = Bs + buf * BSZ + kl * LDSB + wn0 + ml;
         float af[2][TT], bf[2][TT];
@@ -151,6 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             if (ks + 1 < GK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < kiters) {
@@ -216,21 +255,21 @@ int gemm_splits(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
-template <bool AKC, bool BKC, int T>
+template <bool AKC, bool BKC, int T, bool BF = false>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st) {
     constexpr int ASZ = ((GK * Stage<AKC, T>::LD + 3) / 4) * 4, BSZ = ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = ((M + T - 1) / T) * ((N + T - 1) / T) * splits;
     int kchunk = (K + splits - 1) / splits;
     kchunk = (kchunk + GK - 1) / GK * GK;
-    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
                        a_al, b_al, splits, kchunk, partial);
     if (splits > 1) {
         long nb = ((long)M * N + 255) / 256;
@@ -240,7 +279,7 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
 }
 
 int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc, int M,
-                int N, int K, Epilogue ep, float* ws, hipStream_t st) {
+                int N, int K, Epilogue ep, float* ws, hipStream_t st, bool bf = false) {
     const int splits = (ws && !ep.scatter) ? gemm_splits(M, N, K) : 1;
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
@@ -249,8 +288,11 @@ int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     const bool akc = !transA, bkc = transB != 0;
     // 128x128 tiles once they still fill the 256 CUs, 64x64 tiles for the small problems
     const bool big = splits == 1 && (long)((M + 127) / 128) * ((N + 127) / 128) >= 192;
-#define GEMM_DISPATCH(AK, BK_)                                                                                  \
-    if (big) launch_gemm_t<AK, BK_, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st);      \
+#define GEMM_DISPATCH(AK, BK_)                                                                                        \
+    if (bf) {                                                                                                         \
+        if (big) launch_gemm_t<AK, BK_, 128, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st);  \
+        else launch_gemm_t<AK, BK_, 64, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, splits, ws, st);       \
+    } else if (big) launch_gemm_t<AK, BK_, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st);     \
     else launch_gemm_t<AK, BK_, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, splits, ws, st);
     if (akc && bkc) { GEMM_DISPATCH(true, true) }
     else if (akc && !bkc) { GEMM_DISPATCH(true, false) }
@@ -364,6 +406,17 @@ extern "C" int tag_gemm(const float* A, int lda, int transA, const float* B, int
     TAG_CHECK_ARG(act == 0 || act == 1 || act == 3 || act == 4 || act == 5);
     Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
     launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same GEMM with both operands rounded to bf16 (nearest-even) and fp32 accumulation (BASELINE configs[2] mode)
+extern "C" int tag_gemm_bf16(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                             int M, int N, int K, const float* bias, int act, int accumulate, void* ws, void* stream) {
+    TAG_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
+    TAG_CHECK_ARG(act == 0 || act == 1 || act == 3 || act == 4 || act == 5);
+    Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
+    launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream), true);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,7 @@ _SIGS = {
     "tag_pack_conv_weight": (c_int, [P, P, P, c_int, c_int, P]),
     "tag_conv3x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_x3_bf16_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "tag_bn_stats_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
     "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -65,6 +66,7 @@ _SIGS = {
     "tag_mean_w_backward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_gemm_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tag_gemm": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P]),
+    "tag_gemm_bf16": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "tag_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
     "tag_colsum": (c_int, [P, c_int, c_long, c_int, P, P, P]),
     "tag_relu_backward": (c_int, [P, P, P, c_long, P]),

@@ -173,6 +173,15 @@ ACT_DTYPE = os.environ.get("TAG_ACT_DTYPE", "fp32")
 BF16 = torch.bfloat16
 
 
+#: BASELINE configs[2] mode only: GEMM operands (nn.Linear fc1 / projections, GRU input projections and their backward GEMMs)
+#: rounded to bf16 on the bf16 MFMA with fp32 accumulation, as autocast would; "auto" = on exactly when ACT_DTYPE is bf16
+GEMM_MATH = os.environ.get("TAG_GEMM_MATH", "auto")
+
+
+def gemm_bf16() -> bool:
+    return GEMM_MATH == "bf16" or (GEMM_MATH == "auto" and ACT_DTYPE == "bf16")
+
+
 def act_bf16() -> bool:
     return CONV_MATH == "bf16" and ACT_DTYPE == "bf16"
 
@@ -232,7 +241,8 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     x3 = wpack.dtype == torch.uint8
     part = None
     if want_stats and FUSE_BN_STATS:
-        P = query("tag_conv3x3_x3_stats_rows" if x3 else "tag_conv3x3_stats_rows", B, H, W, Cout)
+        P = query(("tag_conv3x3_x3_bf16_stats_rows" if x.dtype == BF16 else "tag_conv3x3_x3_stats_rows") if x3
+                  else "tag_conv3x3_stats_rows", B, H, W, Cout)
         if P > 0:
             part = (P, _empty(P * (3 * Cout + 1), like=x))
     sp = ptr(part[1]) if part else None
@@ -270,7 +280,7 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     if (FUSE_BN_BWD_SUMS and dy_in.dtype == BF16 and wpack.dtype == torch.uint8 and wpack.products == 1 and st.train
             and yref.dtype == BF16 and W in (8, 16, 32, 64)):
         # BASELINE configs[2] mode: the same fusion on the one-product bf16 kernels (sums from the fp32 accumulators)
-        P = query("tag_conv3x3_x3_stats_rows", B, H, W, C)
+        P = query("tag_conv3x3_x3_bf16_stats_rows", B, H, W, C)
         da = _empty(B, H, W, C, like=dy_in, dtype=BF16)
         part = _empty(P * 2 * C, like=dy_in)
         with _timed(("conv3x3_x3_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
@@ -455,8 +465,8 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     ldc = ldc if ldc is not None else N
     nws = query("tag_gemm_ws_bytes", M, N, K)
     ws = _ws(nws, A) if nws else None
-    call("tag_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(out), ldc, M, N, K, ptr(bias), act,
-         int(accumulate), ptr(ws))
+    call("tag_gemm_bf16" if gemm_bf16() else "tag_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(out), ldc, M,
+         N, K, ptr(bias), act, int(accumulate), ptr(ws))
     return out
 
 

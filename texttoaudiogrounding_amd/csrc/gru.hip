@@ -240,16 +240,25 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __
         if (s > 0) {
             const u64* src = hxd + (size_t)((s - 1) & 1) * Bpad * H + (size_t)(b0 + li) * H + wid * KQ + lk;
             float av[NI];
-            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;   // after one timeout never wait again (bounded total time)
-            while (true) {
-                bool ok = true;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    u64 g = arow ? __hip_atomic_load(src + 4 * i, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
-                    av[i] = __uint_as_float((unsigned)g);
-                    ok &= (unsigned)(g >> 32) == (unsigned)s;
-                }
-                if (__all(ok)) break;
+            for (int i = 0; i < NI; ++i) av[i] = 0.0f;
+            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;   // after one timeout never wait again (bounded total time)
+            // granules still missing (bit i): a re-poll asks only for those -- the first sweep usually finds most producers
+            // done, and re-reading everything (32 KB per workgroup per sweep, 128 workgroups) only queues behind the very
+            // stores it is waiting for
+            unsigned pend = arow ? ((NI >= 32) ? 0xffffffffu : ((1u << NI) - 1u)) : 0u;
+            while (true) {
+                u64 gq[NI];
+                const unsigned want = pend;                // all loads of the sweep are issued before the first is looked at
+#pragma unroll
+                for (int i = 0; i < NI; ++i) gq[i] = (want & (1u << i)) ? __hip_atomic_load(src + 4 * i, TAG_RLX_AGENT) : 0ull;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if ((want & (1u << i)) && (unsigned)(gq[i] >> 32) == (unsigned)s) {
+                        av[i] = __uint_as_float((unsigned)gq[i]);
+                        pend &= ~(1u << i);
+                    }
+                if (__all(pend == 0u)) break;
                 if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1u); dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -346,16 +355,23 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
         if (s > 0) {
             const u64* src = xbase + (size_t)((s - 1) & 1) * parity_stride + (size_t)row * H + j;
             float pv[NU];
-            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;
-            while (true) {
-                bool ok = true;
 #pragma unroll
-                for (int p = 0; p < NU; ++p) {
-                    u64 g = valid ? __hip_atomic_load(src + (size_t)p * slab, TAG_RLX_AGENT) : granule((unsigned)s, 0.0f);
-                    pv[p] = __uint_as_float((unsigned)g);
-                    ok &= (unsigned)(g >> 32) == (unsigned)s;
-                }
-                if (__all(ok)) break;
+            for (int p = 0; p < NU; ++p) pv[p] = 0.0f;
+            unsigned spins = dead ? GRU_SPIN_LIMIT : 0;
+            unsigned pend = valid ? ((NU >= 32) ? 0xffffffffu : ((1u << NU) - 1u)) : 0u;   // producers still missing
+            while (true) {
+                u64 gq[NU];
+                const unsigned want = pend;
+#pragma unroll
+                for (int p = 0; p < NU; ++p)
+                    gq[p] = (want & (1u << p)) ? __hip_atomic_load(src + (size_t)p * slab, TAG_RLX_AGENT) : 0ull;
+#pragma unroll
+                for (int p = 0; p < NU; ++p)
+                    if ((want & (1u << p)) && (unsigned)(gq[p] >> 32) == (unsigned)s) {
+                        pv[p] = __uint_as_float((unsigned)gq[p]);
+                        pend &= ~(1u << p);
+                    }
+                if (__all(pend == 0u)) break;
                 if (++spins > GRU_SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1u); dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }

@@ -31,3 +31,17 @@ if "logmel" in which:
         w, f = window.to(dev), fb.to(dev)
         us = timeit(lambda: ops.logmel(wave, p["n_fft"], p["win_length"], p["hop_length"], w, f))
         print(f"logmel[{kind}] B=64 x 10 s: {us:.1f} us")
+if "gru" in which:
+    import math
+    B, T, I, H = 64, 250, 512, 256
+    g = torch.Generator().manual_seed(0)
+    k = 1 / math.sqrt(H)
+    rnn = []
+    for _ in range(2):
+        rnn += [((torch.rand(3 * H, I, generator=g) * 2 - 1) * k).to(dev), ((torch.rand(3 * H, H, generator=g) * 2 - 1) * k).to(dev),
+                ((torch.rand(3 * H, generator=g) * 2 - 1) * k).to(dev), ((torch.rand(3 * H, generator=g) * 2 - 1) * k).to(dev)]
+    x = torch.randn(B * T, I, device=dev)
+    y, sv = ops.gru_bidir_forward(x, rnn, B, T, True)
+    dy = torch.randn_like(y)
+    print(f"GRU fwd (proj GEMM + persistent kernel) B=64 T=250: {timeit(lambda: ops.gru_bidir_forward(x, rnn, B, T, True)):.1f} us")
+    print(f"GRU bwd (persistent kernel + GEMMs): {timeit(lambda: ops.gru_bidir_backward(dy, x, sv)):.1f} us")

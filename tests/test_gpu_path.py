@@ -512,16 +512,18 @@ def test_edge_shapes_train_step(dev, B, S):
         assert (p.grad.cpu().double() - g).abs().max().item() / (g.abs().max().item() + 1e-30) < 1e-3, name
 
 
-@pytest.mark.parametrize("math_", ["fp32", "x3"])
+@pytest.mark.parametrize("math_", ["fp32", "x3", "x9", "bf16mode"])
 def test_training_trajectory_matches_oracle(dev, math_):
     """Ten optimiser steps (forward, backward, clip_grad_norm_(1.0), Adam) on a fixed batch, dropout off: the loss
-    trajectory of the HIP path follows the fp64 oracle's (torch.optim.Adam on the oracle's parameters)."""
+    trajectory of the HIP path follows the fp64 oracle's (torch.optim.Adam on the oracle's parameters).  "bf16mode" =
+    BASELINE configs[2] as a mode (bf16 conv arithmetic + bf16 activation storage + bf16 GEMM operands): the same descent
+    within a bf16-sized budget."""
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.runner import StrongRunner
     st = O.init_state(seed=23, logit_gain=20.0)
     batch = O.synthetic_batch(4, 32000, seed=9, ragged=True)
-    old = ops.CONV_MATH
-    ops.CONV_MATH = math_
+    old = (ops.CONV_MATH, ops.ACT_DTYPE)
+    ops.CONV_MATH, ops.ACT_DTYPE = ("bf16", "bf16") if math_ == "bf16mode" else (math_, "fp32")
     try:
         model = build_hip_model(st, "dot", dev).train()
         model.audio_encoder.dropout_p = (0.0, 0.0)
@@ -530,7 +532,7 @@ def test_training_trajectory_matches_oracle(dev, math_):
         for _ in range(10):
             hip.append(runner.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}).item())
     finally:
-        ops.CONV_MATH = old
+        ops.CONV_MATH, ops.ACT_DTYPE = old
     s64 = O.state_to(st, torch.float64, requires_grad=True)
     b64 = dict(batch)
     b64["waveform"], b64["label"] = batch["waveform"].double(), batch["label"].double()
@@ -548,8 +550,12 @@ def test_training_trajectory_matches_oracle(dev, math_):
     print(f"trajectory [{math_}]: hip {['%.5f' % v for v in hip]}")
     print(f"                 oracle {['%.5f' % v for v in ref]}")
     assert ref[-1] < ref[0] - 0.005                                  # the oracle actually learns on this batch
-    assert max(abs(a - b) for a, b in zip(hip, ref)) < 3e-3           # Adam's sign-like first steps amplify fp32 noise
-    assert abs(hip[0] - ref[0]) < 2e-5
+    if math_ == "bf16mode":                                          # 8 significand bits through 8 conv layers + the GEMMs
+        assert max(abs(a - b) for a, b in zip(hip, ref)) < 2e-2 and abs(hip[0] - ref[0]) < 5e-3
+        assert hip[-1] < hip[0] - 0.005                              # and it learns
+    else:
+        assert max(abs(a - b) for a, b in zip(hip, ref)) < 3e-3       # Adam's sign-like first steps amplify fp32 noise
+        assert abs(hip[0] - ref[0]) < 2e-5
 
 
 @pytest.mark.parametrize("math_", ["fp32", "x3"])

@@ -33,6 +33,11 @@
 #ifndef TAG_X3_BF16_MB64
 #define TAG_X3_BF16_MB64 2
 #endif
+// ablation of the forward/dgrad kernel for tools/conv_bf16_bench.py (never set in the product build): 1 = no output stores,
+// 2 = no statistics epilogue, 3 = no MFMAs (and hence no operand reads), 4 = 1 + 2
+#ifndef TAG_X3_ABL
+#define TAG_X3_ABL 0
+#endif
 // depth of the weight-fragment ring of the ONE-product (plain bf16) forward/dgrad kernels (3, 6, 9 or 18)
 #ifndef TAG_X3_RING1
 #define TAG_X3_RING1 9
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
             for (int p = P0; p < 9; ++p)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    acc[hb + i] = mfma_bf16(afb[hidx & 1][i][PA[p]], bq[slot][PB[p]], acc[hb + i]);
+                    if (TAG_X3_ABL != 3) acc[hb + i] = mfma_bf16(afb[hidx & 1][i][PA[p]], bq[slot][PB[p]], acc[hb + i]);
             // pin: (2 MFMA, 1 VMEM read)* then (2 MFMA, 1 DS read)*
             constexpr int NM = 2 * (9 - P0), NR = 2 * NSPL;
 #pragma unroll
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                 const float other = __shfl_xor(acc[i][r], 1, 64);
                 const bool mine = ((r ^ ml) & 1) == 0;
                 const unsigned w2 = (ml & 1) ? tag_pack_bf16(other, acc[i][r]) : tag_pack_bf16(acc[i][r], other);
-                if (mine && h < H)
+                if (TAG_X3_ABL != 1 && TAG_X3_ABL != 4 && mine && h < H)
                     *reinterpret_cast<unsigned*>(y + (((size_t)img * H + h) * W + tx) * Cout + (n & ~1)) = w2;
             } else {
                 if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
         if (kl == 0) { ps[n] = s1; ps[Cout + n] = s2; }
     }
     // ---- fused BatchNorm statistics (see conv.hip): one partial row per wave M-group (MB * 32 pixels) ----
-    if (EPI == 0 && stats) {
+    if (EPI == 0 && stats && TAG_X3_ABL != 2 && TAG_X3_ABL != 4) {
         constexpr int MG = WM;
         const int prow = mt * MG + wm;
         float* ps = stats + (size_t)prow * 3 * Cout;

@@ -33,6 +33,10 @@
 #ifndef TAG_X3_BF16_MB64
 #define TAG_X3_BF16_MB64 2
 #endif
+// bf16-storage launches: stage the output tile through LDS and store 16-byte pieces (1) or store 4 bytes per lane directly (0)
+#ifndef TAG_X3_LDS_EPI
+#define TAG_X3_LDS_EPI 1
+#endif
 // ablation of the forward/dgrad kernel for tools/conv_bf16_bench.py (never set in the product build): 1 = no output stores,
 // 2 = no statistics epilogue, 3 = no MFMAs (and hence no operand reads), 4 = 1 + 2
 #ifndef TAG_X3_ABL
@@ -331,15 +335,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     // ---- epilogue: D col = lane&31 (cout), D row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel via row_to_pix ----
     const int n = n0 + wn * 32 + ml;
     bool okrow[MB][16];
+    // bf16 storage: the tile goes through LDS ([pixel][BN_ channels], the patch buffer is free by now) and leaves as 16-byte
+    // pieces, consecutive threads = consecutive channel octets of a pixel (128 / 256 contiguous bytes per pixel, whole rows of the
+    // 64-cout layers) -- the direct form below writes 4 bytes per lane and costs 18 % of the one-product kernel's time
+    // (tools/conv_bf16_bench.py, ablation 1)
+    constexpr bool LDS_EPI = HS16 && (TAG_X3_LDS_EPI != 0);
+    constexpr int OROWB = BN_ * 2 + 16;                           // bytes per pixel row of the staged tile
+    if constexpr (LDS_EPI) __syncthreads();                       // every wave is done reading the patch
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int ty, tx;
-            pix_to_yx<TW>((wm * MB + i) * 32 + row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl), ty, tx);
+            const int pm = (wm * MB + i) * 32 + row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl);
+            pix_to_yx<TW>(pm, ty, tx);
             const int h = h0 + ty;
             okrow[i][r] = h < H;
-            if constexpr (HS16) {
+            if constexpr (LDS_EPI) {
+                const float other = __shfl_xor(acc[i][r], 1, 64);
+                const bool mine = ((r ^ ml) & 1) == 0;
+                const unsigned w2 = (ml & 1) ? tag_pack_bf16(other, acc[i][r]) : tag_pack_bf16(acc[i][r], other);
+                if (mine) *reinterpret_cast<unsigned*>(smem + pm * OROWB + ((wn * 32 + ml) & ~1) * 2) = w2;
+            } else if constexpr (HS16) {
                 // channel pairs: even lanes store (n, n+1) of the even rows r, odd lanes (n-1, n) of the odd rows
                 const float other = __shfl_xor(acc[i][r], 1, 64);
                 const bool mine = ((r ^ ml) & 1) == 0;
@@ -350,6 +367,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                 if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
             }
         }
+    if constexpr (LDS_EPI) {
+        __syncthreads();
+        constexpr int TP = WM * MB * 32, PPP = BN_ / 8;           // pixels per tile, 16-byte pieces per pixel
+#pragma unroll
+        for (int k = 0; k < TP * PPP / 256; ++k) {
+            const int piece = tid + 256 * k;
+            const int pm = piece / PPP, c8 = piece % PPP;
+            int ty, tx;
+            pix_to_yx<TW>(pm, ty, tx);
+            const int h = h0 + ty;
+            if (TAG_X3_ABL != 1 && TAG_X3_ABL != 4 && h < H)
+                *reinterpret_cast<u32x4*>(y + (((size_t)img * H + h) * W + tx) * Cout + n0 + c8 * 8) =
+                    *reinterpret_cast<const u32x4*>(smem + pm * OROWB + c8 * 16);
+        }
+    }
     // ---- EPI == 1: the reduction half of the BatchNorm+ReLU backward this gradient flows into (conv.hip, EPI == 1): per wave
     // M-group and channel sum(g) and sum(g * xhat), g taken from the fp32 accumulators; rows [prow][2][Cout] ----
     if (EPI == 1) {
@@ -833,7 +865,11 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
     using G = X3Geom<TW, WM * MB * 32>;
     constexpr int BN_ = (4 / WM) * 32;
     const int grid = B * ((H + G::TH - 1) / G::TH) * (Cout / BN_);
-    const size_t lds = (NP == 1 ? 1 : 3) * G::PLANE + 2 * 512 * 4;
+    size_t lds = (NP == 1 ? 1 : 3) * G::PLANE + 2 * 512 * 4;
+    if (Act<TS>::is_bf16 && TAG_X3_LDS_EPI) {                     // the staged output tile reuses the patch buffer
+        const size_t ot = (size_t)(WM * MB * 32) * (BN_ * 2 + 16);
+        if (ot > lds) lds = ot;
+    }
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \

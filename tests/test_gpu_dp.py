@@ -25,13 +25,15 @@ def _free_port():
     return p
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher in the environment must spawn 2 ranks and print ONE JSON line."""
+@pytest.mark.parametrize("extra", [[], ["--dtype", "bf16"]], ids=["fp32", "bf16mode"])
+def test_bench_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with no launcher in the environment must spawn 2 ranks and print ONE JSON line -- for the
+    contract's fp32 workload and for BASELINE configs[2] as a mode (bf16 arithmetic / storage / all-reduce payload)."""
     env = dict(os.environ, TAG_DIST_BACKEND="gloo", TAG_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "8", "--no-cpu-baseline", "--no-alt"], env=env, capture_output=True, text=True,
+                        "--batch", "8", "--no-cpu-baseline", "--no-alt"] + extra, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -7,6 +7,7 @@
 // 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 staged k-major in LDS
 // (As[k][m], Bs[k][n]) and double-buffered; a k-contiguous operand is transposed on its way into
 // LDS with a stride of 65 floats (conflict-free), an mn-contiguous one is copied with float4.
+#include <type_traits>
 #include "tag_common.h"
 
 namespace {
@@ -64,6 +65,56 @@ struct Stage {
     }
 };
 
+// bf16-MFMA variant (tag_gemm_bf16): the LDS image is bf16, ROW-major S[r][32 k] with an 80-byte row stride (64 B of k + 16 B
+// pad: the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots), so a fragment of v_mfma_f32_32x32x16_bf16 -- lane
+// (kl, ml) = row ml, k = 8 kl .. 8 kl + 7 of a k16 step -- is ONE 16-byte LDS read.  Operands are rounded to bf16 (nearest-even)
+// on their way into LDS.  A k-contiguous operand stores 4 k of one row as 8 bytes; an mn-contiguous one loads the same 4 rows
+// at k and k + 1 and stores four (k, k+1) pairs.
+constexpr int BFROW = 80;
+template <bool KC, int T>
+struct StageBF {
+    static constexpr int NL = T / 32;
+    f32x4 reg[NL];
+    __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            float4 v;
+            if (KC) {
+                const int idx = threadIdx.x + 256 * i;
+                const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
+            } else {
+                const int idx2 = threadIdx.x + 256 * (i >> 1);
+                const int k = k0 + 2 * (idx2 / (T / 4)) + (i & 1), r = r0 + (idx2 % (T / 4)) * 4;
+                v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
+            }
+            reg[i] = (f32x4){v.x, v.y, v.z, v.w};
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* s) const {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                const int r = idx >> 3, k = (idx & 7) * 4;
+                *reinterpret_cast<tag_u32x2*>(s + r * BFROW + k * 2) =
+                    (tag_u32x2){tag_pack_bf16(reg[i].x, reg[i].y), tag_pack_bf16(reg[i].z, reg[i].w)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; i += 2) {
+                const int idx2 = threadIdx.x + 256 * (i >> 1);
+                const int kp = idx2 / (T / 4), r = (idx2 % (T / 4)) * 4;
+                unsigned char* d = s + r * BFROW + kp * 4;
+                *reinterpret_cast<unsigned*>(d) = tag_pack_bf16(reg[i].x, reg[i + 1].x);
+                *reinterpret_cast<unsigned*>(d + BFROW) = tag_pack_bf16(reg[i].y, reg[i + 1].y);
+                *reinterpret_cast<unsigned*>(d + 2 * BFROW) = tag_pack_bf16(reg[i].z, reg[i + 1].z);
+                *reinterpret_cast<unsigned*>(d + 3 * BFROW) = tag_pack_bf16(reg[i].w, reg[i + 1].w);
+            }
+        }
+    }
+};
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.0f);
     if (act == 2) return fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-7f), 1.0f);
@@ -95,7 +146,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                                                    float* __restrict__ partial) {
     constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
     constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
-    constexpr int ASZ = ((GK * LDSA + 3) / 4) * 4, BSZ = ((GK * LDSB + 3) / 4) * 4;   // keep 16-byte alignment
+    constexpr int ASZ = BF ? T * BFROW / 4 : ((GK * LDSA + 3) / 4) * 4;               // floats per buffer (16-byte aligned)
+    constexpr int BSZ = BF ? T * BFROW / 4 : ((GK * LDSB + 3) / 4) * 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][ASZ]
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
@@ -110,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int wm0 = (wid >> 1) * (T / 2), wn0 = (wid & 1) * (T / 2);
     const int kl = lane >> 5, ml = lane & 31;
 
-    Stage<AKC, T> sa;
-    Stage<BKC, T> sb;
+    typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T>>::type sa;
+    typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T>>::type sb;
     f32x16 acc[TT][TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -123,8 +175,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int kiters = (kend - kbeg + GK - 1) / GK;
     sa.load(A, lda, m0, M, kbeg, kend, a_al);
     sb.load(B, ldb, n0, N, kbeg, kend, b_al);
-    sa.store(As);
-    sb.store(Bs);
+    auto st_a = [&](float* p) { if constexpr (BF) sa.store(reinterpret_cast<unsigned char*>(p)); else sa.store(p); };
+    auto st_b = [&](float* p) { if constexpr (BF) sb.store(reinterpret_cast<unsigned char*>(p)); else sb.store(p); };
+    st_a(As);
+    st_b(Bs);
     __syncthreads();
     for (int it = 0; it < kiters; ++it) {
         const int buf = it & 1;
@@ -134,28 +188,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BF) {
-            // lane (kl, ml) of a 32x32x16 fragment holds k = 8 kl .. 8 kl + 7 of row ml: eight LDS words, packed pairwise
-            const float* a = As + buf * ASZ + 8 * kl * LDSA + wm0 + ml;
-            const float* b = Bs + buf * BSZ + 8 * kl * LDSB + wn0 + ml;
+            const unsigned char* a = reinterpret_cast<const unsigned char*>(As + buf * ASZ) + (wm0 + ml) * BFROW + kl * 16;
+            const unsigned char* b = reinterpret_cast<const unsigned char*>(Bs + buf * BSZ) + (wn0 + ml) * BFROW + kl * 16;
 #pragma unroll
             for (int ks = 0; ks < GK / 16; ++ks) {
                 gemm_u32x4 af[TT], bfr[TT];
 #pragma unroll
-                for (int i = 0; i < TT; ++i) {
-                    float v[8];
+                for (int i = 0; i < TT; ++i) af[i] = *reinterpret_cast<const gemm_u32x4*>(a + i * 32 * BFROW + ks * 32);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = a[(16 * ks + e) * LDSA + i * 32];
-                    af[i] = (gemm_u32x4){tag_pack_bf16(v[0], v[1]), tag_pack_bf16(v[2], v[3]), tag_pack_bf16(v[4], v[5]),
-                                         tag_pack_bf16(v[6], v[7])};
-                }
-#pragma unroll
-                for (int j = 0; j < TT; ++j) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = b[(16 * ks + e) * LDSB + j * 32];
-                    bfr[j] = (gemm_u32x4){tag_pack_bf16(v[0], v[1]), tag_pack_bf16(v[2], v[3]), tag_pack_bf16(v[4], v[5]),
-                                          tag_pack_bf16(v[6], v[7])};
-                }
+                for (int j = 0; j < TT; ++j) bfr[j] = *reinterpret_cast<const gemm_u32x4*>(b + j * 32 * BFROW + ks * 32);
 #pragma unroll
                 for (int i = 0; i < TT; ++i)
 #pragma unroll
@@ -193,8 +234,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < kiters) {
-            sa.store(As + (buf ^ 1) * ASZ);
-            sb.store(Bs + (buf ^ 1) * BSZ);
+            st_a(As + (buf ^ 1) * ASZ);
+            st_b(Bs + (buf ^ 1) * BSZ);
         }
         __syncthreads();
     }
@@ -258,7 +299,8 @@ int gemm_splits(int M, int N, int K) {
 template <bool AKC, bool BKC, int T, bool BF = false>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st) {
-    constexpr int ASZ = ((GK * Stage<AKC, T>::LD + 3) / 4) * 4, BSZ = ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
+    constexpr int ASZ = BF ? T * BFROW / 4 : ((GK * Stage<AKC, T>::LD + 3) / 4) * 4;
+    constexpr int BSZ = BF ? T * BFROW / 4 : ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

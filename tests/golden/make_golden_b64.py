@@ -60,7 +60,8 @@ def main():
     out = {"input_checksum": np.array(checksum(batch["waveform"]) + checksum(batch["text"].float())
                                       + checksum(st0["audio_encoder.fc1.weight"])),
            "dropout_seeds": np.array(DROPOUT_SEEDS, dtype=np.int64),
-           "mask_keep_counts": np.array([int(torch.count_nonzero(m).item()) for m in masks.values()], dtype=np.int64)   # exact (a float32 sum is not)}
+           # exact counts (a float32 sum is not)
+           "mask_keep_counts": np.array([int(torch.count_nonzero(m).item()) for m in masks.values()], dtype=np.int64)}
     l64, fs64, g64 = run(torch.float64, st0, batch, masks)
     l32, fs32, g32 = run(torch.float32, st0, batch, masks)
     out["loss_f64"], out["loss_f32"] = np.array(l64), np.array(l32)

@@ -45,3 +45,14 @@ if "gru" in which:
     dy = torch.randn_like(y)
     print(f"GRU fwd (proj GEMM + persistent kernel) B=64 T=250: {timeit(lambda: ops.gru_bidir_forward(x, rnn, B, T, True)):.1f} us")
     print(f"GRU bwd (persistent kernel + GEMMs): {timeit(lambda: ops.gru_bidir_backward(dy, x, sv)):.1f} us")
+if "c1" in which:
+    B, H = 64, 1001
+    x = torch.randn(B, H, 64, device=dev)
+    dy = torch.randn(B, H, 64, 64, device=dev)
+    w = torch.randn(64, 1, 3, 3, device=dev) * 0.1
+    cs, ct = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    us = timeit(lambda: ops.conv3x3_c1_backward(x, dy, w, cs, ct))
+    print(f"conv_c1 backward (fp32 dy 1.05 GB): {us:.1f} us = {dy.numel() * 4 / us / 1e6:.2f} TB/s")
+    dyb = dy.bfloat16()
+    us = timeit(lambda: ops.conv3x3_c1_backward(x, dyb, w, cs, ct))
+    print(f"conv_c1 backward (bf16 dy 0.52 GB): {us:.1f} us = {dyb.numel() * 2 / us / 1e6:.2f} TB/s")

@@ -9,6 +9,11 @@
 // finalize kernel sums the partials in a fixed order (deterministic, no atomics).
 #include "tag_common.h"
 
+// bf16 tensors: 8 channels per thread in the pool BACKWARD passes too (1) or only in the forward pass (0)
+#ifndef TAG_POOL_BWD_NC8
+#define TAG_POOL_BWD_NC8 1
+#endif
+
 namespace {
 
 constexpr int RED_MAX_BLOCKS = 1024;
@@ -305,53 +310,54 @@ struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
 // ------------------------------------------------------------------------------------------
 // forward: act(bn(y)) -> pool -> dropout
 // ------------------------------------------------------------------------------------------
-template <int PH, int PW, class TS = float>
+template <int PH, int PW, class TS = float, int NC = 4>
 __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restrict__ y,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
                                                              TS* __restrict__ out, int B, int H, int W, int C,
                                                              int act, int pool, float drop_p, uint64_t seed) {
-    const int Ho = H / PH, Wo = W / PW, C4 = C >> 2, rpi = 256 / C4;
-    const int c = (threadIdx.x % C4) << 2, rsub = threadIdx.x / C4;
+    const int Ho = H / PH, Wo = W / PW, CN = C / NC, rpi = 256 / CN;
+    const int c = (threadIdx.x % CN) * NC, rsub = threadIdx.x / CN;
     const long slots = (long)B * Ho * Wo;
     const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    float4 s = make_float4(1, 1, 1, 1), t = make_float4(0, 0, 0, 0);
-    if (scale) {
-        s = *reinterpret_cast<const float4*>(scale + c);
-        t = *reinterpret_cast<const float4*>(shift + c);
-    }
+    float s[NC], t[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) { s[j] = scale ? scale[c + j] : 1.0f; t[j] = scale ? shift[c + j] : 0.0f; }
     for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
-        const long i = r * C4 + (c >> 2);            // flat float4 index of the output element
+        const long e0 = r * C + c;                    // flat index of the thread's first output element
         const int wo = (int)(r % Wo); long q = r / Wo;
         const int ho = (int)(q % Ho);
         const int b = (int)(q / Ho);
-        float sum[4] = {0, 0, 0, 0}, mx[4];
+        float sum[NC], mx[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { sum[j] = 0.0f; mx[j] = 0.0f; }
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
                 const size_t off = (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c;
-                const f32x4 v = Act<TS>::ld4(y + off);
-                float a[4] = {fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w)};
+                float v[NC];
+                ActN<TS, NC>::ld(y + off, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a[j] = (act == 1) ? fmaxf(a[j], 0.0f) : leaky01(a[j]);
+                for (int j = 0; j < NC; ++j) {
+                    float a = fmaf(v[j], s[j], t[j]);
+                    a = (act == 1) ? fmaxf(a, 0.0f) : leaky01(a);
                     if (pool == 0) {
-                        sum[j] += a[j];
-                        mx[j] = (dh == 0 && dw == 0) ? a[j] : fmaxf(mx[j], a[j]);
+                        sum[j] += a;
+                        mx[j] = (dh == 0 && dw == 0) ? a : fmaxf(mx[j], a);
                     } else {
-                        const float a2 = a[j] * a[j];
+                        const float a2 = a * a;
                         sum[j] += a2 * a2;
                     }
                 }
             }
-        float rr[4];
+        float rr[NC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NC; ++j) {
             rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
-            if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)i * 4 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
+            if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)e0 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
         }
-        Act<TS>::st4(out + i * 4, (f32x4){rr[0], rr[1], rr[2], rr[3]});
+        ActN<TS, NC>::st(out + e0, rr);
     }
 }
 
@@ -360,32 +366,33 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
 // including the partial slots of the floor-dropped last row/column (dz = 0 there).
 // MODE 0: accumulate (sum dz, sum dz*xhat); MODE 1: write dy.
 // ------------------------------------------------------------------------------------------
-template <int PH, int PW, class TS = float>
+template <int PH, int PW, class TS = float, int NC = 4>
 struct PoolBwdCtx {
     const TS* y; const float* scale; const float* shift; const float* mean; const float* invstd;
     const TS* dout; int B, H, W, C; float drop_p; uint64_t seed;
-    float sv[4], tv[4], mv[4], iv[4];      // per-channel constants of this thread's channel quad
+    float sv[NC], tv[NC], mv[NC], iv[NC];  // per-channel constants of this thread's NC channels
     __device__ void prep(int c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sv[j] = scale[c + j]; tv[j] = shift[c + j]; mv[j] = mean[c + j]; iv[j] = invstd[c + j]; }
+        for (int j = 0; j < NC; ++j) { sv[j] = scale[c + j]; tv[j] = shift[c + j]; mv[j] = mean[c + j]; iv[j] = invstd[c + j]; }
     }
     // dz for the slot (b, hs, ws, c..c+3); valid[dh][dw] tells which positions exist
-    __device__ void slot(int b, int hs, int ws, int c, float dz[PH][PW][4], float xh[PH][PW][4],
+    __device__ void slot(int b, int hs, int ws, int c, float dz[PH][PW][NC], float xh[PH][PW][NC],
                          bool ex[PH][PW]) const {
         const int Ho = H / PH, Wo = W / PW;
         const bool full = hs < Ho && ws < Wo;
-        float a[PH][PW][4];
+        float a[PH][PW][NC];
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
                 const int h = hs * PH + dh, w = ws * PW + dw;
                 ex[dh][dw] = h < H && w < W;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ex[dh][dw]) v = Act<TS>::ld4(y + (((size_t)b * H + h) * W + w) * C + c);
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+                float vv[NC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NC; ++j) vv[j] = 0.0f;
+                if (ex[dh][dw]) ActN<TS, NC>::ld(y + (((size_t)b * H + h) * W + w) * C + c, vv);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
                     a[dh][dw][j] = fmaf(vv[j], sv[j], tv[j]);
                     xh[dh][dw][j] = (vv[j] - mv[j]) * iv[j];
                     dz[dh][dw][j] = 0.0f;
@@ -393,11 +400,11 @@ struct PoolBwdCtx {
             }
         if (!full) return;
         const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
-        const f32x4 g4 = Act<TS>::ld4(dout + oi);
-        float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float g[NC];
+        ActN<TS, NC>::ld(dout + oi, g);
         const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NC; ++j) {
             if (drop_p > 0.0f) g[j] = tag_keep(seed, (uint64_t)oi + j, drop_p) ? g[j] * keep_scale : 0.0f;
             // first maximum in scan order (h then w), as ATen's max_pool2d picks it
             int am = 0; float best = fmaxf(a[0][0][j], 0.0f);
@@ -419,57 +426,59 @@ struct PoolBwdCtx {
     }
 };
 
-template <int PH, int PW, class TS = float>
-__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW, TS> ctx, double* __restrict__ partials) {
+template <int PH, int PW, class TS = float, int NC = 4>
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW, TS, NC> ctx, double* __restrict__ partials) {
     extern __shared__ double sred[];
-    const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
-    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    const int C = ctx.C, tpr = C / NC, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) * NC, rsub = threadIdx.x / tpr;
     const int Ho = ctx.H / PH, Wo = ctx.W / PW;   // only full slots carry gradient
     const long slots = (long)ctx.B * Ho * Wo;
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    double s1[NC], s2[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
     ctx.prep(c);
     for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
         const int ws = (int)(r % Wo); long q = r / Wo;
         const int hs = (int)(q % Ho); const int b = (int)(q / Ho);
-        float dz[PH][PW][4], xh[PH][PW][4]; bool ex[PH][PW];
+        float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
         ctx.slot(b, hs, ws, c, dz, xh, ex);
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += dz[dh][dw][j]; s2[j] += dz[dh][dw][j] * xh[dh][dw][j]; }
+                for (int j = 0; j < NC; ++j) { s1[j] += dz[dh][dw][j]; s2[j] += dz[dh][dw][j] * xh[dh][dw][j]; }
     }
-    double* mine = sred + threadIdx.x * 8;
+    double* mine = sred + threadIdx.x * 2 * NC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mine[j] = s1[j]; mine[4 + j] = s2[j]; }
+    for (int j = 0; j < NC; ++j) { mine[j] = s1[j]; mine[NC + j] = s2[j]; }
     __syncthreads();
     if (rsub == 0) {
         for (int q = 1; q < rpi; ++q) {
-            const double* o = sred + (threadIdx.x + q * tpr) * 8;
+            const double* o = sred + (threadIdx.x + q * tpr) * 2 * NC;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s1[j] += o[j]; s2[j] += o[4 + j]; }
+            for (int j = 0; j < NC; ++j) { s1[j] += o[j]; s2[j] += o[NC + j]; }
         }
         double* p = partials + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { p[c + j] = s1[j]; p[C + c + j] = s2[j]; }
+        for (int j = 0; j < NC; ++j) { p[c + j] = s1[j]; p[C + c + j] = s2[j]; }
     }
 }
 
-template <int PH, int PW, class TS = float>
-__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, TS> ctx, const float* __restrict__ gamma,
+template <int PH, int PW, class TS = float, int NC = 4>
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, TS, NC> ctx, const float* __restrict__ gamma,
                                                              const float* __restrict__ dgamma,
                                                              const float* __restrict__ dbeta, int bn_train,
                                                              TS* __restrict__ dy) {
-    const int C = ctx.C, tpr = C >> 2, rpi = 256 / tpr;
-    const int c = (threadIdx.x % tpr) << 2, rsub = threadIdx.x / tpr;
+    const int C = ctx.C, tpr = C / NC, rpi = 256 / tpr;
+    const int c = (threadIdx.x % tpr) * NC, rsub = threadIdx.x / tpr;
     const int Hs = (ctx.H + PH - 1) / PH, Ws = (ctx.W + PW - 1) / PW;
     const long slots = (long)ctx.B * Hs * Ws;
     const float invN = 1.0f / (float)((long)ctx.B * ctx.H * ctx.W);
     ctx.prep(c);
-    float k0[4], k1[4], k2[4];
+    float k0[NC], k1[NC], k2[NC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NC; ++j) {
         k0[j] = gamma[c + j] * ctx.iv[j];
         k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
         k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, 
     for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
         const int ws = (int)(r % Ws); long q = r / Ws;
         const int hs = (int)(q % Hs); const int b = (int)(q / Hs);
-        float dz[PH][PW][4], xh[PH][PW][4]; bool ex[PH][PW];
+        float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
         ctx.slot(b, hs, ws, c, dz, xh, ex);
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
@@ -485,10 +494,10 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, 
             for (int dw = 0; dw < PW; ++dw) {
                 if (!ex[dh][dw]) continue;
                 const int h = hs * PH + dh, w = ws * PW + dw;
-                float o[4];
+                float o[NC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
-                Act<TS>::st4(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c, (f32x4){o[0], o[1], o[2], o[3]});
+                for (int j = 0; j < NC; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
+                ActN<TS, NC>::st(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c, o);
             }
     }
 }
@@ -697,21 +706,25 @@ __global__ __launch_bounds__(256) void mean_w_bwd_kernel(const float* __restrict
     }
 }
 
-int red_blocks(long rows, int C) {
-    const int rpi = 256 / (C >> 2 > 0 ? C >> 2 : 1);
+int red_blocks(long rows, int C, int nc = 4) {
+    const int rpi = 256 / (C / nc > 0 ? C / nc : 1);
     long nb = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);
     if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
 // row-strided elementwise kernels: 256/(C/4) rows per block iteration, <= 8 iterations per thread at full size
-int apply_blocks(long rows, int C) {
-    const int rpi = 256 / (C >> 2);
+int apply_blocks(long rows, int C, int nc = 4) {
+    const int rpi = 256 / (C / nc);
     long nb = (rows + (long)rpi * 4 - 1) / ((long)rpi * 4);
     if (nb > 8192) nb = 8192;
     return (int)(nb < 1 ? 1 : nb);
 }
 bool vec_ok(int C) { return C % 4 == 0 && C >= 4 && (C >> 2) <= 256 && 256 % (C >> 2) == 0; }
+// channels per thread of the pool passes: 8 for bf16 tensors when the channel count allows (16-byte accesses), else 4
+template <class TS>
+constexpr bool pool_nc8_type() { return Act<TS>::is_bf16; }
+bool pool_nc8_ok(int C) { return C % 8 == 0 && (C >> 3) <= 256 && 256 % (C >> 3) == 0; }
 int ew_blocks(long n) {
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -823,10 +836,21 @@ static int bnact_pool_forward_impl(const TS* y, const float* scale, const float*
     TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
     TAG_CHECK_ARG(vec_ok(C));
     bool launched = false;
-    const int nb = apply_blocks((long)B * (H / ph) * (W / pw), C);
+    const bool nc8 = pool_nc8_type<TS>() && pool_nc8_ok(C);
+    const int nb = apply_blocks((long)B * (H / ph) * (W / pw), C, nc8 ? 8 : 4);
 #define POOL_FWD_BODY                                                                                              \
-    hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW, TS>), dim3(nb), dim3(256), 0, as_stream(stream), y, scale, shift, \
-                       out, B, H, W, C, act, pool, drop_p, seed)
+    if constexpr (pool_nc8_type<TS>()) {                                                                            \
+        if (nc8) {                                                                                                  \
+            hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW, TS, 8>), dim3(nb), dim3(256), 0, as_stream(stream), y, scale, \
+                               shift, out, B, H, W, C, act, pool, drop_p, seed);                                    \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW, TS, 4>), dim3(nb), dim3(256), 0, as_stream(stream), y, scale, \
+                               shift, out, B, H, W, C, act, pool, drop_p, seed);                                    \
+        }                                                                                                           \
+    } else {                                                                                                        \
+        hipLaunchKernelGGL((bnact_pool_fwd_kernel<PH, PW, TS, 4>), dim3(nb), dim3(256), 0, as_stream(stream), y, scale, shift, \
+                           out, B, H, W, C, act, pool, drop_p, seed);                                               \
+    }
     DISPATCH_POOL(2, 2, POOL_FWD_BODY)
     DISPATCH_POOL(1, 2, POOL_FWD_BODY)
     DISPATCH_POOL(2, 4, POOL_FWD_BODY)
@@ -858,21 +882,29 @@ static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const floa
     TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
     double* partials = static_cast<double*>(ws);
     const long slots = (long)B * (H / ph) * (W / pw);
-    const int nblk = red_blocks(slots, C);
-    const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C);
+    const bool nc8 = pool_nc8_type<TS>() && pool_nc8_ok(C) && TAG_POOL_BWD_NC8;
+    const int nblk = red_blocks(slots, C, nc8 ? 8 : 4);
+    const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C, nc8 ? 8 : 4);
     bool launched = false;
+#define POOL_BWD_NC(NC_)                                                                                           \
+    {                                                                                                              \
+        PoolBwdCtx<PH, PW, TS, NC_> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};            \
+        hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW, TS, NC_>), dim3(nblk), dim3(256), 256 * 2 * NC_ * sizeof(double), \
+                           as_stream(stream), ctx, partials);                                                      \
+        hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, \
+                           C, dgamma, dbeta);                                                                      \
+        hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW, TS, NC_>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma, \
+                           dgamma, dbeta, bn_train, dy);                                                           \
+    }
 #define POOL_BWD_BODY                                                                                              \
-    PoolBwdCtx<PH, PW, TS> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};                     \
-    hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW, TS>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double),      \
-                       as_stream(stream), ctx, partials);                                                          \
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, \
-                       C, dgamma, dbeta);                                                                          \
-    hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW, TS>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma, \
-                       dgamma, dbeta, bn_train, dy);
+    if constexpr (pool_nc8_type<TS>()) {                                                                           \
+        if (nc8) POOL_BWD_NC(8) else POOL_BWD_NC(4)                                                                \
+    } else POOL_BWD_NC(4)
     DISPATCH_POOL(2, 2, POOL_BWD_BODY)
     DISPATCH_POOL(1, 2, POOL_BWD_BODY)
     DISPATCH_POOL(1, 1, POOL_BWD_BODY)
 #undef POOL_BWD_BODY
+#undef POOL_BWD_NC
     TAG_CHECK_ARG(launched);
     TAG_LAUNCH_CHECK();
     return 0;

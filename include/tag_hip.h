@@ -169,7 +169,7 @@ int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float*
  * models/panns.py:49-58 with pool_type 'avg+max'; F.dropout models/audio_encoder.py:203-210.
  * y raw conv output (B,H,W,C); out (B,H/ph,W/pw,C).  Dropout keep-mask = counter-based hash of
  * (seed, flat output index); p = 0 disables.  act: 1 relu(bn) | 2 leaky(.1) without bn (scale=NULL),
- * pool: 0 avg+max | 1 LPPool(norm 4).
+ * pool: 0 avg+max | 1 LPPool(norm 4) | 2 avg | 3 max (the three pool_type values of ConvBlock.forward, models/panns.py:51-60).
  * ------------------------------------------------------------------------------------------- */
 int tag_bnact_pool_forward(const float* y, const float* scale, const float* shift, float* out, int B,
                            int H, int W, int C, int ph, int pw, int act, int pool, float drop_p,
@@ -181,8 +181,8 @@ size_t tag_bn_backward_ws_bytes(long rows, int C);
 int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift,
                              const float* mean, const float* invstd, const float* gamma,
                              const float* dout, float* dy, float* dgamma, float* dbeta, int B, int H,
-                             int W, int C, int ph, int pw, float drop_p, uint64_t seed, int bn_train,
-                             void* ws, void* stream);
+                             int W, int C, int ph, int pw, int pool /* 0 avg+max | 2 avg | 3 max */, float drop_p,
+                             uint64_t seed, int bn_train, void* ws, void* stream);
 /* same without pooling: upstream gradient da (rows,C) wrt relu(bn(y)); dy may alias da */
 int tag_bnrelu_backward(const float* y, const float* scale, const float* shift, const float* mean,
                         const float* invstd, const float* gamma, const float* da, float* dy,
@@ -493,8 +493,8 @@ int tag_bnact_pool_forward_bf16(const void* y, const float* scale, const float* 
                                 int C, int ph, int pw, int act, int pool, float drop_p, uint64_t seed, void* stream);
 int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
                                   const float* invstd, const float* gamma, const void* dout, void* dy, float* dgamma,
-                                  float* dbeta, int B, int H, int W, int C, int ph, int pw, float drop_p, uint64_t seed,
-                                  int bn_train, void* ws, void* stream);
+                                  float* dbeta, int B, int H, int W, int C, int ph, int pw, int pool, float drop_p,
+                                  uint64_t seed, int bn_train, void* ws, void* stream);
 /* bf16 twins of tag_conv3x3_dgrad_bnsums / tag_bnrelu_backward_apply (BASELINE configs[2] mode): the sums are taken from the
  * fp32 accumulators of the dgrad conv before its output is rounded to bf16; bnpart rows [P][2][Cout],
  * P = tag_conv3x3_x3_stats_rows(B,H,W,Cout). */

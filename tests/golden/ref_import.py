@@ -94,6 +94,11 @@ def install():
         mp.pyplot = _stub("matplotlib.pyplot")
     if REF not in sys.path:
         sys.path.insert(0, REF)
+    # texttoaudiogrounding_amd.install_aliases() registers this repo's modules under the reference's names: drop such aliases
+    # so that the names below resolve to /root/reference
+    for k in [k for k, m in sys.modules.items() if k.split(".")[0] in ("models", "losses", "utils")
+              and getattr(m, "__name__", "").startswith("texttoaudiogrounding_amd")]:
+        del sys.modules[k]
     mods = {}
     for name in ("models.panns", "models.utils", "models.match", "models.align", "losses",
                  "models.audio_encoder", "models.text_encoder", "models.audio_text_model",

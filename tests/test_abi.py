@@ -111,5 +111,5 @@ def test_yaml_style_construction_with_aliases():
     model = build_model(cfg)
     assert type(model).__name__ == "BiEncoder" and type(model).__module__.startswith("texttoaudiogrounding_amd")
     import sys
-    for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "losses"]:
+    for k in [k for k in sys.modules if k.split(".")[0] in ("models", "losses", "utils")]:
         del sys.modules[k]

@@ -105,3 +105,78 @@ def test_grounding_model_30s_clips_vs_oracle(dev):
     for b in range(3):
         for ti, tt in enumerate(th):
             assert np.array_equal(got[b][ti], O.segments(fs[b].numpy(), tt, 1, 13))
+
+
+def test_grounding_model_30s_full_pass_b67(dev):
+    """BASELINE configs[4] at its real pass size (models/hf_modeling_grounding.py:319-352 in the reference): 30 s clips,
+    B = 67 = ONE FULL 64-clip pass (3.15 GB first-conv output, the 32-bit activation-offset guard's regime) + a ragged
+    3-clip remainder.  Asserted: shape / finiteness, `length` semantics (frames beyond a clip's length are still scored,
+    like the reference, and the valid count is floor((len // hop + 1) / 4)), the pass split is invisible (the same clips run
+    alone give bit-identical rows), and 3 sampled clips (first of the full pass, last of it, last of the remainder) agree
+    with the CPU oracle to 1e-4 with bit-exact integer segments at the 50 thresholds."""
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import Cnn8RnnLaionClapGroundingModel
+    from texttoaudiogrounding_amd.utils import eval_util
+    S, B = 960000, 67
+    st_a = O.init_state(seed=31, add_proj=True, shared_dim=512, logit_gain=40.0)
+    st_t = C.init_text_state(seed=6)
+    st_a["audio_proj.weight"] = st_a["audio_proj.weight"] * 8.0
+    st_a["text_proj.weight"] = st_a["text_proj.weight"] * 30.0
+    g = torch.Generator().manual_seed(4101)
+    wave = 0.1 * torch.randn(B, S, generator=g)
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    lens[0] = S
+    for i in range(B):
+        wave[i, lens[i]:] = 0.0
+    ids, mask = C.synthetic_tokens(B, 10, seed=2)
+    model = Cnn8RnnLaionClapGroundingModel()          # default max_clips_per_pass = 64
+    sd = {"model." + k: v for k, v in st_a.items() if not k.startswith("text_encoder.")}
+    sd.update({"model.text_encoder." + k: v for k, v in st_t.items()})
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+    model = model.to(dev)
+    enc = model.model.audio_encoder
+    enc.train()
+    enc.dropout_p = (0.0, 0.0)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():          # calibrate the running statistics on two clips, then eval
+        enc({"waveform": wave[:2].to(dev), "waveform_len": lens[:2], "specaug": False})
+    model.eval()
+    text = {"input_ids": ids, "attention_mask": mask}
+    torch.cuda.reset_peak_memory_stats()
+    fs_dev = model(wave, lens, text)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    fs = fs_dev.cpu()
+    assert fs.shape == (B, 750) and torch.isfinite(fs).all()
+    assert fs.min() >= 1e-7 and fs.max() <= 1.0                      # sigmoid().clamp(1e-7, 1.0)
+    want_len = (lens // 320 + 1) // 4
+    out_len = model.model.audio_encoder({"waveform": wave[64:].to(dev), "waveform_len": lens[64:], "specaug": False})["length"]
+    assert torch.equal(out_len.cpu(), want_len[64:])
+    # the split into passes is invisible: clips from both passes, run alone in a different pass composition
+    pick = [0, 63, 64, 66]
+    alone = model(wave[pick], lens[pick], {"input_ids": ids[pick], "attention_mask": mask[pick]}).cpu()
+    assert torch.equal(alone, fs[pick]), (alone - fs[pick]).abs().max()
+    # ---- CPU oracle on three sampled clips (eval-mode BatchNorm: clips are independent) ----
+    st2 = {k[len("model."):]: v.detach().cpu() for k, v in model.state_dict().items() if "melspec" not in k}
+    samp = [0, 63, 66]
+    audio = O.cnn8rnn_forward({k: v for k, v in st2.items() if k.startswith("audio_encoder.")}, wave[samp],
+                              lens[samp].numpy(), training=False)["embedding"]
+    a = F.linear(audio, st2["audio_proj.weight"], st2["audio_proj.bias"])
+    tx = C.laion_clap_encoder_forward({k[len("text_encoder."):]: v for k, v in st2.items() if k.startswith("text_encoder.")},
+                                      ids[samp], mask[samp], 12, 1e-12)
+    t = F.linear(tx["seq_emb"], st2["text_proj.weight"], st2["text_proj.bias"])
+    ref = O.match_dot_product(a, t)
+    err = (fs[samp] - ref).abs().max().item()
+    print(f"30 s clips, B = 67 (64 + 3): peak memory {peak:.1f} GiB; frame_sim err on 3 sampled clips {err:.2e}; "
+          f"range [{ref.min():.3f}, {ref.max():.3f}]")
+    assert err < 1e-4
+    th = eval_util.eval_thresholds(50)
+    got = eval_util.segments_for_thresholds(fs_dev[samp].contiguous(), th, 1, eval_util.n_connect_for(0.04))
+    mism = 0
+    for j in range(3):
+        for ti, tt in enumerate(th):
+            assert np.array_equal(got[j][ti], O.segments(fs[samp[j]].numpy(), tt, 1, 13))     # kernel == oracle, same scores
+            mism += int(not np.array_equal(got[j][ti], O.segments(ref[j].numpy(), tt, 1, 13)))
+    print(f"segments vs the oracle's own scores: {mism} of {3 * len(th)} (clip, threshold) pairs differ")
+    assert mism == 0

@@ -799,7 +799,7 @@ def test_match_heads(ops, dev, golden_dir, kind, l2norm, scale):
            (1, False, False): "expnegl2_raw"}[(kind, l2norm, scale)]
     a = audio.to(dev).requires_grad_(True)
     t = text.to(dev).requires_grad_(True)
-    sim = ops.MatchFunction.apply(a, t, kind, l2norm, scale)
+    sim = torch.ops.tag.frame_match(a, t, kind, l2norm, scale)
     assert (sim.cpu() - torch.from_numpy(gold["sim_" + key])).abs().max().item() < 1e-6    # golden (reference)
     ad, td = audio.double().requires_grad_(True), text.double().requires_grad_(True)
     ref = O.match_dot_product(ad, td, l2norm, scale) if kind == 0 else O.match_exp_neg_l2(ad, td, l2norm)
@@ -815,7 +815,7 @@ def test_frame_bce(ops, dev, golden_dir):
     sim = torch.from_numpy(gold["sim_dot"])
     label, length = torch.from_numpy(gold["label"]), torch.from_numpy(gold["length"])
     s = sim.to(dev).requires_grad_(True)
-    loss = ops.FrameBceFunction.apply(s, label.to(dev), length.to(dev), sim.shape[1])
+    loss = torch.ops.tag.frame_bce(s, label.to(dev), length.to(dev), sim.shape[1])
     assert abs(loss.item() - float(gold["loss_dot"])) < 1e-6                               # golden (reference)
     sd = sim.double().requires_grad_(True)
     ref = O.frame_bce_loss(sd, label.double(), length)
@@ -825,7 +825,7 @@ def test_frame_bce(ops, dev, golden_dir):
     # saturated probabilities: log clamp at -100 and the 1e-12 guard of the backward
     edge = torch.tensor([[1.0, 1e-7, 0.5, 1.0]]), torch.tensor([[0.0, 1.0, 1.0, 1.0]])
     e = edge[0].to(dev).requires_grad_(True)
-    le = ops.FrameBceFunction.apply(e, edge[1].to(dev), torch.tensor([4]).to(dev), 4)
+    le = torch.ops.tag.frame_bce(e, edge[1].to(dev), torch.tensor([4]).to(dev), 4)
     ed = edge[0].clone().requires_grad_(True)
     lr = O.frame_bce_loss(ed, edge[1], torch.tensor([4]))
     lr.backward()

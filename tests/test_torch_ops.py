@@ -57,12 +57,15 @@ def test_ops_match_the_autograd_nodes_and_pass_opcheck(dev):
     loss.backward()
     g1 = (audio.grad.clone(), table.grad.clone())
     audio.grad = table.grad = None
-    # ... equals the composition through the autograd nodes of ops.py
+    # ... equals the same formulas driven by hand (ops.py's plain forward / backward functions, which ARE the operators'
+    # bodies) and the direct-gradient EmbedMeanFunction node kept for StrongRunner
     seq2, _ = ops.EmbedMeanFunction.apply(table, text, lens, True)
-    sim2 = ops.MatchFunction.apply(audio, seq2, 0, False, True)
-    loss2 = ops.FrameBceFunction.apply(sim2, label, length, T)
-    loss2.backward()
-    assert torch.equal(loss, loss2) and torch.equal(g1[0], audio.grad) and torch.equal(g1[1], table.grad)
+    sim2 = ops.match_forward(audio.detach(), seq2.detach(), 0, False, True)
+    loss2 = ops.frame_bce_forward(sim2, label, length, T)
+    dsim = ops.frame_bce_backward(sim2, label, length, T, torch.ones((), device=dev))
+    da, dseq = ops.match_backward(audio.detach(), seq2.detach(), sim2, dsim, 0, False, True)
+    seq2.backward(dseq)
+    assert torch.equal(loss, loss2) and torch.equal(g1[0], da) and torch.equal(g1[1], table.grad)
     # conv + GRU operators against the oracle
     x = torch.randn(2, 9, 8, 64, generator=g).to(dev).requires_grad_(True)
     w = (torch.randn(128, 64, 3, 3, generator=g) / 24).to(dev).requires_grad_(True)

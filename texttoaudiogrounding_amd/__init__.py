@@ -29,6 +29,9 @@ def install_aliases(force: bool = False):
         "models.sim_pooling": "texttoaudiogrounding_amd.models.sim_pooling",
         "models.hf_modeling_grounding": "texttoaudiogrounding_amd.models.hf_modeling_grounding",
         "losses": "texttoaudiogrounding_amd.losses",
+        "utils": "texttoaudiogrounding_amd.utils",
+        "utils.eval_util": "texttoaudiogrounding_amd.utils.eval_util",
+        "utils.train_util": "texttoaudiogrounding_amd.utils.train_util",
     }
     for alias, target in names.items():
         if alias in sys.modules and not force:

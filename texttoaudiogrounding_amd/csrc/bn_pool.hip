@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
                 for (int j = 0; j < NC; ++j) {
                     float a = fmaf(v[j], s[j], t[j]);
                     a = (act == 1) ? fmaxf(a, 0.0f) : leaky01(a);
-                    if (pool == 0) {
+                    if (pool != 1) {
                         sum[j] += a;
                         mx[j] = (dh == 0 && dw == 0) ? a : fmaxf(mx[j], a);
                     } else {
@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
         float rr[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j] : sqrtf(sqrtf(sum[j]));
+            // pool: 0 avg+max | 1 LPPool(4) | 2 avg | 3 max  (models/panns.py:51-60)
+            rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j]
+                  : (pool == 2) ? sum[j] * (1.0f / (PH * PW)) : (pool == 3) ? mx[j] : sqrtf(sqrtf(sum[j]));
             if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)e0 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
         }
         ActN<TS, NC>::st(out + e0, rr);
@@ -370,6 +372,7 @@ template <int PH, int PW, class TS = float, int NC = 4>
 struct PoolBwdCtx {
     const TS* y; const float* scale; const float* shift; const float* mean; const float* invstd;
     const TS* dout; int B, H, W, C; float drop_p; uint64_t seed;
+    float wavg, wmax;                      // pool_type: 'avg+max' (1/(PH*PW), 1) | 'avg' (1/(PH*PW), 0) | 'max' (0, 1)
     float sv[NC], tv[NC], mv[NC], iv[NC];  // per-channel constants of this thread's NC channels
     __device__ void prep(int c) {
 #pragma unroll
@@ -419,7 +422,7 @@ struct PoolBwdCtx {
             for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
                 for (int dw = 0; dw < PW; ++dw) {
-                    const float da = g[j] * ((1.0f / (PH * PW)) + ((am == dh * PW + dw) ? 1.0f : 0.0f));
+                    const float da = g[j] * (wavg + ((am == dh * PW + dw) ? wmax : 0.0f));
                     dz[dh][dw][j] = a[dh][dw][j] > 0.0f ? da : 0.0f;
                 }
         }
@@ -831,7 +834,7 @@ extern "C" int tag_bn_param_grad(const float* x, const float* dy, long rows, int
 template <class TS>
 static int bnact_pool_forward_impl(const TS* y, const float* scale, const float* shift, TS* out, int B, int H, int W, int C,
                                    int ph, int pw, int act, int pool, float drop_p, uint64_t seed, void* stream) {
-    TAG_CHECK_ARG(y && out && C % 4 == 0 && (act == 1 || act == 2) && (pool == 0 || pool == 1));
+    TAG_CHECK_ARG(y && out && C % 4 == 0 && (act == 1 || act == 2) && pool >= 0 && pool <= 3);
     TAG_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
     TAG_CHECK_ARG(vec_ok(C));
@@ -876,9 +879,11 @@ extern "C" int tag_bnact_pool_forward_bf16(const void* y, const float* scale, co
 template <class TS>
 static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, const float* gamma, const TS* dout, TS* dy, float* dgamma,
-                                     float* dbeta, int B, int H, int W, int C, int ph, int pw, float drop_p, uint64_t seed,
-                                     int bn_train, void* ws, void* stream) {
+                                     float* dbeta, int B, int H, int W, int C, int ph, int pw, int pool, float drop_p,
+                                     uint64_t seed, int bn_train, void* ws, void* stream) {
     TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && dout && dy && dgamma && dbeta && ws);
+    TAG_CHECK_ARG(pool == 0 || pool == 2 || pool == 3);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
     TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
     double* partials = static_cast<double*>(ws);
     const long slots = (long)B * (H / ph) * (W / pw);
@@ -888,7 +893,7 @@ static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const floa
     bool launched = false;
 #define POOL_BWD_NC(NC_)                                                                                           \
     {                                                                                                              \
-        PoolBwdCtx<PH, PW, TS, NC_> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed};            \
+        PoolBwdCtx<PH, PW, TS, NC_> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed, wavg, wmax}; \
         hipLaunchKernelGGL((pool_bwd_reduce_kernel<PH, PW, TS, NC_>), dim3(nblk), dim3(256), 256 * 2 * NC_ * sizeof(double), \
                            as_stream(stream), ctx, partials);                                                      \
         hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(cdiv(C, 16)), dim3(FOLD_T), 0, as_stream(stream), partials, nblk, \
@@ -912,17 +917,17 @@ static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const floa
 extern "C" int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* shift, const float* mean,
                                         const float* invstd, const float* gamma, const float* dout, float* dy,
                                         float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
-                                        float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+                                        int pool, float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
     return bnrelu_pool_backward_impl<float>(y, scale, shift, mean, invstd, gamma, dout, dy, dgamma, dbeta, B, H, W, C, ph, pw,
-                                            drop_p, seed, bn_train, ws, stream);
+                                            pool, drop_p, seed, bn_train, ws, stream);
 }
 extern "C" int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, const float* shift, const float* mean,
                                              const float* invstd, const float* gamma, const void* dout, void* dy,
                                              float* dgamma, float* dbeta, int B, int H, int W, int C, int ph, int pw,
-                                             float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
+                                             int pool, float drop_p, uint64_t seed, int bn_train, void* ws, void* stream) {
     return bnrelu_pool_backward_impl<bf16_t>(static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
                                              static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dy), dgamma, dbeta, B, H, W,
-                                             C, ph, pw, drop_p, seed, bn_train, ws, stream);
+                                             C, ph, pw, pool, drop_p, seed, bn_train, ws, stream);
 }
 
 template <class TS>

@@ -56,7 +56,7 @@ _SIGS = {
     "tag_bnact_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_uint64, P]),
     "tag_bn_backward_ws_bytes": (c_size_t, [c_long, c_int]),
-    "tag_bnrelu_pool_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+    "tag_bnrelu_pool_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_float, c_uint64, c_int, P, P]),
     "tag_bnrelu_backward": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
     "tag_bn_act_backward": (c_int, [P, c_int, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
@@ -113,7 +113,7 @@ _SIGS = {
     "tag_conv3x3_wgrad_x3_bf16": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_bnact_pool_forward_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_float, c_uint64, P]),
-    "tag_bnrelu_pool_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+    "tag_bnrelu_pool_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                               c_float, c_uint64, c_int, P, P]),
     "tag_bnrelu_backward_bf16": (c_int, [P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
     "tag_conv3x3_dgrad_bnsums_bf16": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import torch_ops  # noqa: F401  (registers torch.ops.tag.*)
 
 
 class FrameBceLoss(nn.Module):
@@ -19,7 +20,7 @@ class FrameBceLoss(nn.Module):
         if frame_sim.size(1) != label.size(1):
             raise RuntimeError("frame_sim and label must be aligned first (Runner.forward does it)")
         length = torch.as_tensor(length).long().to(frame_sim.device).contiguous()
-        return ops.FrameBceFunction.apply(frame_sim, label.to(frame_sim.device).float(), length, Tt)
+        return torch.ops.tag.frame_bce(frame_sim, label.to(frame_sim.device).float(), length, Tt)
 
 
 class ClipBceLoss(nn.Module):
@@ -32,7 +33,7 @@ class ClipBceLoss(nn.Module):
     def forward_tensor(self, prob, label):
         B, N = prob.shape
         length = torch.full((B,), N, dtype=torch.long, device=prob.device)
-        return ops.FrameBceFunction.apply(prob.contiguous(), label.to(prob.device).float().contiguous(), length, N)
+        return torch.ops.tag.frame_bce(prob.contiguous(), label.to(prob.device).float().contiguous(), length, N)
 
 
 class MaxMarginRankingLoss(nn.Module):
@@ -65,6 +66,6 @@ class ClipFrameBceLoss(nn.Module):
         fs2 = fs.transpose(1, 2).reshape(B * N, T)                      # a view for MultiTextBiEncoder's output
         lab2 = lab.to(fs.device).float().transpose(1, 2).reshape(B * N, T).contiguous()
         length = torch.as_tensor(output["length"]).long().to(fs.device).repeat_interleave(N).contiguous()
-        frame = ops.FrameBceFunction.apply(fs2.contiguous(), lab2, length, T)
+        frame = torch.ops.tag.frame_bce(fs2.contiguous(), lab2, length, T)
         clip = self.clip_loss_fn.forward_tensor(output[self.clip_prob_key], output[self.clip_label_key])
         return (1 - self.frame_weight) * clip + self.frame_weight * frame

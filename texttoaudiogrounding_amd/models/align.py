@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops  # noqa: F401  (registers torch.ops.tag.*)
 
 
 class DotProduct(nn.Module):
@@ -16,4 +16,4 @@ class DotProduct(nn.Module):
         t_bs, _, t_dim = text.size()
         assert a_bs == t_bs
         assert a_dim == t_dim
-        return ops.AlignDotFunction.apply(audio, text, self.l2norm, self.scaled)
+        return torch.ops.tag.align_dot(audio, text, bool(self.l2norm), bool(self.scaled))

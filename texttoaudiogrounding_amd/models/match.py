@@ -1,7 +1,9 @@
 """Frame x phrase similarity heads (mirror of models/match.py:10-88 in the reference)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import torch_ops  # noqa: F401  (registers torch.ops.tag.*)
 
 
 def _token_text(input_dict):
@@ -23,7 +25,7 @@ class ExpNegL2(nn.Module):
     def forward(self, input_dict):
         if self.text_level == "token":
             return ops.RowPairFunction.apply(input_dict["audio_emb"], _token_text(input_dict), 1, self.l2norm, False)
-        return ops.MatchFunction.apply(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 1, self.l2norm, False)
+        return torch.ops.tag.frame_match(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 1, bool(self.l2norm), False)
 
 
 class DotProduct(nn.Module):
@@ -40,7 +42,8 @@ class DotProduct(nn.Module):
             if self.l2norm:
                 return ops.RowPairFunction.apply(input_dict["audio_emb"], text, 0, True, self.scale)
             return ops.RowDotFunction.apply(input_dict["audio_emb"], text, self.scale)
-        return ops.MatchFunction.apply(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 0, self.l2norm, self.scale)
+        return torch.ops.tag.frame_match(input_dict["audio_emb"], input_dict["text_emb"]["seq_emb"], 0, bool(self.l2norm),
+                                         bool(self.scale))
 
 
 class CrossAttention(nn.Module):

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import torch_ops  # noqa: F401  (registers torch.ops.tag.*)
 from .utils import init_weights
 
 
@@ -58,7 +59,10 @@ class EmbeddingAgg(nn.Module):
         dev = table.device
         text = input_dict["text"].long().to(dev).contiguous()
         lens = torch.as_tensor(input_dict["text_len"]).long().to(dev).contiguous()
-        seq, tok = ops.EmbedMeanFunction.apply(table, text, lens, True)
+        if ops.DIRECT_GRADS:          # StrongRunner: scatter the table gradient straight into its flat-gradient rows
+            seq, tok = ops.EmbedMeanFunction.apply(table, text, lens, True)
+        else:
+            seq, tok = torch.ops.tag.embed_mean(table, text, lens)
         if self.agg == "attention":
             seq = self.attn(tok, lens)
         return {"token_emb": tok, "seq_emb": seq}

@@ -79,19 +79,64 @@ GRAD_READY = None        # callable(list of parameters) -> None: their gradient 
 GRAD_FLUSH = None        # callable() -> None: a safe point to launch the all-reduce of every complete bucket
 
 
+#: per training step (begin_direct_step): how many autograd nodes claimed each parameter in the forward pass, and which
+#: sinks have been written in the backward pass.  A parameter seen by ONE node gets its gradient written in place; a
+#: parameter shared by several nodes (a Linear applied twice, an encoder called twice) is NOT delivered directly by any of
+#: them -- every contribution goes back to autograd, whose AccumulateGrad sums them into p.grad (= the same flat view) --
+#: and is not announced to the gradient buckets early (GradBuckets.finish() exchanges it after backward).
+_CLAIMS = {}
+_WRITTEN = set()
+
+
+def begin_direct_step():
+    """Called by StrongRunner.forward_backward after zero_grad, before the forward pass."""
+    _CLAIMS.clear()
+    _WRITTEN.clear()
+
+
+class _LazySinks:
+    """List-like view of the flat-gradient sinks of a node's parameters, resolved when INDEXED (i.e. in backward, when the
+    claim counts of the whole forward pass are known)."""
+
+    def __init__(self, params, direct):
+        self.params, self.direct = list(params), direct
+        if direct:
+            for t in self.params:
+                if isinstance(t, torch.Tensor) and t.requires_grad and getattr(t, "_tag_grad_sink", None) is not None:
+                    _CLAIMS[id(t)] = _CLAIMS.get(id(t), 0) + 1
+
+    def _one(self, t):
+        if not self.direct or not (isinstance(t, torch.Tensor) and t.requires_grad):
+            return None
+        sink = getattr(t, "_tag_grad_sink", None)
+        return sink if (sink is not None and _CLAIMS.get(id(t), 0) == 1) else None
+
+    def __len__(self):
+        return len(self.params)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._one(t) for t in self.params[i]]
+        return self._one(self.params[i])
+
+
 def _sinks(params):
-    """Per input parameter: its flat-gradient view, or None (frozen parameter / direct gradients off)."""
-    if not DIRECT_GRADS:
-        return [None] * len(params)
-    return [getattr(t, "_tag_grad_sink", None) if (isinstance(t, torch.Tensor) and t.requires_grad) else None
-            for t in params]
+    """Per input parameter: its flat-gradient view, or None (frozen parameter / direct gradients off / a parameter claimed
+    by more than one node in this forward pass)."""
+    return _LazySinks(params, DIRECT_GRADS)
 
 
 def _deliver(grads, sinks, i, val):
     """Gradient ``val`` of input i: copied into its sink (the node then returns None) or returned to autograd."""
-    if sinks[i] is not None:
-        if val.data_ptr() != sinks[i].data_ptr():
-            sinks[i].copy_(val.view_as(sinks[i]))
+    sink = sinks[i]
+    if sink is not None:
+        key = sink.data_ptr()
+        if key in _WRITTEN:
+            raise RuntimeError("direct gradients: a flat-gradient sink was written twice in one step (a retained graph run "
+                               "twice?); plain autograd would have accumulated -- run this pattern with ops.DIRECT_GRADS off")
+        _WRITTEN.add(key)
+        if val.data_ptr() != key:
+            sink.copy_(val.view_as(sink))
         grads[i] = None
     else:
         grads[i] = val
@@ -99,7 +144,7 @@ def _deliver(grads, sinks, i, val):
 
 def _ready(params):
     if GRAD_READY is not None and params:
-        GRAD_READY([t for t in params if isinstance(t, torch.Tensor)])
+        GRAD_READY([t for t in params if isinstance(t, torch.Tensor) and _CLAIMS.get(id(t), 0) == 1])
 
 
 def _flush():
@@ -412,7 +457,7 @@ def bnact_pool(y, st: Optional[BNStat], ph, pw, act=1, pool=0, drop_p=0.0, seed=
     return out
 
 
-def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None):
+def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None, pool=0):
     B, H, W, C = y.shape
     if dout.dtype != y.dtype:
         raise RuntimeError("bnrelu_pool_backward: y and dout must share their storage type")
@@ -421,7 +466,7 @@ def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0,
     db = db_out if db_out is not None else _empty(C, like=y)
     ws = _ws(query("tag_bn_backward_ws_bytes", B * H * W, C), y)
     call("tag_bnrelu_pool_backward" + _sfx(y), ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-         ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, float(drop_p), seed, int(st.train), ptr(ws))
+         ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, int(pool), float(drop_p), seed, int(st.train), ptr(ws))
     return dy, dg, db
 
 
@@ -497,12 +542,15 @@ def segments(frame_sim, thresholds, window_size, n_connect):
 
 
 def align_dot(audio, text, l2norm=False, scaled=False):
+    """align.DotProduct forward (models/align.py:14-31): (B,T,D),(B,N,D) -> (B,B,T,N); F.normalize of both operands first
+    when l2norm (row kernels), then the MFMA GEMM with the [/sqrt D ->] sigmoid -> clamp -> (B,B,T,N) scatter epilogue."""
     audio, text = _chk(audio, "audio"), _chk(text, "text")
     B, T, D = audio.shape
     N = text.shape[1]
+    if l2norm:
+        audio, text = _l2norm_rows(audio, B * T, D), _l2norm_rows(text, B * N, D)
     out = _empty(B, B, T, N, like=audio)
-    ws = _empty((B * T + B * N) * D, like=audio) if l2norm else None
-    call("tag_align_dot_forward", ptr(audio), ptr(text), ptr(out), int(l2norm), int(scaled), B, T, N, D, ptr(ws))
+    call("tag_align_dot_forward", ptr(audio), ptr(text), ptr(out), 0, int(scaled), B, T, N, D, None)
     return out
 
 
@@ -797,6 +845,50 @@ class Cnn8RnnFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# One conv3x3 -> BatchNorm -> ReLU (-> pool) stage as a standalone operator: what SURVEY.md section 8(b) lists as
+# ``conv3x3_bn_relu[_pool]`` and what ConvBlock.forward (models/panns.py:46-62) is made of.  The fused Cnn8Rnn engine above
+# never materialises relu(bn(y)); this stage does (its output IS that tensor, pooled), so that it composes like an nn.Module.
+# ------------------------------------------------------------------------------------------------
+POOL_TYPES = {"avg+max": 0, "avg": 2, "max": 3}
+
+
+def conv_bn_relu_pool_forward(x, w, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, pool):
+    """x channels-last (B,H,W,Cin) fp32; w (Cout,Cin,3,3).  -> (out (B,H/ph,W/pw,Cout), y raw conv output, BNStat).
+    running statistics are updated in place when training (nn.BatchNorm2d semantics)."""
+    x = _chk(x, "x")
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if Cin == 1:
+        y, part = conv3x3_c1_stats(x.view(B, H, W), w, want_stats=training)
+    elif Cin % 32 == 0:
+        wf, _ = pack_conv_weight(w, want_dgrad=False, W=W)
+        y, part = conv3x3_stats(x, wf, Cout, want_stats=training)
+    else:
+        raise RuntimeError(f"conv3x3_bn_relu_pool: in_channels must be 1 or a multiple of 32, got {Cin}")
+    st = bn_stats(y.view(-1, Cout), gamma, beta, running_mean, running_var, training, eps, momentum, partials=part)
+    out = bnact_pool(y, st, ph, pw, act=1, pool=pool)
+    return out, y, st
+
+
+def conv_bn_relu_pool_backward(dout, x, w, y, st: BNStat, gamma, ph, pw, pool, need_dx=True):
+    """-> (dx or None, dw, dgamma, dbeta): BatchNorm/ReLU/pool backward (two passes over y), weight gradient and input
+    gradient of the stage above."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    dy, dg, db = bnrelu_pool_backward(y, st, gamma, _chk(dout, "grad_output"), ph, pw, pool=pool)
+    if Cin == 1:
+        dw = conv3x3_c1_wgrad(x.view(B, H, W), dy)
+        dx = conv3x3_c1_dgrad(dy, w).view(B, H, W, 1) if need_dx else None
+    else:
+        dw = conv3x3_wgrad(x, dy)
+        dx = None
+        if need_dx:
+            _, wd = pack_conv_weight(w, want_dgrad=True, W=W)
+            dx = conv3x3(dy, wd, Cin)
+    return dx, dw, dg, db
+
+
+# ------------------------------------------------------------------------------------------------
 # CrnnEncoder (row A1'): cdur_block = BN -> conv3x3 -> LeakyReLU(0.1), LPPool2d(4), Dropout(0.3), BiGRU(128)
 # ------------------------------------------------------------------------------------------------
 
@@ -960,127 +1052,122 @@ class LinearFunction(torch.autograd.Function):
         return tuple(g)
 
 
+# Each head's forward / backward arithmetic lives in ONE plain function below.  texttoaudiogrounding_amd/torch_ops.py
+# registers them as PyTorch operators (torch.ops.tag.embed_mean / frame_match / align_dot / frame_bce + *_backward, with
+# autograd formulas) and the reference-shaped modules (models/match.py, models/align.py, losses.py, models/text_encoder.py)
+# call THOSE operators; the only autograd.Function kept here is EmbedMeanFunction, the direct-gradient variant that scatters
+# straight into the flat-gradient rows of the table (an operator may not mutate hidden state).
+
+def embed_mean_forward(table, text, text_len, want_tokens=True):
+    """nn.Embedding gather + mean over the valid tokens (rows T1/T2): -> (seq_emb (B,D), token_emb (B,L,D) or None)."""
+    tab = _chk(table, "embedding table")
+    if not text.is_cuda:
+        raise RuntimeError("embed_mean: token ids must live on the device (no CPU fallback)")
+    B, L = text.shape
+    V, D = tab.shape
+    seq = _empty(B, D, like=tab)
+    tok = _empty(B, L, D, like=tab) if want_tokens else None
+    call("tag_embed_check_ids", ptr(text), B * L, V, ptr(_embed_flag(tab)))     # nn.Embedding raises; see check_async_errors
+    call("tag_embed_mean_forward", ptr(text), ptr(text_len), ptr(tab), ptr(tok), ptr(seq), B, L, D, V)
+    return seq, tok
+
+
+def embed_mean_backward_into(dtab, dseq, dtok, text, text_len):
+    """Adds the seq_emb / token_emb gradients into ``dtab`` (V,D) -- a zeroed tensor or the zeroed flat-gradient rows of the
+    table.  Deterministic (fixed-order per-row sums, no atomics)."""
+    B, L = text.shape
+    V, D = dtab.shape
+    if dseq is not None:
+        call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
+    if dtok is not None:
+        call("tag_embed_tokens_backward", ptr(_chk(dtok, "grad")), ptr(text), ptr(dtab), B, L, D, V)
+    return dtab
+
+
 class EmbedMeanFunction(torch.autograd.Function):
-    """nn.Embedding gather + mean over valid tokens (rows T1/T2).  token_emb is differentiable too (the cross-encoder
-    consumes it): its gradient is a scatter-add into the table (tag_embed_tokens_backward)."""
+    """embed_mean with direct gradients (StrongRunner): the table gradient is scattered straight into the (zeroed)
+    flat-gradient rows; same kernels as torch.ops.tag.embed_mean."""
 
     @staticmethod
     def forward(ctx, table, text, text_len, want_tokens):
-        tab = _chk(table.detach(), "embedding table")
-        B, L = text.shape
-        V, D = tab.shape
-        seq = _empty(B, D, like=tab)
-        tok = _empty(B, L, D, like=tab) if want_tokens else None
-        call("tag_embed_check_ids", ptr(text), B * L, V, ptr(_embed_flag(tab)))     # nn.Embedding raises; see check_async_errors
-        call("tag_embed_mean_forward", ptr(text), ptr(text_len), ptr(tab), ptr(tok), ptr(seq), B, L, D, V)
+        seq, tok = embed_mean_forward(table.detach(), text, text_len, want_tokens)
         ctx.save_for_backward(text, text_len)
-        ctx.shape = (B, L, D, V)
-        ctx.sink = _sinks([table])[0]
-        ctx.table = table if ctx.sink is not None else None
+        ctx.vd = tuple(table.shape)
+        ctx.sinks = _sinks([table])
+        ctx.table = table
         ctx.set_materialize_grads(False)
         return seq, tok
 
     @staticmethod
     def backward(ctx, dseq, dtok):
         text, text_len = ctx.saved_tensors
-        B, L, D, V = ctx.shape
-        # direct gradients: scatter straight into the (zeroed) flat-gradient rows of the table; otherwise a dense zeroed
-        # (V,D) gradient for autograd.  Deterministic either way (fixed-order per-row sums, no atomics).
-        direct = ctx.sink is not None
-        dtab = ctx.sink if direct else torch.zeros(V, D, device=text.device, dtype=F32)
-        if dseq is not None:
-            call("tag_embed_mean_backward", ptr(_chk(dseq, "grad")), ptr(text), ptr(text_len), ptr(dtab), B, L, D, V)
-        if dtok is not None:
-            call("tag_embed_tokens_backward", ptr(_chk(dtok, "grad")), ptr(text), ptr(dtab), B, L, D, V)
+        sink = ctx.sinks[0]
+        direct = sink is not None
+        dtab = sink if direct else torch.zeros(*ctx.vd, device=text.device, dtype=F32)
+        embed_mean_backward_into(dtab, dseq, dtok, text, text_len)
         if direct:
             _ready([ctx.table])
             return None, None, None, None
         return dtab, None, None, None
 
 
-class MatchFunction(torch.autograd.Function):
-    """match.DotProduct (kind 0) / match.ExpNegL2 (kind 1), text_level='seq'."""
-
-    @staticmethod
-    def forward(ctx, audio, text, kind, l2norm, scale):
-        a, t = _chk(audio, "audio_emb"), _chk(text, "text_emb")
-        B, T, D = a.shape
-        sim = _empty(B, T, like=a)
-        call("tag_match_forward", ptr(a), ptr(t), ptr(sim), kind, int(l2norm), int(scale), B, T, D)
-        ctx.save_for_backward(a, t, sim)
-        ctx.cfg = (kind, int(l2norm), int(scale))
-        return sim
-
-    @staticmethod
-    def backward(ctx, dsim):
-        a, t, sim = ctx.saved_tensors
-        kind, l2norm, scale = ctx.cfg
-        B, T, D = a.shape
-        da, dt = torch.empty_like(a), torch.empty_like(t)
-        call("tag_match_backward", ptr(a), ptr(t), ptr(sim), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), kind, l2norm,
-             scale, B, T, D)
-        return da, dt, None, None, None
+def match_forward(audio, text, kind, l2norm, scale):
+    """match.DotProduct (kind 0) / match.ExpNegL2 (kind 1), text_level='seq' (models/match.py:16-33,43-60): (B,T,D),(B,D) -> (B,T)."""
+    a, t = _chk(audio, "audio_emb"), _chk(text, "text_emb")
+    B, T, D = a.shape
+    sim = _empty(B, T, like=a)
+    call("tag_match_forward", ptr(a), ptr(t), ptr(sim), int(kind), int(l2norm), int(scale), B, T, D)
+    return sim
 
 
-class FrameBceFunction(torch.autograd.Function):
-    """FrameBceLoss (losses.py:12-24) on (frame_sim[:, :Tt], label[:, :Tt], clamp(length, 1, Tt))."""
-
-    @staticmethod
-    def forward(ctx, sim, label, length, Tt):
-        s, lab = _chk(sim, "frame_sim"), _chk(label, "label")
-        B = s.shape[0]
-        loss = _empty(1, like=s)
-        call("tag_frame_bce_forward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), B, Tt, ptr(loss))
-        ctx.save_for_backward(s, lab, length)
-        ctx.Tt = Tt
-        return loss.view(())
-
-    @staticmethod
-    def backward(ctx, dloss):
-        s, lab, length = ctx.saved_tensors
-        B = s.shape[0]
-        ds = torch.empty_like(s)
-        dl = _chk(dloss.reshape(1), "grad")
-        call("tag_frame_bce_backward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), B, ctx.Tt, ptr(dl),
-             ptr(ds))
-        return ds, None, None, None
+def match_backward(audio, text, sim, dsim, kind, l2norm, scale):
+    a, t = _chk(audio, "audio_emb"), _chk(text, "text_emb")
+    B, T, D = a.shape
+    da, dt = torch.empty_like(a), torch.empty_like(t)
+    call("tag_match_backward", ptr(a), ptr(t), ptr(sim), ptr(_chk(dsim, "grad")), ptr(da), ptr(dt), int(kind), int(l2norm),
+         int(scale), B, T, D)
+    return da, dt
 
 
-class AlignDotFunction(torch.autograd.Function):
-    """align.DotProduct (models/align.py:14-31) with gradients: (B,T,D),(B,N,D) -> (B,B,T,N)."""
+def frame_bce_forward(sim, label, length, Tt):
+    """FrameBceLoss (losses.py:12-24) on (frame_sim[:, :Tt], label[:, :Tt], clamp(length, 1, Tt)) -> 0-dim loss."""
+    s, lab = _chk(sim, "frame_sim"), _chk(label, "label")
+    loss = _empty(1, like=s)
+    call("tag_frame_bce_forward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), s.shape[0], int(Tt), ptr(loss))
+    return loss.view(())
 
-    @staticmethod
-    def forward(ctx, audio, text, l2norm, scaled):
-        a, t = _chk(audio, "audio"), _chk(text, "text")
-        B, T, D = a.shape
-        N = t.shape[1]
-        an, tn = a, t
-        if l2norm:
-            an, tn = torch.empty_like(a), torch.empty_like(t)
-            call("tag_l2norm_rows_forward", ptr(a), ptr(an), B * T, D)
-            call("tag_l2norm_rows_forward", ptr(t), ptr(tn), B * N, D)
-        out = _empty(B, B, T, N, like=a)
-        call("tag_align_dot_forward", ptr(an), ptr(tn), ptr(out), 0, int(scaled), B, T, N, D, None)
-        ctx.save_for_backward(a, t, an, tn, out)
-        ctx.cfg = (bool(l2norm), bool(scaled))
-        return out
 
-    @staticmethod
-    def backward(ctx, dout):
-        a, t, an, tn, out = ctx.saved_tensors
-        l2norm, scaled = ctx.cfg
-        B, T, D = a.shape
-        N = t.shape[1]
-        ds = _empty(B * T, B * N, like=a)
-        call("tag_align_dot_dscore", ptr(out), ptr(_chk(dout, "grad")), ptr(ds), int(scaled), B, T, N, D)
-        da = gemm(ds, tn.view(B * N, D), B * T, D, B * N)                       # (B*T, D)
-        dt = gemm(ds, an.view(B * T, D), B * N, D, B * T, transA=True, lda=B * N)   # (B*N, D)
-        if l2norm:
-            da2, dt2 = torch.empty_like(da), torch.empty_like(dt)
-            call("tag_l2norm_rows_backward", ptr(a), ptr(da), ptr(da2), B * T, D)
-            call("tag_l2norm_rows_backward", ptr(t), ptr(dt), ptr(dt2), B * N, D)
-            da, dt = da2, dt2
-        return da.view(B, T, D), dt.view(B, N, D), None, None
+def frame_bce_backward(sim, label, length, Tt, dloss):
+    s, lab = _chk(sim, "frame_sim"), _chk(label, "label")
+    ds = torch.empty_like(s)
+    call("tag_frame_bce_backward", ptr(s), s.shape[1], ptr(lab), lab.shape[1], ptr(length), s.shape[0], int(Tt),
+         ptr(_chk(dloss.reshape(1), "grad")), ptr(ds))
+    return ds
+
+
+def _l2norm_rows(x, rows, D):
+    y = torch.empty_like(x)
+    call("tag_l2norm_rows_forward", ptr(x), ptr(y), rows, D)
+    return y
+
+
+def align_dot_backward(audio, text, out, dout, l2norm, scaled):
+    """Gradient of align.DotProduct (models/align.py:14-31): d score from (out, dout), then two MFMA GEMMs against the
+    (re-normalised when l2norm) operands and the backward of F.normalize."""
+    a, t = _chk(audio, "audio"), _chk(text, "text")
+    B, T, D = a.shape
+    N = t.shape[1]
+    an, tn = (_l2norm_rows(a, B * T, D), _l2norm_rows(t, B * N, D)) if l2norm else (a, t)
+    ds = _empty(B * T, B * N, like=a)
+    call("tag_align_dot_dscore", ptr(out), ptr(_chk(dout, "grad")), ptr(ds), int(scaled), B, T, N, D)
+    da = gemm(ds, tn.view(B * N, D), B * T, D, B * N)                       # (B*T, D)
+    dt = gemm(ds, an.view(B * T, D), B * N, D, B * T, transA=True, lda=B * N)   # (B*N, D)
+    if l2norm:
+        da2, dt2 = torch.empty_like(da), torch.empty_like(dt)
+        call("tag_l2norm_rows_backward", ptr(a), ptr(da), ptr(da2), B * T, D)
+        call("tag_l2norm_rows_backward", ptr(t), ptr(dt), ptr(dt2), B * N, D)
+        da, dt = da2, dt2
+    return da.view(B, T, D), dt.view(B, N, D)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1099,56 +1186,42 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gnorm_sq=None, max_norm=0
          float(max_norm), float(grad_scale))
 
 
-class CrossEncoderFunction(torch.autograd.Function):
-    """CrossAttentionGating (models/cross_encoder.py:60-79): additive attention of every frame over the phrase tokens,
-    then sigmoid cross-gating.  inputs audio (B,T,D), token (B,L,D); outputs (u_out, s_out) both (B,T,D).
-    params: h2attn.weight (Da, 2D), h2attn.bias (Da), v (Da), fc_u.{weight,bias}, fc_s.{weight,bias}."""
+class Seq2SeqAttentionFunction(torch.autograd.Function):
+    """Seq2SeqAttention.forward (models/cross_encoder.py:11-42): additive attention of every query row over the key/value
+    rows, ``score[b,q,k] = v . tanh(W [query_q ; kv_k] + b)``, the two -1e10 mask fills, softmax over k, ``out = attn @ kv``.
+    The reference materialises the (B, Lq*Lk, Dq+Dkv) concatenation; here ``W = [Wq | Wk]`` is applied as two MFMA GEMMs and
+    cross.hip does the rest.  query (B,Lq,Dq), kv (B,Lk,Dkv) -> (B,Lq,Dkv).  params: h2attn.weight (Da, Dq+Dkv),
+    h2attn.bias (Da), v (Da)."""
 
     @staticmethod
-    def forward(ctx, audio, token, audio_len, text_len, w_h, b_h, v, w_u, b_u, w_s, b_s):
-        a, t = _chk(audio, "audio_emb"), _chk(token, "token_emb")
+    def forward(ctx, query, kv, query_len, kv_len, w_h, b_h, v):
+        a, t = _chk(query, "query"), _chk(kv, "kv")
         B, T, D = a.shape
         L, Dk = t.shape[1], t.shape[2]
         Da = w_h.shape[0]
-        ctx.sinks = _sinks([w_h, b_h, v, w_u, b_u, w_s, b_s])
-        ctx.params = [w_h, b_h, v, w_u, b_u, w_s, b_s] if DIRECT_GRADS else None
-        w_h, b_h, v, w_u, b_u, w_s, b_s = (_chk(x.detach(), "parameter") for x in (w_h, b_h, v, w_u, b_u, w_s, b_s))
-        if w_h.shape[1] != D + Dk or w_u.shape != (D, D) or w_s.shape != (Dk, Dk) or D != Dk:
-            raise RuntimeError("CrossAttentionGating: inconsistent dimensions")
+        ctx.sinks = _sinks([w_h, b_h, v])
+        ctx.params = [w_h, b_h, v] if DIRECT_GRADS else None
+        w_h, b_h, v = (_chk(x.detach(), "parameter") for x in (w_h, b_h, v))
+        if w_h.shape[1] != D + Dk or b_h.shape != (Da,) or v.shape != (Da,):
+            raise RuntimeError("Seq2SeqAttention: inconsistent dimensions")
         dev = a.device
-        ql = torch.as_tensor(audio_len).long().to(dev).contiguous()
-        kl = torch.as_tensor(text_len).long().to(dev).contiguous()
-        M = B * T
-        aq = gemm(a, w_h, M, Da, D, transB=True, ldb=D + Dk)
+        ql = torch.as_tensor(query_len).long().to(dev).contiguous()
+        kl = torch.as_tensor(kv_len).long().to(dev).contiguous()
+        aq = gemm(a, w_h, B * T, Da, D, transB=True, ldb=D + Dk)
         ak = gemm(t, w_h[:, D:], B * L, Da, Dk, transB=True, ldb=D + Dk, bias=b_h)
         attn = _empty(B, T, L, like=a)
         cx = _empty(B, T, Dk, like=a)
         call("tag_addattn_forward", ptr(aq), ptr(ak), ptr(v), ptr(t), ptr(ql), ptr(kl), ptr(attn), ptr(cx), B, T, L, Da, Dk)
-        g_u = gemm(a, w_u, M, D, D, transB=True, bias=b_u, act=5)
-        g_s = gemm(cx, w_s, M, Dk, Dk, transB=True, bias=b_s, act=5)
-        u_out, s_out = torch.empty_like(a), torch.empty_like(cx)
-        call("tag_mul", ptr(a), ptr(g_s), ptr(u_out), a.numel())
-        call("tag_mul", ptr(cx), ptr(g_u), ptr(s_out), cx.numel())
-        ctx.save_for_backward(a, t, aq, ak, attn, cx, g_u, g_s, ql, kl, w_h, v, w_u, w_s)
-        return u_out, s_out
+        ctx.save_for_backward(a, t, aq, ak, attn, ql, kl, w_h, v)
+        return cx
 
     @staticmethod
-    def backward(ctx, du_out, ds_out):
-        a, t, aq, ak, attn, cx, g_u, g_s, ql, kl, w_h, v, w_u, w_s = ctx.saved_tensors
+    def backward(ctx, dcx):
+        a, t, aq, ak, attn, ql, kl, w_h, v = ctx.saved_tensors
         B, T, D = a.shape
         L, Dk = t.shape[1], t.shape[2]
         Da, M = w_h.shape[0], B * T
-        du_out, ds_out = _chk(du_out, "grad"), _chk(ds_out, "grad")
-        da, dz_s = torch.empty_like(a), torch.empty_like(a)
-        call("tag_gate_backward", ptr(du_out), ptr(a), ptr(g_s), ptr(da), 0, ptr(dz_s), a.numel())       # u_out = a * g_s
-        dcx, dz_u = torch.empty_like(cx), torch.empty_like(cx)
-        call("tag_gate_backward", ptr(ds_out), ptr(cx), ptr(g_u), ptr(dcx), 0, ptr(dz_u), cx.numel())    # s_out = cx * g_u
-        dw_s = gemm(dz_s, cx, Dk, Dk, M, transA=True, lda=Dk)
-        db_s = colsum(dz_s, M, Dk)
-        gemm(dz_s, w_s, M, Dk, Dk, out=dcx, accumulate=True)
-        dw_u = gemm(dz_u, a, D, D, M, transA=True, lda=D)
-        db_u = colsum(dz_u, M, D)
-        gemm(dz_u, w_u, M, D, D, out=da, accumulate=True)
+        dcx = _chk(dcx, "grad")
         daq, dak = _empty(B, T, Da, like=a), _empty(B, L, Da, like=a)
         dkv, dv = _empty(B, L, Dk, like=a), _empty(Da, like=a)
         ws = _ws(query("tag_addattn_backward_ws_bytes", B, T, L, Da, Dk), a)
@@ -1158,13 +1231,58 @@ class CrossEncoderFunction(torch.autograd.Function):
         gemm(daq, a, Da, D, M, transA=True, lda=Da, out=dw_h, ldc=D + Dk)
         gemm(dak, t, Da, Dk, B * L, transA=True, lda=Da, out=dw_h[:, D:], ldc=D + Dk)
         db_h = colsum(dak, B * L, Da)
-        gemm(daq, w_h, M, D, Da, ldb=D + Dk, out=da, accumulate=True)
+        da = gemm(daq, w_h, M, D, Da, ldb=D + Dk).view(B, T, D)
         gemm(dak, w_h[:, D:], B * L, Dk, Da, ldb=D + Dk, out=dkv, accumulate=True)
-        g = [dw_h, db_h, dv, dw_u, db_u, dw_s, db_s]
-        for k in range(7):
+        g = [dw_h, db_h, dv]
+        for k in range(3):
             _deliver(g, ctx.sinks, k, g[k])
         _ready(ctx.params)
         return (da, dkv, None, None, *g)
+
+
+class CrossGatingFunction(torch.autograd.Function):
+    """CrossGating.forward (models/cross_encoder.py:45-57): ``s_out = s * sigmoid(fc_u(u))``, ``u_out = u * sigmoid(fc_s(s))``
+    -- two MFMA GEMMs with the sigmoid epilogue + tag_mul / tag_gate_backward.  u, s (..., D) -> (u_out, s_out)."""
+
+    @staticmethod
+    def forward(ctx, u, s, w_u, b_u, w_s, b_s):
+        a, cx = _chk(u, "u"), _chk(s, "s")
+        D = a.shape[-1]
+        if cx.shape != a.shape or w_u.shape != (D, D) or w_s.shape != (D, D):
+            raise RuntimeError("CrossGating: inconsistent dimensions")
+        ctx.sinks = _sinks([w_u, b_u, w_s, b_s])
+        ctx.params = [w_u, b_u, w_s, b_s] if DIRECT_GRADS else None
+        w_u, b_u, w_s, b_s = (_chk(x.detach(), "parameter") for x in (w_u, b_u, w_s, b_s))
+        M = a.numel() // D
+        g_u = gemm(a, w_u, M, D, D, transB=True, bias=b_u, act=5)
+        g_s = gemm(cx, w_s, M, D, D, transB=True, bias=b_s, act=5)
+        u_out, s_out = torch.empty_like(a), torch.empty_like(cx)
+        call("tag_mul", ptr(a), ptr(g_s), ptr(u_out), a.numel())
+        call("tag_mul", ptr(cx), ptr(g_u), ptr(s_out), cx.numel())
+        ctx.save_for_backward(a, cx, g_u, g_s, w_u, w_s)
+        return u_out, s_out
+
+    @staticmethod
+    def backward(ctx, du_out, ds_out):
+        a, cx, g_u, g_s, w_u, w_s = ctx.saved_tensors
+        D = a.shape[-1]
+        M = a.numel() // D
+        du_out, ds_out = _chk(du_out, "grad"), _chk(ds_out, "grad")
+        da, dz_s = torch.empty_like(a), torch.empty_like(a)
+        call("tag_gate_backward", ptr(du_out), ptr(a), ptr(g_s), ptr(da), 0, ptr(dz_s), a.numel())       # u_out = u * g_s
+        dcx, dz_u = torch.empty_like(cx), torch.empty_like(cx)
+        call("tag_gate_backward", ptr(ds_out), ptr(cx), ptr(g_u), ptr(dcx), 0, ptr(dz_u), cx.numel())    # s_out = s * g_u
+        dw_s = gemm(dz_s, cx, D, D, M, transA=True, lda=D)
+        db_s = colsum(dz_s, M, D)
+        gemm(dz_s, w_s, M, D, D, out=dcx, accumulate=True)
+        dw_u = gemm(dz_u, a, D, D, M, transA=True, lda=D)
+        db_u = colsum(dz_u, M, D)
+        gemm(dz_u, w_u, M, D, D, out=da, accumulate=True)
+        g = [dw_u, db_u, dw_s, db_s]
+        for k in range(4):
+            _deliver(g, ctx.sinks, k, g[k])
+        _ready(ctx.params)
+        return (da, dcx, *g)
 
 
 class CrossAttentionHeadFunction(torch.autograd.Function):

@@ -32,9 +32,10 @@ class FlatParams:
     """Re-homes every trainable parameter (and its .grad) into one contiguous buffer each.
 
     ``p._tag_grad_sink`` is the parameter's view of the flat gradient: inside ``direct_grads()`` the HIP autograd nodes
-    write gradients there themselves (no ``grad += new`` kernels).  Only ``FlatParams.zero_grad`` may clear gradients:
-    ``model.zero_grad()`` / ``optimizer.zero_grad()`` (set_to_none) detach ``p.grad`` from the flat buffer -- ``check()``
-    (called by StrongRunner.optimizer_step) raises if that happened instead of silently stepping on zeros."""
+    write gradients there themselves (no ``grad += new`` kernels).  ``model.zero_grad()`` / ``optimizer.zero_grad()``
+    (set_to_none) detach ``p.grad`` from the flat buffer: ``zero_grad()`` re-attaches such parameters, and ``check()``
+    (called at the entry of StrongRunner.forward_backward and by optimizer_step) raises when a parameter or a gradient was
+    re-homed elsewhere instead of silently writing into / stepping on memory nobody reads."""
 
     def __init__(self, model: torch.nn.Module):
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -55,15 +56,22 @@ class FlatParams:
         self.numel = n
 
     def zero_grad(self):
+        """Zero the flat gradient; parameters whose ``.grad`` was dropped (``model.zero_grad()`` /
+        ``optimizer.zero_grad(set_to_none=True)`` between steps) get their flat view back -- nothing is lost, the
+        gradients are being zeroed anyway."""
         self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None:
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
+                p._tag_grad_sink = p.grad
 
     def check(self):
         base, esz = self.grad.data_ptr(), self.grad.element_size()
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != base + off * esz or p.data.data_ptr() != self.flat.data_ptr() + off * esz:
-                raise RuntimeError("a parameter or its .grad no longer aliases the flat buffers (model.zero_grad() / "
-                                   "optimizer.zero_grad(set_to_none=True) / p.grad = None / .to() after FlatParams was built); "
-                                   "use FlatParams.zero_grad() only")
+                raise RuntimeError("a parameter or its .grad no longer aliases the flat buffers (p.grad = <other tensor> / "
+                                   "p.data = ... / .to() after FlatParams was built); rebuild the runner, or clear gradients "
+                                   "with FlatParams.zero_grad() / set_to_none only")
 
 
 class GradBuckets:
@@ -213,9 +221,11 @@ class StrongRunner:
 
     def forward_backward(self, batch: Dict):
         """zero_grad -> forward -> FrameBceLoss -> backward [with the bucketed gradient all-reduce inside it]."""
-        self.flat.zero_grad()
+        self.flat.zero_grad()                    # also re-attaches gradients dropped by model.zero_grad()
+        self.flat.check()                        # fail fast: the kernels are about to write into the flat views
         prev = (ops.DIRECT_GRADS, ops.GRAD_READY, ops.GRAD_FLUSH)
         ops.DIRECT_GRADS = True
+        ops.begin_direct_step()
         if self.buckets is not None:
             self.buckets.reset()
             ops.GRAD_READY = self.buckets.ready

@@ -1,8 +1,13 @@
 """``torch.library`` registration of the hot-path kernels (namespace ``tag``) -- the op list SURVEY.md section 8(b) asks a
 native replacement to export, with schemas, fake (meta) kernels for shape inference / tracing and autograd formulas, on top
 of the SAME C ABI (libtag_hip.so through ctypes, texttoaudiogrounding_amd.lib): PyTorch sees these as first-class operators
-(``torch.ops.tag.logmel`` ...), the reference-shaped modules keep calling the autograd nodes of ``ops.py``, which run the very
-same entry points.
+(``torch.ops.tag.logmel`` ...).  They are the FRONT door: the reference-shaped modules call them (models/match.py ->
+``frame_match``, models/align.py -> ``align_dot``, losses.py -> ``frame_bce``, models/text_encoder.py -> ``embed_mean``,
+models/panns.py ConvBlock.forward -> ``conv3x3_bn_relu_pool``, utils/eval_util.py -> ``segments``).  Every formula exists
+once: an operator's forward / backward body is a plain function of ``ops.py`` (``ops.match_forward`` / ``ops.match_backward``
+...), shared with the two composite autograd nodes that stay there because they own per-step state an operator cannot
+(``ops.Cnn8RnnFunction`` / ``ops.CrnnFunction``: the fused encoders, which never materialise the intermediate activations and
+write parameter gradients straight into the flat buffer; ``ops.EmbedMeanFunction``: the direct-gradient scatter).
 
     import texttoaudiogrounding_amd.torch_ops          # registers torch.ops.tag.*
 
@@ -93,6 +98,65 @@ def _conv_backward(ctx, dy):
 register_autograd("tag::conv3x3", _conv_backward, setup_context=_conv_setup)
 
 
+# ------------------------------------------------------------------------------------------------ A1 conv3x3 -> BN -> ReLU (-> pool)
+@custom_op("tag::conv3x3_bn_relu_pool", mutates_args=())
+def conv3x3_bn_relu_pool(x: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor,
+                         training: bool, momentum: float, eps: float, ph: int, pw: int,
+                         pool: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """One stage of ConvBlock.forward (models/panns.py:46-62), channels-last: relu(bn(conv3x3(x))) then pooling with kernel =
+    stride = (ph, pw) (1,1 = none); pool 0 'avg+max' | 2 'avg' | 3 'max'.  x (B,H,W,Cin) with Cin = 1 or a multiple of 32,
+    weight (Cout,Cin,3,3).  Functional (an operator with an autograd formula may not mutate its inputs): train mode uses the
+    batch statistics and RETURNS the updated running statistics, which the caller copies into the BatchNorm buffers.
+    -> (out (B,H/ph,W/pw,Cout), y = raw conv output, mean, invstd, scale, shift, new_running_mean, new_running_var)."""
+    rm, rv = running_mean.clone(), running_var.clone()
+    out, y, st = ops.conv_bn_relu_pool_forward(x, weight, gamma, beta, rm, rv, training, momentum, eps, ph, pw, pool)
+    mean = st.mean.clone() if not training else st.mean           # eval: st.mean IS rm (no aliased outputs)
+    return out, y, mean, st.invstd, st.scale, st.shift, rm, rv
+
+
+@conv3x3_bn_relu_pool.register_fake
+def _(x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, pool):
+    B, H, W, _ = x.shape
+    C = weight.shape[0]
+    v = lambda: x.new_empty(C)
+    return x.new_empty(B, H // ph, W // pw, C), x.new_empty(B, H, W, C), v(), v(), v(), v(), v(), v()
+
+
+@custom_op("tag::conv3x3_bn_relu_pool_backward", mutates_args=())
+def conv3x3_bn_relu_pool_backward(dout: Tensor, x: Tensor, weight: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, scale: Tensor,
+                                  shift: Tensor, gamma: Tensor, training: bool, ph: int, pw: int, pool: int,
+                                  need_dx: bool) -> List[Tensor]:
+    """-> [dx (empty (0,) tensor when not needed), dweight, dgamma, dbeta]."""
+    st = ops.BNStat()
+    st.mean, st.invstd, st.scale, st.shift, st.train = mean, invstd, scale, shift, bool(training)
+    dx, dw, dg, db = ops.conv_bn_relu_pool_backward(dout, x, weight, y, st, gamma, ph, pw, pool, need_dx)
+    return [dx if dx is not None else x.new_empty(0), dw, dg, db]
+
+
+@conv3x3_bn_relu_pool_backward.register_fake
+def _(dout, x, weight, y, mean, invstd, scale, shift, gamma, training, ph, pw, pool, need_dx):
+    return [torch.empty_like(x) if need_dx else x.new_empty(0), torch.empty_like(weight), torch.empty_like(gamma),
+            torch.empty_like(gamma)]
+
+
+def _cbrp_setup(ctx, inputs, output):
+    x, weight, gamma, _beta, _rm, _rv, training, _mom, _eps, ph, pw, pool = inputs
+    _out, y, mean, invstd, scale, shift, _rm, _rv = output
+    ctx.save_for_backward(x, weight, y, mean, invstd, scale, shift, gamma)
+    ctx.cfg = (training, ph, pw, pool)
+
+
+def _cbrp_backward(ctx, dout, *_unused):
+    x, weight, y, mean, invstd, scale, shift, gamma = ctx.saved_tensors
+    training, ph, pw, pool = ctx.cfg
+    dx, dw, dg, db = torch.ops.tag.conv3x3_bn_relu_pool_backward(dout.contiguous(), x, weight, y, mean, invstd, scale, shift, gamma,
+                                                                 training, ph, pw, pool, ctx.needs_input_grad[0])
+    return (dx if ctx.needs_input_grad[0] else None, dw, dg, db, None, None, None, None, None, None, None, None)
+
+
+register_autograd("tag::conv3x3_bn_relu_pool", _cbrp_backward, setup_context=_cbrp_setup)
+
+
 # ------------------------------------------------------------------------------------------------ A4 BiGRU
 @custom_op("tag::gru_bidir", mutates_args=())
 def gru_bidir(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor, w_ih_r: Tensor, w_hh_r: Tensor,
@@ -147,15 +211,7 @@ register_autograd("tag::gru_bidir", _gru_backward, setup_context=_gru_setup)
 @custom_op("tag::embed_mean", mutates_args=())
 def embed_mean(table: Tensor, text: Tensor, text_len: Tensor) -> Tuple[Tensor, Tensor]:
     """nn.Embedding gather + mean over the valid tokens: -> seq_emb (B,D), token_emb (B,L,D)."""
-    table = ops._chk(table, "embedding table")
-    if not text.is_cuda:
-        raise RuntimeError("tag::embed_mean: token ids must live on the device (no CPU fallback)")
-    B, L = text.shape
-    V, D = table.shape
-    seq, tok = table.new_empty(B, D), table.new_empty(B, L, D)
-    ops.call("tag_embed_check_ids", ops.ptr(text), B * L, V, ops.ptr(ops._embed_flag(table)))
-    ops.call("tag_embed_mean_forward", ops.ptr(text), ops.ptr(text_len), ops.ptr(table), ops.ptr(tok), ops.ptr(seq), B, L, D, V)
-    return seq, tok
+    return ops.embed_mean_forward(table, text, text_len, True)
 
 
 @embed_mean.register_fake
@@ -167,13 +223,7 @@ def _(table, text, text_len):
 @custom_op("tag::embed_mean_backward", mutates_args=())
 def embed_mean_backward(dseq: Optional[Tensor], dtok: Optional[Tensor], text: Tensor, text_len: Tensor, V: int, D: int) -> Tensor:
     """Deterministic scatter of the seq_emb / token_emb gradients into a zeroed (V,D) table gradient."""
-    B, L = text.shape
-    dtab = torch.zeros(V, D, device=text.device, dtype=torch.float32)
-    if dseq is not None:
-        ops.call("tag_embed_mean_backward", ops.ptr(dseq.contiguous()), ops.ptr(text), ops.ptr(text_len), ops.ptr(dtab), B, L, D, V)
-    if dtok is not None:
-        ops.call("tag_embed_tokens_backward", ops.ptr(dtok.contiguous()), ops.ptr(text), ops.ptr(dtab), B, L, D, V)
-    return dtab
+    return ops.embed_mean_backward_into(torch.zeros(V, D, device=text.device, dtype=torch.float32), dseq, dtok, text, text_len)
 
 
 @embed_mean_backward.register_fake
@@ -199,11 +249,7 @@ register_autograd("tag::embed_mean", _embed_backward, setup_context=_embed_setup
 @custom_op("tag::frame_match", mutates_args=())
 def frame_match(audio: Tensor, text: Tensor, kind: int, l2norm: bool, scale: bool) -> Tensor:
     """kind 0 = match.DotProduct (sigmoid(a.t [/sqrt D]).clamp(1e-7,1)), 1 = match.ExpNegL2 (exp(-||a - t||)): (B,T,D),(B,D) -> (B,T)."""
-    audio, text = ops._chk(audio, "audio_emb"), ops._chk(text, "text_emb")
-    B, T, D = audio.shape
-    sim = audio.new_empty(B, T)
-    ops.call("tag_match_forward", ops.ptr(audio), ops.ptr(text), ops.ptr(sim), kind, int(l2norm), int(scale), B, T, D)
-    return sim
+    return ops.match_forward(audio, text, kind, l2norm, scale)
 
 
 @frame_match.register_fake
@@ -214,11 +260,7 @@ def _(audio, text, kind, l2norm, scale):
 @custom_op("tag::frame_match_backward", mutates_args=())
 def frame_match_backward(audio: Tensor, text: Tensor, sim: Tensor, dsim: Tensor, kind: int, l2norm: bool,
                          scale: bool) -> Tuple[Tensor, Tensor]:
-    B, T, D = audio.shape
-    da, dt = torch.empty_like(audio), torch.empty_like(text)
-    ops.call("tag_match_backward", ops.ptr(audio), ops.ptr(text), ops.ptr(sim), ops.ptr(dsim.contiguous()), ops.ptr(da), ops.ptr(dt),
-             kind, int(l2norm), int(scale), B, T, D)
-    return da, dt
+    return ops.match_backward(audio, text, sim, dsim, kind, l2norm, scale)
 
 
 @frame_match_backward.register_fake
@@ -254,16 +296,25 @@ def _(audio, text, l2norm, scaled):
     return audio.new_empty(B, B, T, text.shape[1])
 
 
+@custom_op("tag::align_dot_backward", mutates_args=())
+def align_dot_backward(audio: Tensor, text: Tensor, out: Tensor, dout: Tensor, l2norm: bool, scaled: bool) -> Tuple[Tensor, Tensor]:
+    return ops.align_dot_backward(audio, text, out, dout, l2norm, scaled)
+
+
+@align_dot_backward.register_fake
+def _(audio, text, out, dout, l2norm, scaled):
+    return torch.empty_like(audio), torch.empty_like(text)
+
+
 def _align_setup(ctx, inputs, output):
-    ctx.inputs = inputs
+    audio, text, l2norm, scaled = inputs
+    ctx.save_for_backward(audio, text, output)
+    ctx.cfg = (l2norm, scaled)
 
 
 def _align_backward(ctx, dout):
-    audio, text, l2norm, scaled = ctx.inputs
-    with torch.enable_grad():                       # the autograd node of ops.py already owns the exact formula
-        a, t = audio.detach().requires_grad_(True), text.detach().requires_grad_(True)
-        out = ops.AlignDotFunction.apply(a, t, l2norm, scaled)
-        da, dt = torch.autograd.grad(out, (a, t), dout.contiguous())
+    audio, text, out = ctx.saved_tensors
+    da, dt = torch.ops.tag.align_dot_backward(audio, text, out, dout, *ctx.cfg)
     return da, dt, None, None
 
 
@@ -274,11 +325,7 @@ register_autograd("tag::align_dot", _align_backward, setup_context=_align_setup)
 @custom_op("tag::frame_bce", mutates_args=())
 def frame_bce(frame_sim: Tensor, label: Tensor, length: Tensor, Tt: int) -> Tensor:
     """FrameBceLoss over the first Tt frames, masked by clamp(length, 1, Tt): -> 0-dim loss."""
-    frame_sim, label = ops._chk(frame_sim, "frame_sim"), ops._chk(label, "label")
-    loss = frame_sim.new_empty(1)
-    ops.call("tag_frame_bce_forward", ops.ptr(frame_sim), frame_sim.shape[1], ops.ptr(label), label.shape[1], ops.ptr(length),
-             frame_sim.shape[0], Tt, ops.ptr(loss))
-    return loss.view(())
+    return ops.frame_bce_forward(frame_sim, label, length, Tt)
 
 
 @frame_bce.register_fake
@@ -288,10 +335,7 @@ def _(frame_sim, label, length, Tt):
 
 @custom_op("tag::frame_bce_backward", mutates_args=())
 def frame_bce_backward(frame_sim: Tensor, label: Tensor, length: Tensor, Tt: int, dloss: Tensor) -> Tensor:
-    ds = torch.empty_like(frame_sim)
-    ops.call("tag_frame_bce_backward", ops.ptr(frame_sim), frame_sim.shape[1], ops.ptr(label), label.shape[1], ops.ptr(length),
-             frame_sim.shape[0], Tt, ops.ptr(dloss.reshape(1).contiguous()), ops.ptr(ds))
-    return ds
+    return ops.frame_bce_backward(frame_sim, label, length, Tt, dloss)
 
 
 @frame_bce_backward.register_fake
@@ -329,6 +373,6 @@ def _(frame_sim, thresholds, window_size, n_connect):
             torch.empty(B, NT, device=frame_sim.device, dtype=torch.int32))
 
 
-OP_NAMES = ["logmel", "conv3x3", "conv3x3_dgrad", "conv3x3_wgrad", "gru_bidir", "gru_bidir_backward", "embed_mean",
-            "embed_mean_backward", "frame_match", "frame_match_backward", "align_dot", "frame_bce", "frame_bce_backward",
-            "segments"]
+OP_NAMES = ["logmel", "conv3x3", "conv3x3_dgrad", "conv3x3_wgrad", "conv3x3_bn_relu_pool", "conv3x3_bn_relu_pool_backward",
+            "gru_bidir", "gru_bidir_backward", "embed_mean", "embed_mean_backward", "frame_match", "frame_match_backward",
+            "align_dot", "align_dot_backward", "frame_bce", "frame_bce_backward", "segments"]

@@ -859,6 +859,7 @@ static int bnact_pool_forward_impl(const TS* y, const float* scale, const float*
     DISPATCH_POOL(2, 4, POOL_FWD_BODY)
     DISPATCH_POOL(1, 4, POOL_FWD_BODY)
     DISPATCH_POOL(1, 1, POOL_FWD_BODY)
+    DISPATCH_POOL(2, 1, POOL_FWD_BODY)
 #undef POOL_FWD_BODY
     TAG_CHECK_ARG(launched);
     TAG_LAUNCH_CHECK();
@@ -908,6 +909,7 @@ static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const floa
     DISPATCH_POOL(2, 2, POOL_BWD_BODY)
     DISPATCH_POOL(1, 2, POOL_BWD_BODY)
     DISPATCH_POOL(1, 1, POOL_BWD_BODY)
+    DISPATCH_POOL(2, 1, POOL_BWD_BODY)
 #undef POOL_BWD_BODY
 #undef POOL_BWD_NC
     TAG_CHECK_ARG(launched);

@@ -502,13 +502,18 @@ def dropout_mask(seed, shape, p, device):
 
 def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
          accumulate=False):
-    """Row-major C(M,N) = act(op(A) op(B) + bias) [+ C].  A/B may be strided views (lda/ldb)."""
+    """Row-major C(M,N) = act(op(A) op(B) + bias) [+ C].  A/B may be strided views (lda/ldb).
+
+    Split-K (a workspace) is offered to the library only for transA products -- the weight-gradient shape, whose reduction
+    runs over the batch rows.  A product with A stored (M,K) has the batch in M: without K slices every output row is one
+    fixed-order sum over k whatever M is, so forward passes are BATCH-INVARIANT (a clip scores bit-identically alone, in a
+    64-clip pass or in a ragged remainder; tools/diag_batch_invariance.py, test_grounding_model_30s_full_pass_b67)."""
     lda = lda if lda is not None else (M if transA else K)
     ldb = ldb if ldb is not None else (K if transB else N)
     if out is None:
         out = _empty(M, N, like=A)
     ldc = ldc if ldc is not None else N
-    nws = query("tag_gemm_ws_bytes", M, N, K)
+    nws = query("tag_gemm_ws_bytes", M, N, K) if transA else 0
     ws = _ws(nws, A) if nws else None
     call("tag_gemm_bf16" if gemm_bf16() else "tag_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(out), ldc, M,
          N, K, ptr(bias), act, int(accumulate), ptr(ws))
@@ -850,6 +855,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
 # never materialises relu(bn(y)); this stage does (its output IS that tensor, pooled), so that it composes like an nn.Module.
 # ------------------------------------------------------------------------------------------------
 POOL_TYPES = {"avg+max": 0, "avg": 2, "max": 3}
+POOL_SIZES = {(1, 1), (1, 2), (2, 1), (2, 2)}      # (time, mel) windows instantiated for forward AND backward in bn_pool.hip
 
 
 def conv_bn_relu_pool_forward(x, w, gamma, beta, running_mean, running_var, training, momentum, eps, ph, pw, pool):
@@ -858,6 +864,8 @@ def conv_bn_relu_pool_forward(x, w, gamma, beta, running_mean, running_var, trai
     x = _chk(x, "x")
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
+    if (ph, pw) not in POOL_SIZES:
+        raise RuntimeError(f"conv3x3_bn_relu_pool: pool_size {(ph, pw)} has no kernel instance (built: {sorted(POOL_SIZES)})")
     if Cin == 1:
         y, part = conv3x3_c1_stats(x.view(B, H, W), w, want_stats=training)
     elif Cin % 32 == 0:

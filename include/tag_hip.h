@@ -49,6 +49,16 @@ int tag_logmel_forward(const float* wave, int B, int S, int n_fft, int win_lengt
                        float* power_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input side of F1: waveform packs hold float16 samples (utils/data/pack_waveform.py:46-52); the reference's loaders widen
+ * them to float32 on the host (datasets/single_phrase_dataset.py:44-45) and zero-pad the batch to its longest clip
+ * (utils/train_util.py:211-216 via datasets/collate_function.py:24-28).  Device form: packed_f16 = the B ragged clips
+ * back to back (what crosses PCIe), offsets (B+1) int64 sample offsets, out (B,S) float32 zero-padded (clips longer than S
+ * are cut), len_out (B) int64 = clip lengths (nullable).  Exact: every float16 is a float32.
+ * ------------------------------------------------------------------------------------------- */
+int tag_waveform_f16_to_f32_padded(const void* packed_f16, const long* offsets, int B, int S, float* out,
+                                   long* len_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * F3 / A1: BatchNorm2d statistics over a channels-last tensor x (rows, C)  (nn.BatchNorm2d, train)
  * models/audio_encoder.py:133,188-190 (bn0 over the mel axis) and models/panns.py:35-36,49-50.
  * Produces batch mean / invstd (biased var, eps) and the fused affine  scale = gamma*invstd,

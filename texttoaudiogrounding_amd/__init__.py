@@ -32,6 +32,12 @@ def install_aliases(force: bool = False):
         "utils": "texttoaudiogrounding_amd.utils",
         "utils.eval_util": "texttoaudiogrounding_amd.utils.eval_util",
         "utils.train_util": "texttoaudiogrounding_amd.utils.train_util",
+        "utils.build_vocab": "texttoaudiogrounding_amd.utils.build_vocab",
+        # ``datasets`` itself stays whatever it is (the reference's directory has no __init__ and is shadowed by the
+        # installed HF package of that name); only the sub-module names the YAML configs spell are registered
+        "datasets.single_phrase_dataset": "texttoaudiogrounding_amd.datasets.single_phrase_dataset",
+        "datasets.collate_function": "texttoaudiogrounding_amd.datasets.collate_function",
+        "datasets.text_tokenizer": "texttoaudiogrounding_amd.datasets.text_tokenizer",
     }
     for alias, target in names.items():
         if alias in sys.modules and not force:

@@ -263,6 +263,36 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     }
 }
 
+// Waveform packs store float16 samples (utils/data/pack_waveform.py:46-52); the loaders widen them to float32 and zero-pad the
+// batch to its longest clip (datasets/single_phrase_dataset.py:44-45, utils/train_util.py:211-216).  Here the RAGGED float16
+// samples are what crosses PCIe (half the bytes, no padding) and this kernel does both steps on the device: out[b][s] =
+// float(packed[off[b] + s]) for s < off[b+1] - off[b], else 0.  8 samples (16 B in, 32 B out) per thread; exact (every
+// float16 is a float32).
+__global__ __launch_bounds__(256) void waveform_f16_unpack_kernel(const _Float16* __restrict__ packed,
+                                                                  const long* __restrict__ off, int B, int S,
+                                                                  float* __restrict__ out, long* __restrict__ len_out) {
+    const int b = blockIdx.y;
+    const long o0 = off[b], n = off[b + 1] - o0;
+    if (len_out && blockIdx.x == 0 && threadIdx.x == 0) len_out[b] = n;
+    const _Float16* src = packed + o0;
+    float* dst = out + (size_t)b * S;
+    // head: scalar samples until the SOURCE is 16-byte aligned (ragged offsets), then 8-sample vector items
+    const int head = (int)(((16 - (reinterpret_cast<uintptr_t>(src) & 15)) & 15) >> 1);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; ; i += (long)gridDim.x * 256) {
+        const long s0 = i == 0 ? 0 : head + (i - 1) * 8;
+        const int cnt = i == 0 ? head : 8;
+        if (s0 >= S) break;
+        if (i > 0 && s0 + 8 <= n && s0 + 8 <= S) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const h8 v = *reinterpret_cast<const h8*>(src + s0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[s0 + j] = (float)v[j];
+        } else {
+            for (int j = 0; j < cnt && s0 + j < S; ++j) dst[s0 + j] = s0 + j < n ? (float)src[s0 + j] : 0.0f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tag_logmel_forward(const float* wave, int B, int S, int n_fft, int win_length, int hop,
@@ -285,6 +315,18 @@ extern "C" int tag_logmel_forward(const float* wave, int B, int S, int n_fft, in
     else
         hipLaunchKernelGGL(logmel_kernel<2048>, dim3(grid), dim3(256), 0, as_stream(stream), wave, B, S, F,
                            win_length, hop, window, fb, n_mels, out_db, power_out);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_waveform_f16_to_f32_padded(const void* packed_f16, const long* offsets, int B, int S, float* out,
+                                              long* len_out, void* stream) {
+    TAG_CHECK_ARG(packed_f16 && offsets && out && B > 0 && S > 0);
+    TAG_CHECK_ARG(reinterpret_cast<uintptr_t>(packed_f16) % 2 == 0);
+    int gx = cdiv((long)S / 8 + 2, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(waveform_f16_unpack_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream),
+                       static_cast<const _Float16*>(packed_f16), offsets, B, S, out, len_out);
     TAG_LAUNCH_CHECK();
     return 0;
 }

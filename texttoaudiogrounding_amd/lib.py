@@ -53,6 +53,7 @@ _SIGS = {
     "tag_conv3x3_c1_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_c1_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_c1_backward": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "tag_waveform_f16_to_f32_padded": (c_int, [P, P, c_int, c_int, P, P, P]),
     "tag_bnact_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_uint64, P]),
     "tag_bn_backward_ws_bytes": (c_size_t, [c_long, c_int]),

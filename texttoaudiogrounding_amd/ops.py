@@ -156,6 +156,29 @@ def _flush():
 # thin functional wrappers (no autograd) -- also what the per-kernel parity tests call
 # ------------------------------------------------------------------------------------------------
 
+def waveform_f16_to_f32_padded(clips, device, length=None):
+    """Ragged float16 clips (a list of 1-D numpy / torch float16 arrays, as WaveformStore.fetch_f16 returns them) ->
+    (waveform (B,S) float32 zero-padded on ``device``, waveform_len (B,) int64 on ``device``), S = ``length`` or the longest
+    clip.  The float16 samples are copied to the device back to back (half the bytes of the padded float32 batch the
+    reference's collate function builds on the host) and widened + padded there (tag_waveform_f16_to_f32_padded)."""
+    import numpy as np
+    arrs = [c.numpy() if isinstance(c, torch.Tensor) else np.asarray(c) for c in clips]
+    if any(a.dtype != np.float16 or a.ndim != 1 for a in arrs):
+        raise RuntimeError("waveform_f16_to_f32_padded: clips must be 1-D float16 arrays (the pack's storage type)")
+    lens = [a.shape[0] for a in arrs]
+    S = int(length) if length is not None else max(lens)
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.long)
+    packed = torch.from_numpy(np.concatenate(arrs) if len(arrs) > 1 else arrs[0].copy())
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("waveform_f16_to_f32_padded: the target must be the MI355X (cuda) device; no CPU fallback")
+    packed_d, off_d = packed.to(dev, non_blocking=True), off.to(dev, non_blocking=True)
+    out = torch.empty(len(arrs), S, device=dev, dtype=F32)
+    lens_d = torch.empty(len(arrs), device=dev, dtype=torch.long)
+    call("tag_waveform_f16_to_f32_padded", ptr(packed_d), ptr(off_d), len(arrs), S, ptr(out), ptr(lens_d))
+    return out, lens_d
+
+
 def logmel(wave, n_fft, win_length, hop, window, fb, want_power=False):
     wave = _chk(wave, "waveform")
     B, S = wave.shape

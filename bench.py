@@ -11,6 +11,7 @@ batch 64 per GPU, 10 s @ 32 kHz synthetic clips, dropout on, train-mode BatchNor
 fixed).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -137,6 +138,9 @@ def main():
     ap.add_argument("--crnn", action="store_true",
                     help="time the variant the strong eg_config literally instantiates instead (cdur_w2vmean.yaml: CrnnEncoder "
                          "(256) + EmbeddingAgg(256) + match.ExpNegL2); NOT the contract's workload")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="N > 1: time ONLY the gradient buckets' all-reduces (fp32 and bf16 payload), nothing else, and print "
+                         "that as the JSON line (diagnosis of a scaling run; not the contract's metric)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE configs[2] as a mode: bf16 conv arithmetic (fp32 accumulate) + bf16 storage of the conv "
@@ -191,6 +195,48 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
+    def comm_only(iters=10):
+        """The buckets' collectives alone, back to back on the communication stream: per payload type the time of one
+        step's worth of all-reduces, each bucket's own duration and the bus bandwidth 2(n-1)/n x bytes / time."""
+        bk = runner.buckets
+        res = {}
+        for name, dt_ in (("fp32", None), ("bf16", torch.bfloat16)):
+            bufs = [runner.flat.grad[s0:e].clone() if dt_ is None else runner.flat.grad[s0:e].to(dt_) for (s0, e, _, _) in bk.bounds]
+            evs = []
+            for it in range(iters + 2):
+                sync()
+                with torch.cuda.stream(bk.comm_stream):
+                    row = [torch.cuda.Event(enable_timing=True) for _ in range(len(bufs) + 1)]
+                    row[0].record(bk.comm_stream)
+                    for i, b_ in enumerate(bufs):
+                        b_.zero_()                                   # keep the payload finite over the repetitions
+                        w = dist.all_reduce(b_, async_op=True)
+                        w.wait()
+                        row[i + 1].record(bk.comm_stream)
+                if it >= 2:
+                    evs.append(row)
+            sync()
+            per = [sum(r[i].elapsed_time(r[i + 1]) for r in evs) / len(evs) for i in range(len(bufs))]
+            nbytes = sum(b_.numel() * b_.element_size() for b_ in bufs)
+            tot = sum(per)
+            t = torch.tensor([tot], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tot = t.item()
+            res[name] = {"ms_per_step": round(tot, 4), "bucket_ms": [round(v, 4) for v in per], "payload_MB": round(nbytes / 2 ** 20, 2),
+                         "bus_GB_per_s": round(2 * (world - 1) / world * nbytes / (tot * 1e-3) / 1e9, 2) if tot > 0 else None}
+        return res
+
+    if args.comm_only:
+        if runner.buckets is None:
+            raise SystemExit("--comm-only needs --gpus N > 1 (one rank has no gradient exchange)")
+        res = comm_only()
+        if rank == 0:
+            print(json.dumps({"metric": "gradient all-reduce alone (diagnosis, not the contract's metric)", "n_gpus": world,
+                              "backend": dist.get_backend(),
+                              "buckets_MB": [round((e - s0) * 4 / 2 ** 20, 2) for (s0, e, _, _) in runner.buckets.bounds],
+                              "comm_only": res}))
+        dist.destroy_process_group()
+        return
     log(f"model on {device}, batch {args.batch}/GPU; warm-up {args.warmup} step(s)")
     for i in range(args.warmup):
         tw = time.perf_counter()
@@ -199,6 +245,8 @@ def main():
         log(f"warm-up step {i}: {time.perf_counter() - tw:.3f} s")
     sync()
     ops.PROFILE = {}
+    if runner.buckets is not None:
+        runner.buckets.record = True          # per-bucket events on the communication stream + the exposed wait
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = runner.train_step(dict(batch))
@@ -206,6 +254,10 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt:.3f} s")
     prof, ops.PROFILE = ops.PROFILE, None
+    comm_timing = None
+    if runner.buckets is not None:
+        runner.buckets.record = False
+        comm_timing = runner.buckets.timing_summary()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,21 +327,32 @@ def main():
         # figure is read from the committed profile of the SAME command (tools/collect_profiles.sh: two separate --pmc passes,
         # FETCH_SIZE x2 + WRITE_SIZE) and labelled with where and when it was collected -- it is offline data.
         traffic, traffic_src = None, None
-        tname = f"r02_pmc_hbm_traffic_{'bf16' if args.dtype == 'bf16' else 'fp32'}.json"
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath) and args.conv_math in ("fp32", "bf16"):
-            tj = json.load(open(tpath))
+        from texttoaudiogrounding_amd.lib import csrc_sha256
+        mode = "bf16" if args.dtype == "bf16" else "fp32"
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{mode}.json")), reverse=True)
+        if not cands or args.conv_math not in ("fp32", "bf16"):
+            traffic_src = {"reason": "no PMC traffic profile for this arithmetic under profiles/"}
+        else:
+            tj = json.load(open(cands[0]))
             meta = tj.pop("_meta", {})
-            rows = [v for k, v in tj.items() if k.startswith(dom)]
-            n = sum(v["launches_in_run"] for v in rows)
-            if n:
-                traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
-                                    for v in rows) / n, 3)
+            tname = os.path.basename(cands[0])
+            if meta.get("csrc_sha256") != csrc_sha256():
+                # a profile of OTHER kernel sources says nothing about this build: no number rather than a stale one
                 traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
-                               "measured_in_this_run": False,
-                               "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
-                               "algorithmic_lower_bound_GB_per_step": round((0.082 if args.dtype == "bf16" else 0.164)
-                                                                            * args.batch, 2)}
+                               "reason": "profile was collected on different kernel sources (csrc sha256 "
+                                         f"{str(meta.get('csrc_sha256'))[:12]} != built {csrc_sha256()[:12]}); re-run "
+                                         "tools/collect_profiles.sh"}
+            else:
+                rows = [v for k, v in tj.items() if k.startswith(dom)]
+                n = sum(v["launches_in_run"] for v in rows)
+                if n:
+                    traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
+                                        for v in rows) / n, 3)
+                    traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
+                                   "csrc_sha256": meta.get("csrc_sha256"), "measured_in_this_run": False,
+                                   "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
+                                   "algorithmic_lower_bound_GB_per_step": round((0.082 if args.dtype == "bf16" else 0.164)
+                                                                                * args.batch, 2)}
         # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
         nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(args.conv_math, 6.0)
         peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / nprod, 1)
@@ -303,6 +366,7 @@ def main():
                 "isolated_avg_launch_ms": round(fam_iso[dom]["ms"] / fam_iso[dom]["launches"], 4),
                 "families_isolated": {k: {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
                                           "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in fam_iso.items()}}
+    comm_only_res = comm_only() if world > 1 else None        # every rank takes part; a few ms
     if rank == 0:
         out = {"metric": "clips/sec (10 s@32 kHz, 1-phrase) fwd+bwd", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,7 +391,14 @@ def main():
         if world > 1:
             out["comm"] = {"collective": "all-reduce(sum) of the flat fp32 gradient in buckets, launched from inside backward",
                            "buckets_MB": [round((e - s0) * 4 / 2 ** 20, 2) for (s0, e, _, _) in runner.buckets.bounds],
-                           "overlap": runner.overlap_comm}
+                           "overlap": runner.overlap_comm,
+                           "payload": "bf16" if args.dtype == "bf16" else "fp32",
+                           # rank 0's events over the timed region: each bucket's all-reduce start->end on the communication
+                           # stream (includes waiting for slower ranks to arrive) and the time the compute stream spent blocked
+                           # on the communication stream at the end of backward (= communication NOT hidden under compute)
+                           "bucket_ms_in_step": comm_timing["bucket_ms"] if comm_timing else None,
+                           "exposed_ms_per_step": comm_timing["exposed_ms_per_step"] if comm_timing else None,
+                           "comm_only": comm_only_res}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             out["cpu_baseline"] = cpu_baseline()

@@ -121,3 +121,25 @@ def test_biencoder_with_cross_attention_train_step(dev):
         e = relerr(p.grad, st64[name].grad)
         print(f"  {name:45s} {e:.2e}")
         assert e < 1e-4, (name, e)
+
+
+def test_cross_attention_empty_phrase_is_nan_and_long_phrase_is_rejected(dev):
+    """a phrase with no valid token is a softmax over a fully masked row -- nn.MultiheadAttention (the reference,
+    models/match.py:75-79) returns NaN for that clip, and so must the HIP head (loud, not a silent 0); the other clips are
+    untouched.  A phrase longer than the kernel's compile-time token limit (32) raises instead of truncating."""
+    from texttoaudiogrounding_amd.models import match
+    torch.manual_seed(5)
+    E, H, B, T, L = 128, 4, 3, 7, 4
+    m = match.CrossAttention(E, H, 0.0).to(dev).eval()
+    audio, token = torch.randn(B, T, E, device=dev), torch.randn(B, L, E, device=dev)
+    sim = m({"audio_emb": audio, "text_emb": {"token_emb": token}, "text_len": torch.tensor([3, 0, 4])})
+    ref = m({"audio_emb": audio, "text_emb": {"token_emb": token}, "text_len": torch.tensor([3, 2, 4])})
+    assert torch.isnan(sim[1]).all() and torch.equal(sim[[0, 2]], ref[[0, 2]]) and torch.isfinite(ref).all()
+    # the same through torch's own module on the CPU: fully masked row -> NaN
+    cpu = torch.nn.MultiheadAttention(E, H, 0.0, batch_first=True).eval()
+    mask = torch.arange(L)[None, :] >= torch.tensor([3, 0, 4])[:, None]
+    with torch.no_grad():
+        out, _ = cpu(audio.cpu(), token.cpu(), token.cpu(), key_padding_mask=mask)
+    assert torch.isnan(out[1]).all() and torch.isfinite(out[0]).all()
+    with pytest.raises(RuntimeError):
+        m({"audio_emb": audio, "text_emb": {"token_emb": torch.randn(B, 33, E, device=dev)}, "text_len": torch.tensor([3, 2, 33])})

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void mha_cross_fwd_kernel(const float* __restr
             for (int i = 0; i < NE; ++i) a[i] = expf(s[i] * scale - mx[i]) / den[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < NE; ++i) a[i] = 0.0f;             // exp(-inf) of the key_padding_mask
+            // exp(-inf) of the key_padding_mask; a phrase with NO valid token (text_len 0) is a softmax over an all-masked
+            // row: nn.MultiheadAttention yields NaN there (models/match.py:75-79) and so does this kernel -- loud, not 0
+            for (int i = 0; i < NE; ++i) a[i] = kl > 0 ? 0.0f : __int_as_float(0x7fc00000);
         }
         float vv[NE];
         load_vec<NE>(vv, v + ((long)b * L + t) * E, E, lane);

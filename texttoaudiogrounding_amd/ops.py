@@ -586,34 +586,47 @@ def align_dot(audio, text, l2norm=False, scaled=False):
 # bidirectional GRU (row A4): input projection GEMM + persistent recurrence, and its backward
 # ------------------------------------------------------------------------------------------------
 
-#: persistent scratch of the GRU kernels per (device, B, T, H, pass): recurrent-weight transpose, exchange granules and a
+#: persistent scratch of the GRU kernels per (device, B, H, pass): recurrent-weight transpose, exchange granules and a
 #: STICKY error word (last 256 bytes; zeroed once here, raised by a persistent kernel whose bounded spin ran out and never
 #: cleared by the library) -> check_async_errors()
 _gru_scratch = {}
 
 
+_GRU_SCRATCH_MAX = 8        # (B, H, pass) combinations kept per process; ragged epochs vary T, which the scratch ignores
+
+
 def _gru_ws(B, T, Hh, like, which):
-    key = (like.device.type, like.device.index, B, T, Hh, which)
-    ws = _gru_scratch.get(key)
+    """Scratch of one persistent GRU launch.  tag_gru_ws_bytes does not depend on T, so the cache key does not either (a
+    ragged epoch pads every batch to its own longest clip); the least recently used entry is dropped beyond
+    _GRU_SCRATCH_MAX.  Kernels run in stream order, so equal-shape GRUs may share one scratch."""
+    key = (like.device.type, like.device.index, B, Hh, which)
+    ws = _gru_scratch.pop(key, None)
     if ws is None:
         nbytes = query("tag_gru_ws_bytes", B, T, Hh)
         ws = torch.zeros((nbytes + 7) // 8, device=like.device, dtype=torch.float64)
         ws._tag_err_index = (nbytes - 256) // 4          # int32 index of the sticky error word
-        _gru_scratch[key] = ws
+        while len(_gru_scratch) >= _GRU_SCRATCH_MAX:
+            old_key = next(iter(_gru_scratch))
+            _check_gru_word(old_key, _gru_scratch.pop(old_key))      # an evicted scratch must not take a raised flag with it
+    _gru_scratch[key] = ws                                # (re-)inserted last = most recently used
     return ws
+
+
+def _check_gru_word(key, ws):
+    word = ws.view(torch.int32)[ws._tag_err_index: ws._tag_err_index + 1]
+    err = word.cpu()
+    if query("tag_gru_timed_out", err.data_ptr()):
+        word.zero_()
+        raise RuntimeError(f"persistent GRU kernel timed out waiting for a neighbouring workgroup (B,H,pass = {key[2:]}): "
+                           "its workgroups were not co-resident; outputs of that step are NaN and the optimiser skipped it")
 
 
 def check_async_errors():
     """Host-side check of the sticky device error words (synchronises): raises RuntimeError when a persistent GRU kernel
     timed out waiting for its neighbours (its outputs were poisoned with NaN and the Adam kernel skipped the step) or an
     embedding lookup saw a token id outside the table.  Called by StrongRunner whenever it hands a loss VALUE to the host."""
-    for key, ws in _gru_scratch.items():
-        word = ws.view(torch.int32)[ws._tag_err_index: ws._tag_err_index + 1]
-        err = word.cpu()
-        if query("tag_gru_timed_out", err.data_ptr()):
-            word.zero_()
-            raise RuntimeError(f"persistent GRU kernel timed out waiting for a neighbouring workgroup (B,T,H,pass = {key[2:]}): "
-                               "its workgroups were not co-resident; outputs of that step are NaN and the optimiser skipped it")
+    for key, ws in list(_gru_scratch.items()):
+        _check_gru_word(key, ws)
     for dev, flag in _embed_err.items():
         if int(flag.cpu().item()) != 0:
             flag.zero_()

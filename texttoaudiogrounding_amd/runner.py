@@ -111,6 +111,9 @@ class GradBuckets:
             for i in range(i0, i1):
                 self.bucket_of[id(flat.params[i])] = b
         self.comm_stream = torch.cuda.Stream(device=flat.grad.device) if self.cuda else None
+        self.stream_wait = self.cuda and dist.get_backend(group) == "nccl"
+        self.record = False                    # bench.py: per-bucket events on the communication stream
+        self.events, self.exposed = [], []
         self.reset()
 
     def reset(self):
@@ -136,11 +139,28 @@ class GradBuckets:
             self.comm_stream.wait_stream(main)
             for side in ops.side_streams(buf.device):
                 self.comm_stream.wait_stream(side)
+            ev = None
             with torch.cuda.stream(self.comm_stream):
+                if self.record:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(self.comm_stream)
                 if self.comm_dtype is not None:
                     wire = buf.to(self.comm_dtype)
-                    wire.record_stream(main)             # widened back on the compute stream in finish()
                 w = dist.all_reduce(wire, group=self.group, async_op=True)
+                if self.stream_wait:
+                    # RCCL: Work.wait() orders the CURRENT stream (= the communication stream) after the collective without
+                    # blocking the host, so the widening copy of a bf16 payload and the end-of-bucket event also live on
+                    # the communication stream, off the compute stream's critical path
+                    w.wait()
+                    if wire is not buf:
+                        buf.copy_(wire)
+                        wire = buf
+                    w = None
+                    if ev is not None:
+                        ev[1].record(self.comm_stream)
+                        self.events.append((b, ev[0], ev[1]))
+                elif wire is not buf:
+                    wire.record_stream(main)             # widened back on the compute stream in finish()
         else:
             if self.comm_dtype is not None:
                 wire = buf.to(self.comm_dtype)
@@ -155,23 +175,43 @@ class GradBuckets:
 
     def finish(self):
         """Everything not yet exchanged goes now (parameters no node announced, e.g. unused ones whose gradient is the
-        zero fill); then the compute stream waits for every collective."""
+        zero fill); then the compute stream waits for every collective.  With ``record`` on, the wait is bracketed by two
+        events on the compute stream: their distance is the EXPOSED communication time of the step."""
         for b in range(len(self.bounds)):
             if not self.launched[b]:
                 self._launch(b)
         for w, _, _ in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
         if self.cuda:
-            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.comm_stream)
+            main = torch.cuda.current_stream(self.flat.grad.device)
+            if self.record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            main.wait_stream(self.comm_stream)
+            if self.record:
+                e1.record(main)
+                self.exposed.append((e0, e1))
         for _, buf, wire in self.works:
             if wire is not buf:
                 buf.copy_(wire)
         self.works = []
 
+    def timing_summary(self):
+        """After a synchronize: {"bucket_ms": [mean duration of each bucket's all-reduce on the communication stream],
+        "exposed_ms_per_step": mean time the compute stream spent blocked on the communication stream}; clears the log."""
+        per = [[] for _ in self.bounds]
+        for b, e0, e1 in self.events:
+            per[b].append(e0.elapsed_time(e1))
+        exp = [e0.elapsed_time(e1) for e0, e1 in self.exposed]
+        self.events, self.exposed = [], []
+        return {"bucket_ms": [round(sum(v) / len(v), 4) if v else None for v in per],
+                "exposed_ms_per_step": round(sum(exp) / len(exp), 4) if exp else None}
+
 
 class StrongRunner:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, device="cuda",
-                 bucket_bytes: int = 8 << 20, overlap_comm: bool = True, grad_comm_dtype=None):
+                 bucket_bytes: int = 8 << 20, overlap_comm: bool = True, grad_comm_dtype=None, force_comm: bool = False):
         self.device = torch.device(device)
         self.model = model.to(self.device)
         self.loss_fn = FrameBceLoss()
@@ -185,7 +225,8 @@ class StrongRunner:
         self.rank = dist.get_rank() if on else 0
         self.overlap_comm = overlap_comm
         self.buckets: Optional[GradBuckets] = None
-        if self.world > 1:
+        if self.world > 1 or (force_comm and on):
+            # (force_comm: a 1-rank group still runs the whole bucket / stream machinery -- tests, bench --comm-only)
             # replicas must START identical whatever each rank's seed / checkpoint was: parameters and every buffer
             # (BatchNorm running statistics, num_batches_tracked) come from rank 0; Adam moments start at zero everywhere
             dist.broadcast(self.flat.flat, 0)

@@ -43,7 +43,10 @@ for k in sorted(f, key=lambda k: -f[k][0]):
         print(f"{k:48s} n={n:3d} fetch {fb / 1e9:7.3f} GB write {wb / 1e9:7.3f} GB /launch, {(fb + wb) / max(dur / n, 1):7.2f} GB/ms")
 print(f"per step: fetch {tf / steps / 1e9:.2f} GB, write {tw / steps / 1e9:.2f} GB")
 import datetime
-res["_meta"] = {"collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "steps_in_run": steps,
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from texttoaudiogrounding_amd.lib import csrc_sha256          # the profile is only valid for THESE kernel sources
+res["_meta"] = {"csrc_sha256": csrc_sha256(), "collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "steps_in_run": steps,
                 "fetch_GB_per_step": round(tf / steps / 1e9, 3), "write_GB_per_step": round(tw / steps / 1e9, 3),
                 "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, HBM section); "
                        "counters are KiB; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); per launch = sum / launches",

@@ -29,6 +29,7 @@ def relerr(a, b):
 @pytest.fixture(scope="module")
 def ops(dev):
     from texttoaudiogrounding_amd import ops as _ops
+    from texttoaudiogrounding_amd import torch_ops  # noqa: F401  (registers torch.ops.tag.*, which the head tests call)
     return _ops
 
 

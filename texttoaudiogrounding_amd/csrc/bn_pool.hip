@@ -310,24 +310,39 @@ struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
 // ------------------------------------------------------------------------------------------
 // forward: act(bn(y)) -> pool -> dropout
 // ------------------------------------------------------------------------------------------
+// The bf16 instances of the pool forward and of the pool-backward reduction are software-pipelined: the loads of a thread's
+// NEXT slot are issued before the arithmetic of the current one (two raw register sets, the loop unrolled by two so that no
+// register rotation -- at which the compiler would wait for the loads -- is needed).  Those instances are latency-bound
+// otherwise: 3-6 waves per SIMD, each alternating between one batch of loads and a few hundred dependent VALU operations
+// (rocprofv3: VALU issue 0.15-0.22 per SIMD cycle at 2.1-3.1 TB/s; pipelined: forward 158 -> 128 us, reduction 229 -> 182 us
+// on the first two blocks).  The fp32 instances already run at 5.6 TB/s and LOSE 3-7 % to the extra registers, and so does
+// the backward apply pass in both storage types: they keep the plain loop.
+template <class TS> constexpr bool pool_pipelined() { return Act<TS>::is_bf16; }
 template <int PH, int PW, class TS = float, int NC = 4>
 __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restrict__ y,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
                                                              TS* __restrict__ out, int B, int H, int W, int C,
                                                              int act, int pool, float drop_p, uint64_t seed) {
+    typedef typename ActN<TS, NC>::raw_t raw_t;
     const int Ho = H / PH, Wo = W / PW, CN = C / NC, rpi = 256 / CN;
     const int c = (threadIdx.x % CN) * NC, rsub = threadIdx.x / CN;
-    const long slots = (long)B * Ho * Wo;
+    const long slots = (long)B * Ho * Wo, stride = (long)gridDim.x * rpi;
     const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float s[NC], t[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) { s[j] = scale ? scale[c + j] : 1.0f; t[j] = scale ? shift[c + j] : 0.0f; }
-    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
+    auto load = [&](long r, raw_t (&raw)[PH][PW]) {
+        const int wo = (int)(r % Wo); const long q = r / Wo;
+        const int ho = (int)(q % Ho), b = (int)(q / Ho);
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw)
+                raw[dh][dw] = ActN<TS, NC>::ldraw(y + (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c);
+    };
+    auto finish = [&](long r, const raw_t (&raw)[PH][PW]) {
         const long e0 = r * C + c;                    // flat index of the thread's first output element
-        const int wo = (int)(r % Wo); long q = r / Wo;
-        const int ho = (int)(q % Ho);
-        const int b = (int)(q / Ho);
         float sum[NC], mx[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) { sum[j] = 0.0f; mx[j] = 0.0f; }
@@ -335,9 +350,8 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
-                const size_t off = (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c;
                 float v[NC];
-                ActN<TS, NC>::ld(y + off, v);
+                ActN<TS, NC>::unpack(raw[dh][dw], v);
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     float a = fmaf(v[j], s[j], t[j]);
@@ -360,6 +374,20 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
             if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)e0 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
         }
         ActN<TS, NC>::st(out + e0, rr);
+    };
+    raw_t ra[PH][PW], rb[PH][PW];
+    long r = (long)blockIdx.x * rpi + rsub;
+    if constexpr (pool_pipelined<TS>()) {
+        if (r < slots) load(r, ra);
+        for (; r < slots; r += 2 * stride) {
+            const long r2 = r + stride, r3 = r2 + stride;
+            if (r2 < slots) load(r2, rb);
+            finish(r, ra);
+            if (r3 < slots) load(r3, ra);
+            if (r2 < slots) finish(r2, rb);
+        }
+    } else {
+        for (; r < slots; r += stride) { load(r, ra); finish(r, ra); }
     }
 }
 
@@ -378,9 +406,24 @@ struct PoolBwdCtx {
 #pragma unroll
         for (int j = 0; j < NC; ++j) { sv[j] = scale[c + j]; tv[j] = shift[c + j]; mv[j] = mean[c + j]; iv[j] = invstd[c + j]; }
     }
-    // dz for the slot (b, hs, ws, c..c+3); valid[dh][dw] tells which positions exist
-    __device__ void slot(int b, int hs, int ws, int c, float dz[PH][PW][NC], float xh[PH][PW][NC],
-                         bool ex[PH][PW]) const {
+    typedef typename ActN<TS, NC>::raw_t raw_t;
+    struct Raw { raw_t v[PH][PW]; raw_t g; };
+    // the loads of the slot (b, hs, ws, c..c+NC-1): positions outside the image load nothing (partial slots of the
+    // floor-dropped last row / column), only full slots have an upstream gradient
+    __device__ void load(int b, int hs, int ws, int c, Raw& raw) const {
+        const int Ho = H / PH, Wo = W / PW;
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < PW; ++dw) {
+                const int h = hs * PH + dh, w = ws * PW + dw;
+                raw.v[dh][dw] = (h < H && w < W) ? ActN<TS, NC>::ldraw(y + (((size_t)b * H + h) * W + w) * C + c) : ActN<TS, NC>::zero();
+            }
+        raw.g = (hs < Ho && ws < Wo) ? ActN<TS, NC>::ldraw(dout + (((size_t)b * Ho + hs) * Wo + ws) * C + c) : ActN<TS, NC>::zero();
+    }
+    // dz for the slot from its loaded values; ex[dh][dw] tells which positions exist
+    __device__ void compute(const Raw& raw, int b, int hs, int ws, int c, float dz[PH][PW][NC], float xh[PH][PW][NC],
+                            bool ex[PH][PW]) const {
         const int Ho = H / PH, Wo = W / PW;
         const bool full = hs < Ho && ws < Wo;
         float a[PH][PW][NC];
@@ -391,9 +434,7 @@ struct PoolBwdCtx {
                 const int h = hs * PH + dh, w = ws * PW + dw;
                 ex[dh][dw] = h < H && w < W;
                 float vv[NC];
-#pragma unroll
-                for (int j = 0; j < NC; ++j) vv[j] = 0.0f;
-                if (ex[dh][dw]) ActN<TS, NC>::ld(y + (((size_t)b * H + h) * W + w) * C + c, vv);
+                ActN<TS, NC>::unpack(raw.v[dh][dw], vv);
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     a[dh][dw][j] = fmaf(vv[j], sv[j], tv[j]);
@@ -404,7 +445,7 @@ struct PoolBwdCtx {
         if (!full) return;
         const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
         float g[NC];
-        ActN<TS, NC>::ld(dout + oi, g);
+        ActN<TS, NC>::unpack(raw.g, g);
         const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
@@ -440,17 +481,44 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW,
 #pragma unroll
     for (int j = 0; j < NC; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
     ctx.prep(c);
-    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
-        const int ws = (int)(r % Wo); long q = r / Wo;
-        const int hs = (int)(q % Ho); const int b = (int)(q / Ho);
+    typedef typename PoolBwdCtx<PH, PW, TS, NC>::Raw Raw;
+    const long stride = (long)gridDim.x * rpi;
+    auto load = [&](long r, Raw& raw) {
+        const int ws = (int)(r % Wo); const long q = r / Wo;
+        ctx.load((int)(q / Ho), (int)(q % Ho), ws, c, raw);
+    };
+    auto finish = [&](long r, const Raw& raw) {
+        const int ws = (int)(r % Wo); const long q = r / Wo;
         float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
-        ctx.slot(b, hs, ws, c, dz, xh, ex);
+        ctx.compute(raw, (int)(q / Ho), (int)(q % Ho), ws, c, dz, xh, ex);
+        // per-slot sums in fp32 (PH * PW terms), folded into the thread's fp64 running sums once per slot
+        float f1[NC], f2[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { f1[j] = 0.0f; f2[j] = 0.0f; }
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw)
 #pragma unroll
-                for (int j = 0; j < NC; ++j) { s1[j] += dz[dh][dw][j]; s2[j] += dz[dh][dw][j] * xh[dh][dw][j]; }
+                for (int j = 0; j < NC; ++j) { f1[j] += dz[dh][dw][j]; f2[j] = fmaf(dz[dh][dw][j], xh[dh][dw][j], f2[j]); }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; }
+    };
+    {
+        Raw ra, rb;
+        long r = (long)blockIdx.x * rpi + rsub;
+        if constexpr (pool_pipelined<TS>()) {
+            if (r < slots) load(r, ra);
+            for (; r < slots; r += 2 * stride) {
+                const long r2 = r + stride, r3 = r2 + stride;
+                if (r2 < slots) load(r2, rb);
+                finish(r, ra);
+                if (r3 < slots) load(r3, ra);
+                if (r2 < slots) finish(r2, rb);
+            }
+        } else {
+            for (; r < slots; r += stride) { load(r, ra); finish(r, ra); }
+        }
     }
     double* mine = sred + threadIdx.x * 2 * NC;
 #pragma unroll
@@ -486,11 +554,17 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, 
         k1[j] = bn_train ? dbeta[c + j] * invN : 0.0f;
         k2[j] = bn_train ? dgamma[c + j] * invN : 0.0f;
     }
-    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += (long)gridDim.x * rpi) {
-        const int ws = (int)(r % Ws); long q = r / Ws;
-        const int hs = (int)(q % Hs); const int b = (int)(q / Hs);
+    typedef typename PoolBwdCtx<PH, PW, TS, NC>::Raw Raw;
+    const long stride = (long)gridDim.x * rpi;
+    auto load = [&](long r, Raw& raw) {
+        const int ws = (int)(r % Ws); const long q = r / Ws;
+        ctx.load((int)(q / Hs), (int)(q % Hs), ws, c, raw);
+    };
+    auto finish = [&](long r, const Raw& raw) {
+        const int ws = (int)(r % Ws); const long q = r / Ws;
+        const int hs = (int)(q % Hs), b = (int)(q / Hs);
         float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
-        ctx.slot(b, hs, ws, c, dz, xh, ex);
+        ctx.compute(raw, b, hs, ws, c, dz, xh, ex);
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
@@ -502,7 +576,9 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, 
                 for (int j = 0; j < NC; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
                 ActN<TS, NC>::st(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c, o);
             }
-    }
+    };
+    Raw ra;
+    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += stride) { load(r, ra); finish(r, ra); }
 }
 
 // plain relu(bn(y)) backward (no pooling)

@@ -108,7 +108,12 @@ template <> struct Act<bf16_t> {
 // NC consecutive channels of one pixel <-> NC floats: 16-byte accesses for fp32 (NC = 4) and for bf16 with NC = 8 (the bf16
 // BatchNorm / pool passes take 8 channels per thread: an 8-byte access moves data at 0.55-0.7 of the 16-byte rate)
 template <class TS, int NC> struct ActN;
+// raw_t / ldraw / unpack: the load on its own (issued one slot ahead by the software-pipelined pool passes) and the conversion
 template <> struct ActN<float, 4> {
+    typedef f32x4 raw_t;
+    static __device__ __forceinline__ raw_t ldraw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ raw_t zero() { return (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    static __device__ __forceinline__ void unpack(raw_t q, float (&v)[4]) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
     static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(p);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
@@ -118,6 +123,12 @@ template <> struct ActN<float, 4> {
     }
 };
 template <> struct ActN<bf16_t, 4> {
+    typedef tag_u32x2 raw_t;
+    static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *reinterpret_cast<const tag_u32x2*>(p); }
+    static __device__ __forceinline__ raw_t zero() { return (tag_u32x2){0u, 0u}; }
+    static __device__ __forceinline__ void unpack(raw_t w, float (&v)[4]) {
+        v[0] = tag_bf16_lo(w.x); v[1] = tag_bf16_hi(w.x); v[2] = tag_bf16_lo(w.y); v[3] = tag_bf16_hi(w.y);
+    }
     static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[4]) {
         const tag_u32x2 w = *reinterpret_cast<const tag_u32x2*>(p);
         v[0] = tag_bf16_lo(w.x); v[1] = tag_bf16_hi(w.x); v[2] = tag_bf16_lo(w.y); v[3] = tag_bf16_hi(w.y);
@@ -127,6 +138,13 @@ template <> struct ActN<bf16_t, 4> {
     }
 };
 template <> struct ActN<bf16_t, 8> {
+    typedef tag_u32x4 raw_t;
+    static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *reinterpret_cast<const tag_u32x4*>(p); }
+    static __device__ __forceinline__ raw_t zero() { return (tag_u32x4){0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ void unpack(raw_t w, float (&v)[8]) {
+        v[0] = tag_bf16_lo(w.x); v[1] = tag_bf16_hi(w.x); v[2] = tag_bf16_lo(w.y); v[3] = tag_bf16_hi(w.y);
+        v[4] = tag_bf16_lo(w.z); v[5] = tag_bf16_hi(w.z); v[6] = tag_bf16_lo(w.w); v[7] = tag_bf16_hi(w.w);
+    }
     static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
         const tag_u32x4 w = *reinterpret_cast<const tag_u32x4*>(p);
         v[0] = tag_bf16_lo(w.x); v[1] = tag_bf16_hi(w.x); v[2] = tag_bf16_lo(w.y); v[3] = tag_bf16_hi(w.y);

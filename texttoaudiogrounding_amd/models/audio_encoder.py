@@ -115,8 +115,7 @@ class CrnnEncoder(nn.Module):
 
     def forward(self, input_dict: Dict):
         if self.training:
-            for m in self._bn_modules():
-                m.num_batches_tracked += 1
+            ops.bump_bn_counters(self, self._bn_modules())
         x = ops.CrnnFunction.apply(input_dict["waveform"], self, *self._flat_params())
         length = torch.div(torch.as_tensor(input_dict["waveform_len"]), self.hop_length, rounding_mode="floor") + 1
         length = torch.div(length, self.downsample_ratio, rounding_mode="floor")
@@ -203,9 +202,8 @@ class Cnn8Rnn(nn.Module):
         if self.training and input_dict.get("mixup_lambda", None) is not None:
             raise NotImplementedError("mixup is not used on the strongly-supervised path")
         if self.training and not self.freeze_bn:
-            for m in (self.bn0, *(getattr(self, f"conv_block{i}").bn1 for i in range(1, 5)),
-                      *(getattr(self, f"conv_block{i}").bn2 for i in range(1, 5))):
-                m.num_batches_tracked += 1
+            ops.bump_bn_counters(self, [self.bn0, *(getattr(self, f"conv_block{i}").bn1 for i in range(1, 5)),
+                                        *(getattr(self, f"conv_block{i}").bn2 for i in range(1, 5))])
         x = ops.Cnn8RnnFunction.apply(waveform, self, *self._flat_params())
         length = torch.div(torch.as_tensor(input_dict["waveform_len"]), self.hop_length, rounding_mode="floor") + 1
         length = torch.div(length, self.downsample_ratio, rounding_mode="floor")

@@ -643,14 +643,40 @@ def _embed_flag(like):
     return _embed_err[key]
 
 
+def _joined(a, b, shape):
+    """``torch.cat / stack([a, b])`` as a VIEW when b lies right behind a in the same storage (runner.FlatParams lays the
+    two directions of an nn.GRU out that way), else a copy: no concatenation kernels per step on the flat-parameter path."""
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        return torch.empty(0, device=a.device, dtype=a.dtype).set_(a.untyped_storage(), a.storage_offset(), tuple(shape))
+    return torch.cat([a.reshape(-1), b.reshape(-1)]).view(*shape)
+
+
+def bump_bn_counters(owner, bns):
+    """``num_batches_tracked += 1`` of the BatchNorm modules ``bns`` (all in train mode) as ONE kernel: the nine 0-dim
+    int64 buffers are re-homed (once per device move) as views of one flat tensor kept on ``owner``; state_dict keys,
+    load_state_dict and the rank-0 buffer broadcast see the same buffers as before."""
+    flat = getattr(owner, "_tag_nbt_flat", None)
+    ok = (flat is not None and flat.numel() == len(bns) and flat.device == bns[0].num_batches_tracked.device
+          and all(m._buffers["num_batches_tracked"].data_ptr() == flat.data_ptr() + 8 * i for i, m in enumerate(bns)))
+    if not ok:
+        flat = torch.stack([m.num_batches_tracked.detach().to(torch.long) for m in bns])
+        for i, m in enumerate(bns):
+            m._buffers["num_batches_tracked"] = flat[i]
+        owner._tag_nbt_flat = flat
+    flat += 1
+
+
 def gru_bidir_forward(x2d, rnn, B, T, need_grad):
     """x2d (B*T, I); rnn = [w_ih, w_hh, b_ih, b_hh] x (forward, reverse).  Returns y (B,T,2H) and the saved state."""
     Hh = rnn[1].shape[1]
     M = B * T
-    w_ih = torch.cat([rnn[0], rnn[4]], 0)            # (2*3H, I)
-    b_ih = torch.cat([rnn[2], rnn[6]], 0)
-    w_hh = torch.stack([rnn[1], rnn[5]], 0).contiguous()   # (2,3H,H)
-    b_hh = torch.stack([rnn[3], rnn[7]], 0).contiguous()
+    I = rnn[0].shape[1]
+    w_ih = _joined(rnn[0], rnn[4], (6 * Hh, I))            # (2*3H, I)
+    b_ih = _joined(rnn[2], rnn[6], (6 * Hh,))
+    w_hh = _joined(rnn[1], rnn[5], (2, 3 * Hh, Hh))
+    b_hh = _joined(rnn[3], rnn[7], (2, 3 * Hh))
     gi = gemm(x2d, w_ih, M, 6 * Hh, x2d.shape[1], transB=True, bias=b_ih)
     y = _empty(B, T, 2 * Hh, like=x2d)
     gates = _empty(B, T, 2, 4 * Hh, like=x2d) if need_grad else None

@@ -38,7 +38,7 @@ class FlatParams:
     re-homed elsewhere instead of silently writing into / stepping on memory nobody reads."""
 
     def __init__(self, model: torch.nn.Module):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.params = self._ordered([p for p in model.parameters() if p.requires_grad], model)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.empty(n, device=dev, dtype=torch.float32)
@@ -54,6 +54,23 @@ class FlatParams:
             p._tag_grad_sink = p.grad
             off += k
         self.numel = n
+
+    @staticmethod
+    def _ordered(params, model):
+        """model.parameters() order, except that the two directions of every one-layer bidirectional nn.GRU are interleaved
+        (w_ih, w_ih_reverse, w_hh, w_hh_reverse, b_ih, b_ih_reverse, b_hh, b_hh_reverse): the HIP GRU takes each pair as one
+        tensor, and adjacent storage makes that a view instead of a torch.cat per step (ops._joined)."""
+        pos = {id(p): i for i, p in enumerate(params)}
+        for m in model.modules():
+            if isinstance(m, torch.nn.GRU) and m.bidirectional and m.num_layers == 1:
+                names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+                group = [getattr(m, n + sfx) for n in names for sfx in ("", "_reverse")]
+                if all(id(t) in pos for t in group):
+                    first = min(pos[id(t)] for t in group)
+                    rest = [p for p in params if all(p is not t for t in group)]
+                    params = rest[:first] + group + rest[first:]
+                    pos = {id(p): i for i, p in enumerate(params)}
+        return params
 
     def zero_grad(self):
         """Zero the flat gradient; parameters whose ``.grad`` was dropped (``model.zero_grad()`` /

@@ -850,23 +850,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
 // dw[co][ci][tap] = sum_split partial[split][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cin,
                                                            int Cout, float* __restrict__ dw) {
-    // 64 consecutive elements x 4 interleaved split groups per block, folded through LDS in a fixed order
-    __shared__ float sh[4][64];
-    const long n = (long)9 * Cin * Cout;
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    // 64 consecutive elements (16 lanes x float4) x 16 interleaved split groups per block, folded through LDS in a fixed
+    // order; up to four splits of a group are in flight at a time.  The partials of a layer are ~150 MB (1024 workgroup
+    // tiles of the all-taps kernel): 16-byte loads and n / 64 blocks (>= 576 even for the 64 x 64 layer) read them at the HBM
+    // rate where one float per lane and 4 groups managed 2.7 TB/s.  Summation order (fixed): split group g = sp mod 16 in
+    // increasing sp, then a balanced tree over the 16 groups.
+    __shared__ f32x4 sh[16][16];
+    const long n = (long)9 * Cin * Cout;          // multiple of 4 (Cin, Cout multiples of 32)
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
     for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {
-        const long i = base + e;                  // indexes partial layout [tap][ci][co] (coalesced reads)
-        float s = 0.0f;
-        if (i < n)
-            for (int sp = g; sp < splits; sp += 4) s += partial[(size_t)sp * n + i];
+        const long i = base + 4 * e;              // indexes partial layout [tap][ci][co] (coalesced reads)
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < n) {
+            const float* p = partial + i;
+            int sp = g;
+            for (; sp + 48 < splits; sp += 64) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sp * n);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 16) * n);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 32) * n);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 48) * n);
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; sp < splits; sp += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)sp * n);
+        }
         sh[g][e] = s;
         __syncthreads();
         if (g == 0 && i < n) {
-            const float t = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
-            const int co = (int)(i % Cout);
-            const long r = i / Cout;
-            const int ci = (int)(r % Cin), tap = (int)(r / Cin);
-            dw[((size_t)co * Cin + ci) * 9 + tap] = t;
+            f32x4 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = sh[2 * q][e] + sh[2 * q + 1][e];
+            const f32x4 r4 = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long iq = i + q;
+                const int co = (int)(iq % Cout);
+                const long r = iq / Cout;
+                const int ci = (int)(r % Cin), tap = (int)(r / Cin);
+                dw[((size_t)co * Cin + ci) * 9 + tap] = r4[q];
+            }
         }
         __syncthreads();
     }
@@ -1551,7 +1572,7 @@ int tag_wgrad_alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks
 }
 int tag_launch_wgrad_reduce(const float* partial, int splits, int Cin, int Cout, float* dw, hipStream_t st) {
     const long nred = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 4096 ? 4096 : cdiv(nred, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 8192 ? 8192 : cdiv(nred, 64)), dim3(256), 0, st,
                        partial, splits, Cin, Cout, dw);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -1637,7 +1658,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
         else if (W == 32) launch_wgrad_alltaps<32>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         else launch_wgrad_alltaps<64>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         TAG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 4096 ? 4096 : cdiv(nred, 64)), dim3(256), 0, st,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nred, 64) > 8192 ? 8192 : cdiv(nred, 64)), dim3(256), 0, st,
                            partial, sp, Cin, Cout, dw);
         TAG_LAUNCH_CHECK();
         return 0;
@@ -1654,7 +1675,7 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
                          as_stream(stream));
     TAG_LAUNCH_CHECK();
     const long n = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64) > 4096 ? 4096 : cdiv(n, 64)), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64) > 8192 ? 8192 : cdiv(n, 64)), dim3(256), 0,
                        as_stream(stream), partial, splits, Cin, Cout, dw);
     TAG_LAUNCH_CHECK();
     return 0;

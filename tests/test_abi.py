@@ -113,3 +113,15 @@ def test_yaml_style_construction_with_aliases():
     import sys
     for k in [k for k in sys.modules if k.split(".")[0] in ("models", "losses", "utils")]:
         del sys.modules[k]
+
+
+def test_host_resident_token_ids_out_of_range_raise_at_once():
+    """ids handed over on the host (the reference's collate output) are range-checked before anything is launched
+    and raise IndexError immediately like nn.Embedding (models/text_encoder.py:39); no GPU needed to see it."""
+    import torch
+    from texttoaudiogrounding_amd.models.text_encoder import EmbeddingAgg
+    enc = EmbeddingAgg(50, 16)
+    with pytest.raises(IndexError, match="out of range"):
+        enc({"text": torch.tensor([[1, 2, 50]]), "text_len": torch.tensor([3])})
+    with pytest.raises(IndexError, match="out of range"):
+        enc({"text": torch.tensor([[1, -1, 3]]), "text_len": torch.tensor([3])})

@@ -38,7 +38,8 @@
 #define TAG_X3_LDS_EPI 1
 #endif
 // ablation of the forward/dgrad kernel for tools/conv_bf16_bench.py (never set in the product build): 1 = no output stores,
-// 2 = no statistics epilogue, 3 = no MFMAs (and hence no operand reads), 4 = 1 + 2
+// 2 = no statistics epilogue, 3 = no MFMAs (and hence no operand reads), 4 = 1 + 2, 5 = A fragments read from LDS only once per
+// chunk, 6 = weight fragments loaded only in the prologue, 7 = 5 + 6 (MFMAs with no operand traffic)
 #ifndef TAG_X3_ABL
 #define TAG_X3_ABL 0
 #endif
@@ -306,10 +307,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
             const bool newstep = hidx % HS == 0;
             if (newstep) {                                        // weights of step+RING-1 (possibly of the next chunk)
                 constexpr int D = RING - 1;
-                if (step + D < 18) issue_b(cc, step + D, (step + D) % RING);
-                else if (more) issue_b(cc + 1, step + D - 18, (step + D) % RING);
+                if (TAG_X3_ABL != 6 && TAG_X3_ABL != 7) {
+                    if (step + D < 18) issue_b(cc, step + D, (step + D) % RING);
+                    else if (more) issue_b(cc + 1, step + D - 18, (step + D) % RING);
+                }
             }
-            if (hidx + 1 < NH) load_a(hidx + 1, afb[(hidx + 1) & 1]);
+            if (hidx + 1 < NH && ((TAG_X3_ABL != 5 && TAG_X3_ABL != 7) || hidx == 0)) load_a(hidx + 1, afb[(hidx + 1) & 1]);
 #pragma unroll
             for (int p = P0; p < 9; ++p)
 #pragma unroll

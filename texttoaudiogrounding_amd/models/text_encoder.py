@@ -57,7 +57,15 @@ class EmbeddingAgg(nn.Module):
     def forward(self, input_dict):
         table = self.embedding.core.weight
         dev = table.device
-        text = input_dict["text"].long().to(dev).contiguous()
+        text = input_dict["text"]
+        if isinstance(text, torch.Tensor) and not text.is_cuda and text.numel():
+            # ids still on the host (what the reference's collate function hands over): checked right here, and an id outside
+            # the table raises at once like nn.Embedding (models/text_encoder.py:39).  Device-resident ids are checked by the
+            # kernel, which can only raise a sticky flag: ops.check_async_errors() (StrongRunner.loss_value, segments_for_thresholds)
+            lo, hi = int(text.min()), int(text.max())
+            if lo < 0 or hi >= table.shape[0]:
+                raise IndexError(f"index out of range in self: token ids span [{lo}, {hi}], the table has {table.shape[0]} rows")
+        text = text.long().to(dev).contiguous()
         lens = torch.as_tensor(input_dict["text_len"]).long().to(dev).contiguous()
         if ops.DIRECT_GRADS:          # StrongRunner: scatter the table gradient straight into its flat-gradient rows
             seq, tok = ops.EmbedMeanFunction.apply(table, text, lens, True)

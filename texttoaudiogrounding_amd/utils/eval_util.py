@@ -34,6 +34,7 @@ def segments_for_thresholds(frame_sim: torch.Tensor, thresholds, window_size: in
     regions, counts = ops.segments(frame_sim, thresholds, window_size, n_connect)
     regions = regions.cpu().numpy()
     counts = counts.cpu().numpy()
+    ops.check_async_errors()          # the copies above synchronised anyway: surface a GRU exchange timeout / a bad token id here
     B, NT = counts.shape
     return [[regions[b, t, :counts[b, t]].copy() for t in range(NT)] for b in range(B)]
 

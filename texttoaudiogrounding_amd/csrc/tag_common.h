@@ -80,7 +80,14 @@ __device__ __forceinline__ unsigned tag_bf16_rne(float f) {           // -> bits
     const unsigned u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ unsigned tag_pack_bf16(float lo, float hi) { return tag_bf16_rne(lo) | (tag_bf16_rne(hi) << 16); }
+// two floats -> packed bf16 pair (low half = first value), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (the integer
+// form above costs ~10 VALU operations per pair, which the bf16 epilogues / prologues pay 30-60 times per lane and tile)
+typedef __bf16 tag_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tag_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned tag_pack_bf16(float lo, float hi) {
+    const tag_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tag_bf16x2));
+}
 __device__ __forceinline__ float tag_bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float tag_bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -48,6 +48,15 @@
 #define TAG_X3_RING1 9
 #endif
 
+// -DTAG_X3_PROF (tools/conv_x3_prof.py, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
+#ifdef TAG_X3_PROF
+__device__ unsigned long long tag_x3_prof[10];
+extern "C" int tag_debug_get_x3_prof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_x3_prof), 80) == hipSuccess ? 0 : -1; }
+#define XP_MARK(i) { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); xpc[i] += p1_ - xp0; xp0 = p1_; }
+#else
+#define XP_MARK(i)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -110,6 +119,12 @@ __device__ __forceinline__ void split_pack(float a, float b, unsigned& h, unsign
     h = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
     m = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
     l = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+}
+
+// value of lane ^ 1: DPP quad_perm [1,0,3,2] -- one VALU operation (__shfl_xor compiles to ds_bpermute_b32: an LDS-crossbar
+// round trip per call; the bf16 epilogue makes 32-64 of them per lane and spent 10 k clocks per tile there, tools/conv_x3_prof.py)
+__device__ __forceinline__ float lane_xor1(float x) {
+    return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(x), 0xB1, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -269,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     };
 
     const int cchunks = Cin / KC;
+#ifdef TAG_X3_PROF   // 0 prologue, 1 MFMA loop, 2 barrier, 3 store_patch, 4 barrier, 5 pre-epilogue barrier, 6 pack + LDS write, 7 16-B stores, 8 statistics
+    unsigned long long xpc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xp0 = __builtin_amdgcn_s_memtime();
+#endif
     issue_patch(0);
 #pragma unroll
     for (int st = 0; st < RING - 1; ++st) issue_b(0, st, st);
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                 af[i][sp] = *reinterpret_cast<const u32x4*>(smem + abase[hb + i] + (tapoff + sp * G::PLANE));
         }
     };
+    XP_MARK(0)
     for (int cc = 0; cc < cchunks; ++cc) {
         const bool more = cc + 1 < cchunks;
         if (more) issue_patch(cc + 1);
@@ -328,10 +347,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        XP_MARK(1)
         if (more) {
             __syncthreads();                                      // every wave is done reading the patch
+            XP_MARK(2)
             store_patch(cc + 1);
+            XP_MARK(3)
             __syncthreads();
+            XP_MARK(4)
         }
     }
 
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
     constexpr bool LDS_EPI = HS16 && (TAG_X3_LDS_EPI != 0);
     constexpr int OROWB = BN_ * 2 + 16;                           // bytes per pixel row of the staged tile
     if constexpr (LDS_EPI) __syncthreads();                       // every wave is done reading the patch
+    XP_MARK(5)
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -355,13 +379,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
             const int h = h0 + ty;
             okrow[i][r] = h < H;
             if constexpr (LDS_EPI) {
-                const float other = __shfl_xor(acc[i][r], 1, 64);
-                const bool mine = ((r ^ ml) & 1) == 0;
-                const unsigned w2 = (ml & 1) ? tag_pack_bf16(other, acc[i][r]) : tag_pack_bf16(acc[i][r], other);
-                if (mine) *reinterpret_cast<unsigned*>(smem + pm * OROWB + ((wn * 32 + ml) & ~1) * 2) = w2;
+                // every lane stores its own element as 2 bytes: no partner lane, no select, no exec-masked branch per element
+                *reinterpret_cast<unsigned short*>(smem + pm * OROWB + (wn * 32 + ml) * 2) =
+                    (unsigned short)tag_pack_bf16(acc[i][r], 0.0f);
             } else if constexpr (HS16) {
                 // channel pairs: even lanes store (n, n+1) of the even rows r, odd lanes (n-1, n) of the odd rows
-                const float other = __shfl_xor(acc[i][r], 1, 64);
+                const float other = lane_xor1(acc[i][r]);
                 const bool mine = ((r ^ ml) & 1) == 0;
                 const unsigned w2 = (ml & 1) ? tag_pack_bf16(other, acc[i][r]) : tag_pack_bf16(acc[i][r], other);
                 if (TAG_X3_ABL != 1 && TAG_X3_ABL != 4 && mine && h < H)
@@ -370,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                 if (h < H) y[(((size_t)img * H + h) * W + tx) * Cout + n] = acc[i][r];
             }
         }
+    XP_MARK(6)
     if constexpr (LDS_EPI) {
         __syncthreads();
         constexpr int TP = WM * MB * 32, PPP = BN_ / 8;           // pixels per tile, 16-byte pieces per pixel
@@ -385,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
                     *reinterpret_cast<const u32x4*>(smem + pm * OROWB + c8 * 16);
         }
     }
+    XP_MARK(7)
     // ---- EPI == 1: the reduction half of the BatchNorm+ReLU backward this gradient flows into (conv.hip, EPI == 1): per wave
     // M-group and channel sum(g) and sum(g * xhat), g taken from the fp32 accumulators; rows [prow][2][Cout] ----
     if (EPI == 1) {
@@ -441,6 +466,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
         if (kl == 0) { ps[n] = mu; ps[Cout + n] = r1; ps[2 * Cout + n] = q; }
         if (n0 == 0 && wn == 0 && lane == 0) stats[(size_t)m_tiles * MG * 3 * Cout + prow] = cnt;
     }
+#ifdef TAG_X3_PROF
+    XP_MARK(8)
+    if (blockIdx.x == 1500 && tid == 0) for (int i = 0; i < 9; ++i) tag_x3_prof[i] = xpc[i];
+#endif
 }
 
 // (Cout,Cin,3,3) fp32 -> split bf16 planes in B-fragment order, for forward (K = Cin, N = Cout) and dgrad

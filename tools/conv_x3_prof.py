@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase clocks of ONE workgroup of the one-product bf16 conv kernel (library built with -DTAG_X3_PROF)."""
+"""Phase clocks of ONE workgroup of the one-product bf16 conv kernel (library built with -DTAG_X3_PROF):
+    bash tools/run_x3_prof.sh   (GPU box, from the repo root)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,9 +17,9 @@ for (H, W, Cin, Cout) in [(1001, 64, 64, 64), (500, 32, 128, 128), (250, 16, 256
     for _ in range(3):
         ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=True)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 10)()
     L.tag_debug_get_x3_prof(buf)
-    names = ["prologue", "MFMA loop", "barrier 1", "store_patch", "barrier 2", "epi: pack + LDS write", "epi: barrier + 16-B stores", "epi: statistics"]
-    v = list(buf)
-    tot = sum(v[:8])
-    print(f"{H}x{W} {Cin}->{Cout}: total {tot} clk  " + "  ".join(f"{n} {x_} ({100 * x_ / tot:.0f}%)" for n, x_ in zip(names, v[:8])))
+    names = ["prologue", "MFMA loop", "barrier", "store_patch", "barrier", "pre-epilogue barrier", "pack + LDS write", "16-B stores", "statistics"]
+    v = list(buf)[:9]
+    tot = sum(v)
+    print(f"{H}x{W} {Cin}->{Cout}: total {tot} clk  " + "  ".join(f"{n} {x_} ({100 * x_ / tot:.0f}%)" for n, x_ in zip(names, v)))

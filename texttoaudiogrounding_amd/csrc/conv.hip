@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 #ifndef TAG_HALO_NB
 #define TAG_HALO_NB 1
 #endif
+// -DTAG_HALO_PROF (tools/run_halo_prof.sh, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
+#ifdef TAG_HALO_PROF
+__device__ unsigned long long tag_halo_prof[8];
+#define HP_MARK(i) { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); hpc[i] += p1_ - hp0; hp0 = p1_; }
+#else
+#define HP_MARK(i)
+#endif
 template <int TW>
 struct HaloGeom {
     static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
@@ -415,12 +422,16 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
         }
     };
 
+#ifdef TAG_HALO_PROF   // 0 prologue, 1 MFMA taps, 2 barrier, 3 operand stores, 4 barrier, 5 output stores, 6 statistics epilogue
+    unsigned long long hpc[7] = {0, 0, 0, 0, 0, 0, 0}, hp0 = __builtin_amdgcn_s_memtime();
+#endif
     issue_patch(0);
     issue_b(0);
     __syncthreads();                           // Ss visible
     store_patch(0);
     store_b(0);
     __syncthreads();
+    HP_MARK(0)
     for (int it = 0; it < total; ++it) {
         const int cc = it / 9, tap = it - cc * 9;
         const int buf = NB == 2 ? (it & 1) : 0;
@@ -431,10 +442,14 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
         __builtin_amdgcn_sched_barrier(0);
         mma_tap(buf, tap);
         __builtin_amdgcn_sched_barrier(0);
+        HP_MARK(1)
         if (NB == 1 || newpatch) __syncthreads();          // all waves are done reading what is overwritten next
+        HP_MARK(2)
         if (more) store_b(NB == 2 ? (buf ^ 1) : 0);
         if (newpatch) store_patch(cc + 1);
+        HP_MARK(3)
         __syncthreads();
+        HP_MARK(4)
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -450,6 +465,7 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
                 if (h < H && n < Cout) y[(((size_t)img * H + h) * W + w) * Cout + n] = acc[i][j][r];
             }
         }
+    HP_MARK(5)
     // ---- fused BatchNorm statistics of the output (training): per (64-pixel wave tile, channel) a pivot mu (the tile
     // mean as rounded in fp32), r = sum(y - mu) and q = sum((y - mu)^2): the tile's sum is n*mu + r EXACTLY up to the
     // rounding of the small deviations, so channels whose |mean| >> std keep their variance;
@@ -533,6 +549,10 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
         }
         if (n0 == 0 && wn0 == 0 && lane == 0) stats[(size_t)m_tiles * 2 * 3 * Cout + prow] = cnt;
     }
+#ifdef TAG_HALO_PROF
+    HP_MARK(6)
+    if (blockIdx.x == 1500 && tid == 0) for (int i = 0; i < 7; ++i) tag_halo_prof[i] = hpc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1827,3 +1847,7 @@ extern "C" int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_sca
     TAG_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef TAG_HALO_PROF
+extern "C" int tag_debug_get_halo_prof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_prof), 56) == hipSuccess ? 0 : -1; }
+#endif

@@ -623,32 +623,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
         else if (d == 2) { img = o_img[2]; h0 = o_h[2]; w0 = o_w[2]; }
         else origin_div(c, img, h0, w0);
     };
+    // ---- chunk-invariant staging geometry of this thread's items, computed ONCE (the per-chunk form re-derived row / column /
+    // 64-bit addresses of every item at every chunk: 619 VALU instructions per 64-pixel chunk against 36 MFMAs -- the staging
+    // phase was 52-57 % of the one-product kernel's time, tools/conv_x3_prof.py).  Per chunk an item now costs two adds and
+    // two compares for its validity and one 32-bit add for its address.
+    constexpr unsigned ESZ = HS16 ? 2u : 4u;                     // bytes per stored element of x / dy
+    int x_pr[XITEMS], x_pc[XITEMS];
+    unsigned x_rel[XITEMS], x_dst0[XITEMS], x_ex = 0;
+#pragma unroll
+    for (int i = 0; i < XITEMS; ++i) {
+        const int pp = (tid + 256 * i) >> QSH;
+        x_pr[i] = pp / PW; x_pc[i] = pp - x_pr[i] * PW;
+        x_ex |= (unsigned)(pp < CH * PW) << i;
+        x_rel[i] = (unsigned)((x_pr[i] * W + x_pc[i]) * Cin + ca) * ESZ;          // byte offset relative to pixel (first_row, w0 - 1)
+        x_dst0[i] = qoff * (unsigned)G::XPL + (unsigned)x_pc[i] * 64u + qbyte;
+    }
+    unsigned d_rel[DITEMS], d_dst0[DITEMS];
+    int d_kh[DITEMS];
+#pragma unroll
+    for (int i = 0; i < DITEMS; ++i) {
+        const int k = (tid + 256 * i) >> QSH;
+        d_kh[i] = k / CW;
+        d_rel[i] = (unsigned)((d_kh[i] * W + k % CW) * Cout + cb) * ESZ;           // relative to pixel (h0, w0)
+        d_dst0[i] = qoff * (unsigned)G::YPL + (unsigned)k * 64u + qbyte;
+    }
     auto load_rows = [&](int img, int first_row, int w0) {       // CH input rows [first_row, first_row+CH), PW columns
-        const long ibase = (long)img * H * W;
+        const char* xb = reinterpret_cast<const char*>(x) + (size_t)img * H * W * Cin * ESZ;     // wave-uniform image base
+        const int roff = ((first_row * W + w0 - 1) * Cin) * (int)ESZ;                           // may be negative (halo rows)
         xok = 0;
 #pragma unroll
         for (int i = 0; i < XITEMS; ++i) {
-            const int pp = (tid + 256 * i) >> QSH;
-            const int pr = pp / PW, pc = pp - pr * PW;
-            const int h = first_row + pr, w = w0 - 1 + pc;
-            const unsigned ok = (unsigned)(pp < CH * PW) & (unsigned)((unsigned)h < (unsigned)H) &
-                                (unsigned)((unsigned)w < (unsigned)W);
+            const unsigned ok = ((x_ex >> i) & 1u) & (unsigned)((unsigned)(first_row + x_pr[i]) < (unsigned)H) &
+                                (unsigned)((unsigned)(w0 - 1 + x_pc[i]) < (unsigned)W);
             xok |= ok << i;
-            const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rx[i] = *reinterpret_cast<const u32x4*>(x + pix * Cin + ca);
+            const unsigned off = ok ? (unsigned)(roff + (int)x_rel[i]) : (unsigned)ca * ESZ;
+            rx[i] = *reinterpret_cast<const u32x4*>(xb + off);
         }
     };
     auto store_rows = [&](int first_row, int last_wanted) {      // rows > last_wanted are not stored (priming overshoot)
+        const int slot_first = (first_row + 4 * R) % R;          // wave-uniform
 #pragma unroll
         for (int i = 0; i < XITEMS; ++i) {
-            const int pp = (tid + 256 * i) >> QSH;
-            if (pp >= CH * PW) continue;
-            const int pr = pp / PW, pc = pp - pr * PW;
-            const int row = first_row + pr;
+            if (!((x_ex >> i) & 1u)) continue;
+            const int row = first_row + x_pr[i];
             if (row > last_wanted) continue;
-            const int slot = (row + 4 * R) % R;
+            int slot = slot_first + x_pr[i];
+            slot = slot >= R ? slot - R : slot;
             const bool valid = (xok >> i) & 1u;
-            unsigned char* dst = Xs + qoff * G::XPL + (slot * PW + pc) * 64 + qbyte;
+            unsigned char* dst = Xs + x_dst0[i] + (unsigned)slot * (unsigned)(PW * 64);
             if constexpr (HS16) {
                 u32x4 o = rx[i];
                 if (PRO != 0) {
@@ -679,24 +701,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
         }
     };
     auto load_dy = [&](int img, int h0, int w0) {
-        const long ibase = (long)img * H * W;
+        const char* db = reinterpret_cast<const char*>(dy) + (size_t)img * H * W * Cout * ESZ;
+        const unsigned roff = (unsigned)((h0 * W + w0) * Cout) * ESZ;
         dok = 0;
 #pragma unroll
         for (int i = 0; i < DITEMS; ++i) {
-            const int k = (tid + 256 * i) >> QSH;
-            const int h = h0 + k / CW, w = w0 + k % CW;
-            const unsigned ok = (unsigned)(h < H);
+            const unsigned ok = (unsigned)(h0 + d_kh[i] < H);
             dok |= ok << i;
-            const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rd[i] = *reinterpret_cast<const u32x4*>(dy + pix * Cout + cb);
+            rd[i] = *reinterpret_cast<const u32x4*>(db + (ok ? roff + d_rel[i] : (unsigned)cb * ESZ));
         }
     };
     auto store_dy = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < DITEMS; ++i) {
-            const int k = (tid + 256 * i) >> QSH;
             const bool valid = (dok >> i) & 1u;
-            unsigned char* dst = Ys + buf * G::YBYTES + qoff * G::YPL + k * 64 + qbyte;
+            unsigned char* dst = Ys + buf * G::YBYTES + d_dst0[i];
             if constexpr (HS16) {
                 *reinterpret_cast<u32x4*>(dst) = valid ? rd[i] : (u32x4){0u, 0u, 0u, 0u};
             } else {
@@ -839,6 +858,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
     };
 
     auto fresh = [&](int c) { int i_, h_, w_; origin(c, i_, h_, w_); return h_ == 0; };   // first chunk of a strip
+#ifdef TAG_X3_PROF   // 0 prologue, 1 store next chunk + issue loads, 2 MFMA chunk, 3 barrier, 4 new-strip rebuild, 5 epilogue
+    unsigned long long xpc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xp0 = __builtin_amdgcn_s_memtime();
+#endif
     if (cbeg < cend) {
         window_set(cbeg);
         prime(cbeg);
@@ -847,15 +869,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
         __syncthreads();
         if (cbeg + 1 < cend && !fresh(cbeg + 1)) issue_chunk(cbeg + 1);
     }
+    XP_MARK(0)
     for (int c = cbeg; c < cend; ++c) {
         const bool next = c + 1 < cend;
         const bool next_fresh = next && fresh(c + 1);
         if (next && !next_fresh) {
+#ifdef TAG_X3_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // profile build only: separates the wait for the loads from the stores
+            XP_MARK(6)
+#endif
             store_chunk(c + 1);                                   // into ring slots / dy buffer chunk c does not read
+            XP_MARK(7)
             if (c + 2 < cend && !fresh(c + 2)) issue_chunk(c + 2);
         }
+        XP_MARK(1)
         mma_chunk(c);
+        XP_MARK(2)
         __syncthreads();
+        XP_MARK(3)
         if (next_fresh) {                                         // new strip: rebuild the ring (rare)
             prime(c + 1);
             issue_chunk(c + 1);
@@ -864,6 +895,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
             if (c + 2 < cend && !fresh(c + 2)) issue_chunk(c + 2);
         }
         window_advance();
+        XP_MARK(4)
     }
     // partial[split][tap][ci][co]
 #pragma unroll
@@ -876,6 +908,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
             out[(size_t)ci * Cout + co] = acc[t][r];
         }
     }
+#ifdef TAG_X3_PROF
+    XP_MARK(5)
+    if (blockIdx.x == 300 && tid == 0) { for (int i = 0; i < 8; ++i) tag_x3_prof[i] = xpc[i]; tag_x3_prof[8] = (unsigned long long)(cend - cbeg); }
+#endif
 }
 
 // products per fp32 multiply: 6 (default), 9 (every partial product), 1 (plain bf16, hi plane rounded to nearest);

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 // -DTAG_HALO_PROF (tools/run_halo_prof.sh, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
 #ifdef TAG_HALO_PROF
 __device__ unsigned long long tag_halo_prof[8];
+__device__ unsigned long long tag_halo_sub[4];        // (written by every workgroup: the last writer wins -- a sample)
 #define HP_MARK(i) { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); hpc[i] += p1_ - hp0; hp0 = p1_; }
 #else
 #define HP_MARK(i)
@@ -427,9 +428,19 @@ __global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_ke
 #endif
     issue_patch(0);
     issue_b(0);
+#ifdef TAG_HALO_PROF
+    { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[0] = p1_ - hp0; }
+#endif
     __syncthreads();                           // Ss visible
+#ifdef TAG_HALO_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[1] = p1_ - hp0; }
+#endif
     store_patch(0);
     store_b(0);
+#ifdef TAG_HALO_PROF
+    { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[2] = p1_ - hp0; }
+#endif
     __syncthreads();
     HP_MARK(0)
     for (int it = 0; it < total; ++it) {
@@ -1849,5 +1860,8 @@ extern "C" int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_sca
 }
 
 #ifdef TAG_HALO_PROF
-extern "C" int tag_debug_get_halo_prof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_prof), 56) == hipSuccess ? 0 : -1; }
+extern "C" int tag_debug_get_halo_prof(unsigned long long* out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_prof), 56) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out + 7, HIP_SYMBOL(tag_halo_sub), 24) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -16,9 +16,10 @@ for (H, W, Cin, Cout) in [(1001, 64, 64, 64), (500, 32, 128, 128), (250, 16, 256
     for _ in range(2):
         ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=True)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     L.tag_debug_get_halo_prof(buf)
     names = ["prologue", "MFMA taps", "barrier", "operand stores", "barrier", "output stores", "statistics"]
     v = list(buf)[:7]
     tot = sum(v)
+    print(f"   prologue of a sampled workgroup: loads issued at {buf[7]}, barrier + loads landed at {buf[8]}, operands stored at {buf[9]} clk")
     print(f"{H}x{W} {Cin}->{Cout}: total {tot} clk  " + "  ".join(f"{n} {x_} ({100 * x_ / tot:.0f}%)" for n, x_ in zip(names, v)))

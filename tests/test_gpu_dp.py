@@ -42,6 +42,29 @@ def test_bench_launches_its_own_ranks(extra):
     assert out["n_gpus"] == 2 and out["ranks_observed"] == 2 and out["config"]["global_batch"] == 16
     assert out["value"] > 0 and out["scaling"] == "weak" and out["comm"]["overlap"] is True
     assert len(out["comm"]["buckets_MB"]) >= 3
+    # the self-diagnosing fields of the comm block (round 3): per-bucket durations / exposed time (events exist only on the
+    # RCCL path: None under gloo) and the collectives timed alone for both payload types
+    comm = out["comm"]
+    assert {"bucket_ms_in_step", "exposed_ms_per_step", "comm_only", "payload"} <= set(comm)
+    assert comm["payload"] == ("bf16" if extra else "fp32")
+    for kind in ("fp32", "bf16"):
+        leg = comm["comm_only"][kind]
+        assert leg["ms_per_step"] > 0 and len(leg["bucket_ms"]) == len(comm["buckets_MB"]) and leg["payload_MB"] > 0
+    assert abs(comm["comm_only"]["fp32"]["payload_MB"] - 2 * comm["comm_only"]["bf16"]["payload_MB"]) < 0.1
+
+
+def test_bench_comm_only_leg():
+    """`python bench.py --gpus 2 --comm-only` times nothing but the gradient buckets' all-reduces and prints one JSON line."""
+    env = dict(os.environ, TAG_DIST_BACKEND="gloo", TAG_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm-only"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and set(out["comm_only"]) == {"fp32", "bf16"} and len(out["buckets_MB"]) >= 3
 
 
 def _worker(rank, world, port, out):

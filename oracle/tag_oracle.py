@@ -304,6 +304,57 @@ def cnn8rnn_forward(st, waveform, waveform_len, training=False, p_drop=(0.2, 0.5
     return {"embedding": x, "length": length}
 
 
+# --------------------------------------------------------------------------
+# BASELINE configs[2] as this build realises it ("bf16 mode"): NOT a reference path -- the reference is
+# fp32 everywhere -- but the SAME forward arithmetic with the mode's rounding points made explicit, so that the HIP bf16 path
+# can be held to "bf16 rounding at exactly these places and nothing else" instead of a loose budget against the fp64 oracle:
+#   * raw conv outputs and pooled activations are STORED as bf16 (round-to-nearest-even of the fp32 accumulator / pool value);
+#   * BatchNorm batch statistics come from the accumulators BEFORE that rounding; the affine is applied to the stored value;
+#   * the operand a 3x3 conv multiplies is bf16: relu(bn(y)) is rounded once more when a BN+ReLU prologue feeds a conv, conv
+#     weights are rounded to bf16 (the Cin = 1 conv runs on fp32 VALU: neither its input nor its weights are rounded);
+#   * fc1 and the GRU input projection round both GEMM operands to bf16 and accumulate in fp32; the recurrence, the heads and
+#     the loss are fp32.
+# Evaluate in float64 so that the only differences from the device are its fp32 accumulation order and rounding ties.
+# --------------------------------------------------------------------------
+def _q_bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _bn_affine(y, st, prefix, training, eps=1e-5):
+    """(scale, shift) of BatchNorm2d over an NCHW tensor: batch statistics (biased variance) or the running ones."""
+    if training:                                   # (y may be None when the running statistics are asked for)
+        mean, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+    else:
+        mean, var = st[prefix + "running_mean"], st[prefix + "running_var"]
+    scale = st[prefix + "weight"] / torch.sqrt(var + eps)
+    return scale.view(1, -1, 1, 1), (st[prefix + "bias"] - mean * scale).view(1, -1, 1, 1)
+
+
+def cnn8rnn_forward_bf16_mode(st, waveform, waveform_len, training=False, prefix="audio_encoder."):
+    """The Cnn8Rnn forward with the bf16 mode's storage / operand roundings (dropout off); same contract as cnn8rnn_forward."""
+    x = logmel(waveform, "cnn8rnn").transpose(1, 2).unsqueeze(1)      # (B, 1, F, 64)
+    s0, t0 = _bn_affine(x.transpose(1, 3), st, prefix + "bn0.", training)
+    x = (x.transpose(1, 3) * s0 + t0).transpose(1, 3)                  # bn0 over the mel axis, fp32 on the device
+    pools = [(2, 2), (2, 2), (1, 2), (1, 2)]
+    for i, ps in enumerate(pools, start=1):
+        bp = f"{prefix}conv_block{i}."
+        w1, w2 = st[bp + "conv1.weight"], st[bp + "conv2.weight"]
+        y1f = F.conv2d(x, w1 if i == 1 else _q_bf16(w1), None, 1, 1)   # block 1: fp32 VALU conv of the fp32 log-mel
+        s1, t1 = _bn_affine(y1f, st, bp + "bn1.", training)
+        a1 = _q_bf16(F.relu(_q_bf16(y1f) * s1 + t1))                    # stored bf16 -> affine + ReLU -> bf16 operand
+        y2f = F.conv2d(a1, _q_bf16(w2), None, 1, 1)
+        s2, t2 = _bn_affine(y2f, st, bp + "bn2.", training)
+        a2 = F.relu(_q_bf16(y2f) * s2 + t2)                             # the pool reads the stored value; no operand rounding
+        x = _q_bf16(F.avg_pool2d(a2, kernel_size=ps) + F.max_pool2d(a2, kernel_size=ps))
+    x = torch.mean(x, dim=3).transpose(1, 2)                           # (B, T', 512), fp32 on the device
+    x = F.relu(F.linear(_q_bf16(x), _q_bf16(st[prefix + "fc1.weight"]), st[prefix + "fc1.bias"]))
+    gst = dict(st)
+    for sfx in ("", "_reverse"):
+        gst[prefix + "rnn.weight_ih_l0" + sfx] = _q_bf16(st[prefix + "rnn.weight_ih_l0" + sfx])
+    x = gru_bidir(_q_bf16(x), gst, prefix + "rnn.")
+    return {"embedding": x, "length": output_length(waveform_len, FRONTEND["cnn8rnn"]["hop_length"])}
+
+
 def gru_bidir(x, st, prefix):
     """nn.GRU(512, 256, bidirectional=True, batch_first=True), h0 = 0, all T' steps (row A4)."""
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]

@@ -546,6 +546,95 @@ def test_bf16_mode_train_step_budget(dev, golden_dir, monkeypatch):
     assert not bad, bad
 
 
+def test_bf16_mode_stages_match_rounding_point_emulation(dev, monkeypatch):
+    """The bf16 mode held to MORE than a budget against fp64 (round-2 review: "no check that the bf16 path equals the fp32 path
+    run on bf16-rounded tensors layer by layer").  The oracle restates the mode's rounding points (O.cnn8rnn_forward_bf16_mode:
+    bf16 storage of raw conv outputs and pooled activations, bf16 conv / GEMM operands, fp32 accumulation and everything else);
+    here EVERY stage of the eval-mode encoder is run on the device and compared with that restatement evaluated in float64 ON
+    THE DEVICE'S OWN INPUT of the stage, so that what remains is fp32 accumulation order and rounding ties: mean error <= 1e-6
+    of the stage's range (measured <= 1.3e-7) and <= 5e-4 of the elements off by more than one bf16 ulp (measured <= 5e-5).  (End to end the same ties amplify
+    chaotically through eight layers -- 15 % of block 4's elements differ by a bf16 ulp -- which is why the whole-path bf16
+    tests are budgets; a dropped or extra rounding point shows up HERE as a whole-tensor ulp-level error.)"""
+    import torch.nn.functional as F
+    from texttoaudiogrounding_amd import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    monkeypatch.setattr(ops, "ACT_DTYPE", "bf16")
+    st = O.init_state(seed=13, logit_gain=30.0)
+    batch = O.synthetic_batch(4, 64000, seed=21, ragged=True)
+    model = build_hip_model(st, "dot", dev).eval()
+    mod = model.audio_encoder
+    s64 = O.state_to(st, torch.float64)
+    q, P = O._q_bf16, "audio_encoder."
+    worst = {"mean": 0.0, "frac": 0.0}
+
+    def check(name, dev_t, ref, nchw=True):
+        d = dev_t.double().cpu()
+        r = ref.permute(0, 2, 3, 1) if (nchw and ref.dim() == 4) else ref
+        e = (d - r).abs()
+        rng = r.abs().max().item()
+        mean, frac = e.mean().item() / rng, (e > r.abs() * 2.0 ** -7 + 1e-6 * rng).double().mean().item()
+        print(f"  {name:26s} mean err / range {mean:.1e}   elements off by > 1 bf16 ulp {frac:.1e}")
+        worst["mean"], worst["frac"] = max(worst["mean"], mean), max(worst["frac"], frac)
+        assert mean <= 1e-6 and frac <= 5e-4, (name, mean, frac)
+
+    def nchw(t):
+        return t.double().cpu().permute(0, 3, 1, 2)
+
+    bn = lambda y, m: ops.bn_stats(y.view(-1, y.shape[-1]), m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, False,
+                                   m.eps, m.momentum)
+    with torch.no_grad():
+        lm = ops.logmel(batch["waveform"].to(dev), mod.n_fft, mod.win_length, mod.hop_length, mod.window, mod.mel_fb)
+        st0 = bn(lm, mod.bn0)
+        x_dev, x_in = None, lm.double().cpu().unsqueeze(1)                      # (B,1,F,64) = the device's own log-mel
+        s0, t0 = O._bn_affine(x_in.transpose(1, 3), s64, P + "bn0.", False)
+        x_in = (x_in.transpose(1, 3) * s0 + t0).transpose(1, 3)
+        for i, ps in enumerate([(2, 2), (2, 2), (1, 2), (1, 2)], start=1):
+            blk, bp = getattr(mod, f"conv_block{i}"), f"{P}conv_block{i}."
+            w1, w2 = s64[bp + "conv1.weight"], s64[bp + "conv2.weight"]
+            if i == 1:
+                y1, _ = ops.conv3x3_c1_stats(lm, blk.conv1.weight.detach(), st0.scale, st0.shift, want_stats=False,
+                                             out_dtype=torch.bfloat16)
+            else:
+                wf, _ = ops.pack_conv_weight(blk.conv1.weight.detach(), want_dgrad=False, W=x_dev.shape[2])
+                y1, _ = ops.conv3x3_stats(x_dev, wf, blk.conv1.weight.shape[0], want_stats=False)
+            assert y1.dtype == torch.bfloat16
+            check(f"block{i}.conv1", y1, q(F.conv2d(x_in, w1 if i == 1 else q(w1), None, 1, 1)))
+            s1 = bn(y1, blk.bn1)
+            r1s, r1t = O._bn_affine(None, s64, bp + "bn1.", False)
+            wf2, _ = ops.pack_conv_weight(blk.conv2.weight.detach(), want_dgrad=False, W=y1.shape[2])
+            y2, _ = ops.conv3x3_stats(y1, wf2, y1.shape[3], prologue=1, scale=s1.scale, shift=s1.shift, want_stats=False)
+            check(f"block{i}.conv2 (BN+ReLU fed)", y2, q(F.conv2d(q(F.relu(nchw(y1) * r1s + r1t)), q(w2), None, 1, 1)))
+            s2 = bn(y2, blk.bn2)
+            r2s, r2t = O._bn_affine(None, s64, bp + "bn2.", False)
+            x_dev = ops.bnact_pool(y2, s2, ps[0], ps[1], act=1, pool=0)
+            a2 = F.relu(nchw(y2) * r2s + r2t)
+            check(f"block{i}.pool", x_dev, q(F.avg_pool2d(a2, kernel_size=ps) + F.max_pool2d(a2, kernel_size=ps)))
+            x_in = nchw(x_dev)
+        B_, Tp, Wp, C = x_dev.shape
+        xm = torch.empty(B_ * Tp, C, device=dev)
+        ops.call("tag_mean_w_forward_bf16", ops.ptr(x_dev), B_ * Tp, Wp, C, 0.0, 0, ops.ptr(xm))
+        check("mean over mel", xm.view(B_, Tp, C), x_in.mean(dim=3).transpose(1, 2), nchw=False)
+        fw, fb = mod.fc1.weight.detach(), mod.fc1.bias.detach()
+        fc = ops.gemm(xm, fw, B_ * Tp, fw.shape[0], C, transB=True, bias=fb, act=1)
+        fc_ref = F.relu(F.linear(q(xm.double().cpu()), q(s64[P + "fc1.weight"]), s64[P + "fc1.bias"]))
+        check("fc1 (bf16 operands)", fc, fc_ref, nchw=False)
+        w_ih = torch.cat([mod.rnn.weight_ih_l0.detach(), mod.rnn.weight_ih_l0_reverse.detach()], 0)
+        b_ih = torch.cat([mod.rnn.bias_ih_l0.detach(), mod.rnn.bias_ih_l0_reverse.detach()], 0)
+        gi = ops.gemm(fc, w_ih, B_ * Tp, w_ih.shape[0], fc.shape[1], transB=True, bias=b_ih)
+        gi_ref = F.linear(q(fc.double().cpu()), q(w_ih.double().cpu()), b_ih.double().cpu())
+        check("GRU input projection", gi, gi_ref, nchw=False)
+        # whole encoder, for the record: the ties above amplify through the layers
+        inp = {k: (v.clone().to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        inp["specaug"] = False
+        emb = mod(inp)["embedding"].double().cpu()
+    emu = O.cnn8rnn_forward_bf16_mode(dict(s64), batch["waveform"].double(), batch["waveform_len"], training=False)["embedding"]
+    ref = O.cnn8rnn_forward(dict(O.state_to(st, torch.float64)), batch["waveform"].double(), batch["waveform_len"], training=False)["embedding"]
+    m_emu, m_ref = (emb - emu).abs().mean().item(), (emb - ref).abs().mean().item()
+    print(f"bf16 mode, per stage: worst mean err / range {worst['mean']:.1e}, worst > 1 ulp fraction {worst['frac']:.1e}; whole encoder: "
+          f"embedding mean |err| {m_emu:.1e} vs the emulation, {m_ref:.1e} vs the plain fp64 oracle")
+    assert m_emu < m_ref and m_emu < 2e-3
+
+
 @pytest.mark.parametrize("B,S", [(1, 4000), (3, 9999), (2, 32000)])
 def test_edge_shapes_train_step(dev, B, S):
     """Edge cases of the path: a single clip, clips of a few frames (T' = 3), odd sample counts, one-token phrases:

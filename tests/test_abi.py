@@ -125,3 +125,13 @@ def test_host_resident_token_ids_out_of_range_raise_at_once():
         enc({"text": torch.tensor([[1, 2, 50]]), "text_len": torch.tensor([3])})
     with pytest.raises(IndexError, match="out of range"):
         enc({"text": torch.tensor([[1, -1, 3]]), "text_len": torch.tensor([3])})
+
+
+def test_pass_size_limit_is_reported_before_any_launch():
+    """A training batch beyond the conv kernels' 32-bit activation offsets raises a RuntimeError that names the limit (round-2
+    review: it used to surface as TAG_EINVAL from the first conv): 10 s clips -> 261 per pass in fp32, 30 s clips -> 87."""
+    from texttoaudiogrounding_amd import ops
+    assert ops.max_clips_per_pass(1001) == 261 and ops.max_clips_per_pass(3001) == 87
+    ops.check_pass_size(64, 3001)
+    with pytest.raises(RuntimeError, match="at most 261 clips"):
+        ops.check_pass_size(262, 1001)

@@ -192,7 +192,7 @@ class Cnn8RnnLaionClapGroundingModel(nn.Module):
         # batches are processed in passes: the conv kernels index activations with 32-bit byte offsets
         # (B * F * 64 * 64 * 4 B < 4 GiB) and the persistent GRU holds <= 128 sequences per launch
         frames = audio.shape[1] // self.model.audio_encoder.hop_length + 1
-        per_pass = max(1, min(self.max_clips_per_pass, (2 ** 32 - 1) // (frames * 64 * 64 * 4)))
+        per_pass = max(1, min(self.max_clips_per_pass, ops.max_clips_per_pass(frames)))
         for b0 in range(0, B, per_pass):
             sl = slice(b0, min(B, b0 + per_pass))
             d = {"waveform": audio[sl], "waveform_len": audio_len[sl], "input_ids": ids[sl], "attention_mask": mask[sl],

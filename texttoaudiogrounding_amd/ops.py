@@ -668,6 +668,25 @@ def bump_bn_counters(owner, bns):
     flat += 1
 
 
+def max_clips_per_pass(frames: int) -> int:
+    """Largest batch the conv kernels take in one launch: activations are indexed with 32-bit BYTE offsets, and the largest
+    tensor is the first block's (B, frames, 64 mel, 64 channels) -- fp32, or bf16 in the bf16-storage mode."""
+    esz = 2 if act_bf16() else 4
+    return max(1, (2 ** 32 - 1) // (int(frames) * 64 * 64 * esz))
+
+
+def check_pass_size(B: int, frames: int):
+    """Loud and early instead of TAG_EINVAL from the first conv: a training batch beyond the 32-bit offset range must be split by
+    the CALLER (train-mode BatchNorm statistics are per forward pass, so the split is not invisible; the inference wrapper
+    models/hf_modeling_grounding.py does split -- eval-mode BatchNorm makes its passes independent)."""
+    lim = max_clips_per_pass(frames)
+    if B > lim:
+        raise RuntimeError(f"batch of {B} clips x {frames} frames exceeds the conv kernels' 32-bit activation offsets: at most {lim} "
+                           f"clips of this length per forward pass ({'bf16' if act_bf16() else 'fp32'} storage). Split the batch "
+                           "(gradient accumulation over sub-batches; note that train-mode BatchNorm statistics are then per "
+                           "sub-batch, as they would be with a smaller batch in the reference)")
+
+
 def gru_bidir_forward(x2d, rnn, B, T, need_grad):
     """x2d (B*T, I); rnn = [w_ih, w_hh, b_ih, b_hh] x (forward, reverse).  Returns y (B,T,2H) and the saved state."""
     Hh = rnn[1].shape[1]
@@ -792,6 +811,7 @@ class Cnn8RnnFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, waveform, mod, *params):
         wave = _chk(waveform, "waveform")
+        check_pass_size(wave.shape[0], wave.shape[1] // mod.hop_length + 1)
         training = mod.training
         bn_train = training and not mod.freeze_bn
         p = [_chk(t.detach(), "parameter") for t in params]

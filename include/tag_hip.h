@@ -173,6 +173,16 @@ size_t tag_conv3x3_c1_backward_ws_bytes(int B, int H, int W, int Cout);
 int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float* col_shift, const float* dy,
                             const float* w /*(Cout,1,3,3)*/, float* dw /*(Cout,1,3,3)*/, float* dx /*(B,H,W)*/,
                             int B, int H, int W, int Cout, void* ws, void* stream);
+/* The same pass fed the RAW dgrad output of block 1's second conv: `da` = dL/d relu(bn1(yref)), and the backward of that
+ * BatchNorm + ReLU (models/panns.py:46-48, x = F.relu_(self.bn1(self.conv1(x)))) is applied as the values are loaded --
+ * dy = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N), dz = da where bn1(yref) > 0, N = B*H*W (bn_train = 0: the two
+ * mean terms are dropped) -- instead of in a separate tag_bnrelu_backward_apply pass over the largest activation.
+ * dgamma / dbeta are INPUTS here: sum(dz * xhat) / sum(dz), as tag_bn_grad_from_partials leaves them. */
+int tag_conv3x3_c1_backward_bnrelu(const float* x, const float* col_scale, const float* col_shift, const float* da,
+                                   const float* yref, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                   const float* bn_invstd, const float* gamma, const float* dgamma, const float* dbeta,
+                                   int bn_train, const float* w, float* dw, float* dx, int B, int H, int W, int Cout,
+                                   void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1 + A2: relu(bn(y)) -> avg_pool + max_pool (kernel = stride = (ph,pw), floor) -> dropout
@@ -494,6 +504,11 @@ int tag_conv3x3_c1_forward_stats_bf16(const float* x, const float* col_scale, co
 int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_scale, const float* col_shift, const void* dy,
                                  const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
                                  void* stream);
+int tag_conv3x3_c1_backward_bnrelu_bf16(const float* x, const float* col_scale, const float* col_shift, const void* da,
+                                        const void* yref, const float* bn_scale, const float* bn_shift,
+                                        const float* bn_mean, const float* bn_invstd, const float* gamma,
+                                        const float* dgamma, const float* dbeta, int bn_train, const float* w, float* dw,
+                                        float* dx, int B, int H, int W, int Cout, void* ws, void* stream);
 int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int prologue, const float* in_scale,
                                 const float* in_shift, void* y, float* stats, int B, int H, int W, int Cin, int Cout,
                                 void* stream);

@@ -419,6 +419,38 @@ def test_conv3x3_c1(ops, dev, B, H):
     assert relerr(dw2, wd.grad) < 2e-6 and relerr(dx2, xin.grad[:, 0]) < 2e-6
 
 
+@pytest.mark.parametrize("train", [True, False], ids=["train_bn", "eval_bn"])
+@pytest.mark.parametrize("B,H", [(2, 21), (3, 1001), (5, 8)])
+def test_conv3x3_c1_backward_with_fused_bnrelu_backward(ops, dev, B, H, train):
+    """tag_conv3x3_c1_backward_bnrelu (bn1's backward applied while da is loaded) == tag_bnrelu_backward followed by
+    tag_conv3x3_c1_backward: bit for bit in fp32 (same arithmetic, same order); with bf16 storage the fused pass skips the
+    bf16 rounding of dy, so it is compared with the fp32 result of the same bf16-valued inputs (also bit for bit) and with
+    the two-pass bf16 result within that one rounding.  Rows at the strip and image borders included (H = 8: one strip)."""
+    g = torch.Generator().manual_seed(100 * B + H)
+    W, C = 64, 64
+    x = (torch.randn(B, H, W, generator=g) * 10 - 30).to(dev)
+    cs, ct = (torch.rand(W, generator=g) * 0.1 + 0.05).to(dev), torch.randn(W, generator=g).to(dev)
+    w = (torch.randn(C, 1, 3, 3, generator=g) / 3).to(dev)
+    y = bf(torch.randn(B, H, W, C, generator=g) * 2 + 0.5).to(dev)
+    da = bf(torch.randn(B, H, W, C, generator=g)).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    rm, rv = torch.zeros(C, device=dev) + 0.4, torch.ones(C, device=dev) * 3.0
+    st = ops.bn_stats(y.float().view(-1, C), gamma, beta, rm, rv, train, 1e-5, 0.1)
+    dy, dg, db = ops.bnrelu_backward(y.float(), st, gamma, da.float(), inplace=False)
+    dw_ref, dx_ref = ops.conv3x3_c1_backward(x, dy, w, cs, ct)
+    dw, dx = ops.conv3x3_c1_backward(x, da.float(), w, cs, ct, bn_bwd=(y.float(), st, gamma, dg, db))
+    assert torch.equal(dw, dw_ref) and torch.equal(dx, dx_ref)
+    dw16, dx16 = ops.conv3x3_c1_backward(x, da, w, cs, ct, bn_bwd=(y, st, gamma, dg, db))
+    assert torch.equal(dw16, dw_ref) and torch.equal(dx16, dx_ref)
+    dy16, dg16, db16 = ops.bnrelu_backward(y, st, gamma, da, inplace=False)
+    dw2, dx2 = ops.conv3x3_c1_backward(x, dy16, w, cs, ct)
+    # dy rounded to bf16 (relative 2^-9 per value) against an input of mean / std = 3: a few 1e-2 of max|dw| at most
+    assert relerr(dw2, dw_ref) < 5e-2 and relerr(dx2, dx_ref) < 1e-2
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_c1_backward(x, da, w, cs, ct, bn_bwd=(y.float(), st, gamma, dg, db))
+    ops.check_async_errors()
+
+
 @pytest.mark.parametrize("B,H", [(2, 21), (3, 1001), (64, 37)])
 def test_conv3x3_c1_fused_bn_stats(ops, dev, B, H):
     """The Cin = 1 forward kernel writes the BatchNorm partial statistics of its own output (no second pass over the

@@ -1153,17 +1153,26 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 }
 __global__ __launch_bounds__(256) void conv_c1_wgrad_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                                     int n, float* __restrict__ dw) {
-    // 16 outputs x 16 interleaved parts per block, folded through LDS in a fixed order
-    __shared__ double sh[16][17];
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-    double s = 0;
-    if (i < n)
-        for (int b = part; b < nblk; b += 16) s += partials[(size_t)b * n + i];
-    sh[part][threadIdx.x & 15] = s;
+    // 8 outputs x 32 interleaved parts per block (four independent chains per part keep the loads in flight), folded
+    // through LDS in a fixed order
+    __shared__ double sh[32][9];
+    const int i = blockIdx.x * 8 + (threadIdx.x & 7), part = threadIdx.x >> 3;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (i < n) {
+        int b = part;
+        for (; b + 96 < nblk; b += 128) {
+            s0 += partials[(size_t)b * n + i];
+            s1 += partials[(size_t)(b + 32) * n + i];
+            s2 += partials[(size_t)(b + 64) * n + i];
+            s3 += partials[(size_t)(b + 96) * n + i];
+        }
+        for (; b < nblk; b += 32) s0 += partials[(size_t)b * n + i];
+    }
+    sh[part][threadIdx.x & 7] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && i < n) {
         double t = 0;
-        for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x & 15];
+        for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x & 7];
         dw[i] = (float)t;
     }
 }
@@ -1305,12 +1314,20 @@ __device__ __forceinline__ float sum16(float v) {
     v = dpp_add<0x140>(v);       // row_mirror
     return v;
 }
-template <class TS>
+// FUSE: `dy` holds da = dL/d relu(bn1(yref)) (the raw dgrad output of block 1's second conv) and the backward of that
+// BatchNorm + ReLU is applied as the values arrive -- dy = k0 * (dz - k1 - xhat * k2), dz = da where bn1(yref) > 0, the
+// arithmetic of bnrelu_bwd_apply_kernel (bn_pool.hip) -- so the separate apply pass over the largest activation of the
+// network (read y, read da, write dy) is replaced by one extra read of y here.
+struct C1BnBwd {
+    const void* yref; const float* scale; const float* shift; const float* mean; const float* invstd;
+    const float* gamma; const float* dgamma; const float* dbeta; float invN; int bn_train;
+};
+template <class TS, bool FUSE>
 __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ cs,
                                                           const float* __restrict__ ct, const TS* __restrict__ dy,
                                                           const float* __restrict__ wgt, float* __restrict__ dx,
                                                           double* __restrict__ partials, int H, int strips,
-                                                          int rows_per_strip) {
+                                                          int rows_per_strip, C1BnBwd bb) {
     constexpr int W = 64, Cout = 64;
     __shared__ float Gs[4][C1B_GW][C1B_GT];
     __shared__ float Xs[4][C1B_GW];
@@ -1345,23 +1362,73 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
             Xs[(row + 8) & 3][tid] = v;
         }
     };
-    f32x4 g[4], gn[4];
-    auto load_dy = [&](int row, f32x4 (&dst)[4]) {
+    typedef ActN<TS, 4> AN;
+    typedef typename AN::raw_t raw_t;
+    constexpr int NY = FUSE ? 4 : 1;
+    f32x4 g[4];
+    raw_t gn[4], yn[NY];                    // the next row, in flight as loaded (converted / transformed in take())
+    // per-channel constants of the fused BatchNorm backward: in LDS and re-read after each row's barrier, so they do not
+    // hold 28 registers through the accumulation (3 workgroups per CU stay resident)
+    __shared__ float bnc[7][Cout];
+    const TS* yimg = nullptr;
+    if constexpr (FUSE) {
+        yimg = static_cast<const TS*>(bb.yref) + (size_t)img * H * W * Cout;
+        if (tid < Cout) {
+            const float is = bb.invstd[tid];
+            bnc[0][tid] = bb.scale[tid]; bnc[1][tid] = bb.shift[tid]; bnc[2][tid] = bb.mean[tid]; bnc[3][tid] = is;
+            bnc[4][tid] = bb.gamma[tid] * is;
+            bnc[5][tid] = bb.bn_train ? bb.dbeta[tid] * bb.invN : 0.0f;
+            bnc[6][tid] = bb.bn_train ? bb.dgamma[tid] * bb.invN : 0.0f;
+        }
+    }
+    auto load_dy = [&](int row) {
         const bool ok = (unsigned)row < (unsigned)H;
-        const TS* p = dimg + ((size_t)(ok ? row : 0) * W + wid * 16 + psub) * Cout + c;
+        const size_t off = ((size_t)(ok ? row : 0) * W + wid * 16 + psub) * Cout + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dst[i] = Act<TS>::ld4(p + (size_t)i * 4 * Cout);
-            if (!ok) dst[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            gn[i] = AN::ldraw(dimg + off + (size_t)i * 4 * Cout);
+            if constexpr (FUSE) yn[i] = AN::ldraw(yimg + off + (size_t)i * 4 * Cout);
+            else if (!ok) gn[i] = AN::zero();
+        }
+    };
+    auto take = [&](bool ok) {              // g <- the row in flight (FUSE: dy from da and yref; zero outside the image)
+        if constexpr (FUSE) {
+            float k[7][4];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&bnc[q][c]);
+                k[q][0] = v.x; k[q][1] = v.y; k[q][2] = v.z; k[q][3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float av[4], vv[4], o[4];
+                AN::unpack(gn[i], av);
+                AN::unpack(yn[i], vv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dz = fmaf(vv[j], k[0][j], k[1][j]) > 0.0f ? av[j] : 0.0f;
+                    o[j] = k[4][j] * (dz - k[5][j] - (vv[j] - k[2][j]) * k[3][j] * k[6][j]);
+                    if (!ok) o[j] = 0.0f;
+                }
+                g[i] = (f32x4){o[0], o[1], o[2], o[3]};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float av[4];
+                AN::unpack(gn[i], av);
+                g[i] = (f32x4){av[0], av[1], av[2], av[3]};
+            }
         }
     };
     stage_x(r0 - 1);
     stage_x(r0);
-    load_dy(r0 - 1, g);
+    load_dy(r0 - 1);
     __syncthreads();
+    take((unsigned)(r0 - 1) < (unsigned)H);
     for (int h = r0 - 1; h <= r1; ++h) {
         stage_x(h + 2 > r1 + 1 ? -1 : h + 2);                             // rows beyond r1+1 are never read
-        if (h < r1) load_dy(h + 1, gn);
+        if (h < r1) load_dy(h + 1);
         const bool own = h >= r0 && h < r1;
         const int gs = (h + 8) & 3;
 #pragma unroll
@@ -1400,8 +1467,7 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
                 sdx += Gs[(ho - (t / 3 - 1) + 8) & 3][tid + 1 - (t % 3 - 1)][t];
             dx[((size_t)img * H + ho) * W + tid] = sdx;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = gn[i];
+        if (h < r1) take((unsigned)(h + 1) < (unsigned)H);
     }
     // dw partial of this workgroup: fold the 4 pixel sub-lanes, then the 4 waves (fixed order), in fp64 across workgroups
 #pragma unroll
@@ -1795,7 +1861,7 @@ extern "C" int tag_conv3x3_c1_wgrad(const float* x, const float* col_scale, cons
         hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nblk), dim3(256), 4 * 64 * 36 * sizeof(double),
                            as_stream(stream), x, col_scale, col_shift, dy, partials, M, H, W, Cout);
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 8)), dim3(256), 0, as_stream(stream),
                        partials, nblk, Cout * 9, dw);
     TAG_LAUNCH_CHECK();
     return 0;
@@ -1828,39 +1894,61 @@ extern "C" size_t tag_conv3x3_c1_backward_ws_bytes(int B, int H, int W, int Cout
     c1_bwd_geom(B, H, &strips, &rows);
     return (size_t)B * strips * Cout * 9 * sizeof(double);
 }
-extern "C" int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float* col_shift, const float* dy,
-                                       const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
-                                       void* stream) {
+template <class TS>
+static int c1_backward_impl(const float* x, const float* col_scale, const float* col_shift, const TS* dy, const float* w,
+                            float* dw, float* dx, int B, int H, int W, int Cout, void* ws, void* stream, const C1BnBwd* bb) {
     TAG_CHECK_ARG(x && dy && w && dw && dx && ws && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 64 && Cout == 64);
     TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
     int strips, rows;
     c1_bwd_geom(B, H, &strips, &rows);
     double* partials = static_cast<double*>(ws);
-    hipLaunchKernelGGL(conv_c1_bwd_kernel<float>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift, dy,
-                       w, dx, partials, H, strips, rows);
+    if (bb) {
+        TAG_CHECK_ARG(bb->yref && bb->scale && bb->shift && bb->mean && bb->invstd && bb->gamma && bb->dgamma && bb->dbeta);
+        hipLaunchKernelGGL((conv_c1_bwd_kernel<TS, true>), dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
+                           col_shift, dy, w, dx, partials, H, strips, rows, *bb);
+    } else {
+        hipLaunchKernelGGL((conv_c1_bwd_kernel<TS, false>), dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale,
+                           col_shift, dy, w, dx, partials, H, strips, rows, C1BnBwd{});
+    }
     TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 8)), dim3(256), 0, as_stream(stream),
                        partials, B * strips, Cout * 9, dw);
     TAG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int tag_conv3x3_c1_backward(const float* x, const float* col_scale, const float* col_shift, const float* dy,
+                                       const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
+                                       void* stream) {
+    return c1_backward_impl<float>(x, col_scale, col_shift, dy, w, dw, dx, B, H, W, Cout, ws, stream, nullptr);
+}
 extern "C" int tag_conv3x3_c1_backward_bf16(const float* x, const float* col_scale, const float* col_shift, const void* dy,
                                             const float* w, float* dw, float* dx, int B, int H, int W, int Cout, void* ws,
                                             void* stream) {
-    TAG_CHECK_ARG(x && dy && w && dw && dx && ws && B > 0 && H > 0);
-    TAG_CHECK_ARG(W == 64 && Cout == 64);
-    TAG_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr));
-    int strips, rows;
-    c1_bwd_geom(B, H, &strips, &rows);
-    double* partials = static_cast<double*>(ws);
-    hipLaunchKernelGGL(conv_c1_bwd_kernel<bf16_t>, dim3(B * strips), dim3(256), 0, as_stream(stream), x, col_scale, col_shift,
-                       static_cast<const bf16_t*>(dy), w, dx, partials, H, strips, rows);
-    TAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(cdiv(Cout * 9, 16)), dim3(256), 0, as_stream(stream),
-                       partials, B * strips, Cout * 9, dw);
-    TAG_LAUNCH_CHECK();
-    return 0;
+    return c1_backward_impl<bf16_t>(x, col_scale, col_shift, static_cast<const bf16_t*>(dy), w, dw, dx, B, H, W, Cout, ws,
+                                    stream, nullptr);
+}
+// the same pass with the backward of relu(bn(yref)) applied to `da` on the fly (C1BnBwd above): dgamma / dbeta hold
+// sum(dz * xhat) / sum(dz) over all B*H*W rows, as tag_bn_grad_from_partials leaves them
+extern "C" int tag_conv3x3_c1_backward_bnrelu(const float* x, const float* col_scale, const float* col_shift, const float* da,
+                                              const float* yref, const float* bn_scale, const float* bn_shift,
+                                              const float* bn_mean, const float* bn_invstd, const float* gamma,
+                                              const float* dgamma, const float* dbeta, int bn_train, const float* w,
+                                              float* dw, float* dx, int B, int H, int W, int Cout, void* ws, void* stream) {
+    const C1BnBwd bb{yref, bn_scale, bn_shift, bn_mean, bn_invstd, gamma, dgamma, dbeta,
+                     1.0f / (float)((long)B * H * W), bn_train};
+    return c1_backward_impl<float>(x, col_scale, col_shift, da, w, dw, dx, B, H, W, Cout, ws, stream, &bb);
+}
+extern "C" int tag_conv3x3_c1_backward_bnrelu_bf16(const float* x, const float* col_scale, const float* col_shift,
+                                                   const void* da, const void* yref, const float* bn_scale,
+                                                   const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                                                   const float* gamma, const float* dgamma, const float* dbeta, int bn_train,
+                                                   const float* w, float* dw, float* dx, int B, int H, int W, int Cout,
+                                                   void* ws, void* stream) {
+    const C1BnBwd bb{yref, bn_scale, bn_shift, bn_mean, bn_invstd, gamma, dgamma, dbeta,
+                     1.0f / (float)((long)B * H * W), bn_train};
+    return c1_backward_impl<bf16_t>(x, col_scale, col_shift, static_cast<const bf16_t*>(da), w, dw, dx, B, H, W, Cout, ws,
+                                    stream, &bb);
 }
 
 #ifdef TAG_HALO_PROF

@@ -53,6 +53,7 @@ _SIGS = {
     "tag_conv3x3_c1_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_c1_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_c1_backward": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_c1_backward_bnrelu": (c_int, [P] * 12 + [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "tag_waveform_f16_to_f32_padded": (c_int, [P, P, c_int, c_int, P, P, P]),
     "tag_bnact_pool_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_float, c_uint64, P]),
@@ -110,6 +111,7 @@ _SIGS = {
     "tag_segments": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P]),
     "tag_conv3x3_c1_forward_stats_bf16": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_c1_backward_bf16": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "tag_conv3x3_c1_backward_bnrelu_bf16": (c_int, [P] * 12 + [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "tag_conv3x3_forward_x3_bf16": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_wgrad_x3_bf16": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "tag_bnact_pool_forward_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -335,12 +335,17 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
 
 #: BatchNorm-backward sums in the dgrad conv epilogue (tag_conv3x3_dgrad_bnsums) instead of a separate two-tensor pass
 FUSE_BN_BWD_SUMS = os.environ.get("TAG_FUSE_BN_BWD", "1") != "0"
+#: block 1: bn1's backward applied inside the Cin = 1 conv backward (tag_conv3x3_c1_backward_bnrelu) instead of a separate pass
+FUSE_C1_BN_BWD = os.environ.get("TAG_FUSE_C1_BN_BWD", "1") != "0"
 
 
-def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=None, db_out=None, after_conv=None):
+def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=None, db_out=None, after_conv=None,
+                                  defer_apply=False):
     """The dgrad convolution da = conv(dy_in, wpack) followed by the backward of relu(bn(yref)):
     returns (dy_ref, dgamma, dbeta) with dy_ref = dL/d yref (written in place over da).  Exact-fp32 halo-tile shapes
-    fold the per-channel sums into the conv epilogue; other shapes / arithmetics run the conv and tag_bnrelu_backward."""
+    fold the per-channel sums into the conv epilogue; other shapes / arithmetics run the conv and tag_bnrelu_backward.
+    defer_apply: a 4-tuple (t, dgamma, dbeta, applied) comes back; on the fused paths applied is False and t is still da --
+    the caller's next kernel applies the BatchNorm + ReLU backward itself (conv3x3_c1_backward(bn_bwd=...))."""
     B, H, W, Cin = dy_in.shape
     C = yref.shape[3]
     fused = (FUSE_BN_BWD_SUMS and wpack.dtype != torch.uint8 and st.train and W in (8, 16, 32, 64)
@@ -360,6 +365,8 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
         db = db_out if db_out is not None else _empty(C, like=da)
         ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), da)
         call("tag_bn_grad_from_partials", ptr(part), P, C, ptr(dg), ptr(db), ptr(ws))
+        if defer_apply:
+            return da, dg, db, False
         call("tag_bnrelu_backward_apply_bf16", ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
              ptr(gamma), ptr(da), ptr(da), ptr(dg), ptr(db), B * H * W, C, int(st.train))
         return da, dg, db
@@ -367,7 +374,8 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
         da = conv3x3(dy_in, wpack, C)
         if after_conv is not None:
             after_conv()
-        return bnrelu_backward(yref, st, gamma, da, dg_out=dg_out, db_out=db_out)
+        res = bnrelu_backward(yref, st, gamma, da, dg_out=dg_out, db_out=db_out)
+        return (*res, True) if defer_apply else res
     P = query("tag_conv3x3_stats_rows", B, H, W, C)
     da = _empty(B, H, W, C, like=dy_in)
     part = _empty(P * 2 * C, like=dy_in)
@@ -380,6 +388,8 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     db = db_out if db_out is not None else _empty(C, like=da)
     ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), da)
     call("tag_bn_grad_from_partials", ptr(part), P, C, ptr(dg), ptr(db), ptr(ws))
+    if defer_apply:
+        return da, dg, db, False
     rows = B * H * W
     call("tag_bnrelu_backward_apply", ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(da), ptr(da), ptr(dg), ptr(db), rows, C, int(st.train))
@@ -449,17 +459,32 @@ def conv3x3_c1_wgrad(x, dy, col_scale=None, col_shift=None):
     return dw
 
 
-def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None, out=None):
-    """(dw, dx) of the Cin = 1 convolution; one fused pass over dy when the shape allows (W == 64, Cout == 64)."""
+C1_BWD_FUSED_SHAPE = (64, 64)            # (mel bins, channels) the one-pass Cin = 1 backward is written for
+
+
+def conv3x3_c1_backward(x, dy, w, col_scale=None, col_shift=None, out=None, bn_bwd=None):
+    """(dw, dx) of the Cin = 1 convolution; one fused pass over dy when the shape allows (W == 64, Cout == 64).
+    bn_bwd = (yref, st, gamma, dgamma, dbeta): `dy` is da = dL/d relu(bn(yref)) and the BatchNorm + ReLU backward is applied
+    while it is loaded (tag_conv3x3_c1_backward_bnrelu; fused shape only)."""
     B, H, W = x.shape
     Cout = dy.shape[3]
-    if W == 64 and Cout == 64:
+    if (W, Cout) == C1_BWD_FUSED_SHAPE:
         dw = out if out is not None else _empty(Cout, 1, 3, 3, like=x)
         dx = _empty(B, H, W, like=x)
         ws = _ws(query("tag_conv3x3_c1_backward_ws_bytes", B, H, W, Cout), x)
+        if bn_bwd is not None:
+            yref, st, gamma, dg, db = bn_bwd
+            if yref.dtype != dy.dtype or yref.shape != dy.shape:
+                raise RuntimeError("conv3x3_c1_backward: yref and da must agree in dtype and shape")
+            call("tag_conv3x3_c1_backward_bnrelu" + _sfx(dy), ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(yref),
+                 ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma), ptr(dg), ptr(db), int(st.train),
+                 ptr(w), ptr(dw), ptr(dx), B, H, W, Cout, ptr(ws))
+            return dw, dx
         call("tag_conv3x3_c1_backward" + _sfx(dy), ptr(x), ptr(col_scale), ptr(col_shift), ptr(dy), ptr(w), ptr(dw), ptr(dx),
              B, H, W, Cout, ptr(ws))
         return dw, dx
+    if bn_bwd is not None:
+        raise RuntimeError("conv3x3_c1_backward: bn_bwd needs the fused 64 x 64 shape")
     if dy.dtype == BF16:
         raise RuntimeError("bf16 activations: the Cin = 1 backward is implemented for 64 mel bins x 64 channels")
     return conv3x3_c1_wgrad(x, dy, col_scale, col_shift), conv3x3_c1_dgrad(dy, w)
@@ -905,8 +930,12 @@ class Cnn8RnnFunction(torch.autograd.Function):
             _deliver(grads, sk, o + 5, db2)
             del dx
             _deliver(grads, sk, o + 3, sw.wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift, out=sk[o + 3]))
-            dy1, dg1, db1 = conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1, dg_out=sk[o + 1], db_out=sk[o + 2],
-                                                          after_conv=sw.release)
+            # block 1: its first conv has ONE consumer of dy1 (the Cin = 1 backward), which applies bn1's backward itself
+            defer = i == 0 and FUSE_C1_BN_BWD and (y1.shape[2], y1.shape[3]) == C1_BWD_FUSED_SHAPE
+            res = conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1, dg_out=sk[o + 1], db_out=sk[o + 2],
+                                                after_conv=sw.release, defer_apply=defer)
+            dy1, dg1, db1 = res[:3]
+            applied = res[3] if defer else True
             del dy2
             _deliver(grads, sk, o + 1, dg1)
             _deliver(grads, sk, o + 2, db1)
@@ -915,7 +944,8 @@ class Cnn8RnnFunction(torch.autograd.Function):
                 dx = conv3x3(dy1, wd1, x_in.shape[3])
                 sw.release()
             else:
-                dw0, dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift, out=sk[2])   # dbn0: (B,F,64) grad wrt bn0 output
+                dw0, dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift, out=sk[2],   # dbn0: (B,F,64) grad wrt bn0 output
+                                                bn_bwd=None if applied else (y1, s1, g1, dg1, db1))
                 _deliver(grads, sk, 2, dw0)
                 Bq, Fr, NM = lm.shape
                 dg0, db0 = bn_param_grad(lm.view(Bq * Fr, NM), dbn0.view(Bq * Fr, NM), st0, dg_out=sk[0], db_out=sk[1])

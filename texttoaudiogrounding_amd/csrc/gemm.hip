@@ -32,6 +32,8 @@ struct Stage {
     static constexpr int LD = KC ? T + 1 : T;
     static constexpr int NL = T / 32;       // float4 per thread per chunk
     f32x4 reg[NL];
+    // FAST: every tile and K chunk is whole and 16-byte aligned (checked by the launcher) -> plain float4 loads, no tail tests
+    template <bool FAST>
     __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -39,10 +41,12 @@ struct Stage {
             float4 v;
             if (KC) {
                 const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-                v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
+                if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)r * ld + k);
+                else v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
             } else {
                 const int k = k0 + idx / (T / 4), r = r0 + (idx % (T / 4)) * 4;
-                v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
+                if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)k * ld + r);
+                else v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
             }
             reg[i] = (f32x4){v.x, v.y, v.z, v.w};
         }
@@ -75,6 +79,7 @@ template <bool KC, int T>
 struct StageBF {
     static constexpr int NL = T / 32;
     f32x4 reg[NL];
+    template <bool FAST>
     __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -82,11 +87,13 @@ struct StageBF {
             if (KC) {
                 const int idx = threadIdx.x + 256 * i;
                 const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-                v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
+                if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)r * ld + k);
+                else v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
             } else {
                 const int idx2 = threadIdx.x + 256 * (i >> 1);
                 const int k = k0 + 2 * (idx2 / (T / 4)) + (i & 1), r = r0 + (idx2 % (T / 4)) * 4;
-                v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
+                if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)k * ld + r);
+                else v = (k < kmax) ? load4(base + (size_t)k * ld + r, rmax - r, al) : make_float4(0, 0, 0, 0);
             }
             reg[i] = (f32x4){v.x, v.y, v.z, v.w};
         }
@@ -139,7 +146,7 @@ typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
 // BF = false: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  BF = true (BASELINE configs[2] mode, tag_gemm_bf16): the same fp32
 // tensors and the same LDS image, but the fragments are rounded to bf16 (nearest-even) on their way from LDS to the registers
 // and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what autocast does to nn.Linear / the GRU projections.
-template <bool AKC, bool BKC, int T, bool BF = false>
+template <bool AKC, bool BKC, int T, bool BF = false, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                    Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
@@ -162,8 +169,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int wm0 = (wid >> 1) * (T / 2), wn0 = (wid & 1) * (T / 2);
     const int kl = lane >> 5, ml = lane & 31;
 
-    typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T>>::type sa;
-    typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T>>::type sb;
+    // PD register sets = PD K chunks requested ahead of the one being multiplied.  Measured at the step's shapes (B = 64,
+    // tools/gemm_bench.py): PD = 3 (64-tiles) / 2 (128-tiles) is 0-17 % SLOWER than PD = 1 -- the loop is bound by its
+    // per-chunk instruction and barrier overhead (TAG_GEMM_ABL), not by the latency of the loads -- so one chunk ahead stays.
+    constexpr int PD = 1;
+    typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T>>::type sa[PD];
+    typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T>>::type sb[PD];
     f32x16 acc[TT][TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -173,19 +184,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int kiters = (kend - kbeg + GK - 1) / GK;
-    sa.load(A, lda, m0, M, kbeg, kend, a_al);
-    sb.load(B, ldb, n0, N, kbeg, kend, b_al);
-    auto st_a = [&](float* p) { if constexpr (BF) sa.store(reinterpret_cast<unsigned char*>(p)); else sa.store(p); };
-    auto st_b = [&](float* p) { if constexpr (BF) sb.store(reinterpret_cast<unsigned char*>(p)); else sb.store(p); };
-    st_a(As);
-    st_b(Bs);
-    __syncthreads();
-    for (int it = 0; it < kiters; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < kiters) {
-            sa.load(A, lda, m0, M, kbeg + (it + 1) * GK, kend, a_al);
-            sb.load(B, ldb, n0, N, kbeg + (it + 1) * GK, kend, b_al);
+    auto ld = [&](auto& ra, auto& rb, int chunk) {
+        // FAST loads carry no bounds tests: past the last chunk the last one is requested again (and never used)
+        const int c = FAST ? (chunk < kiters ? chunk : kiters - 1) : chunk;
+        ra.template load<FAST>(A, lda, m0, M, kbeg + c * GK, kend, a_al);
+        rb.template load<FAST>(B, ldb, n0, N, kbeg + c * GK, kend, b_al);
+    };
+    auto st = [&](const auto& ra, const auto& rb, int buf) {
+        if constexpr (BF) {
+            ra.store(reinterpret_cast<unsigned char*>(As + buf * ASZ));
+            rb.store(reinterpret_cast<unsigned char*>(Bs + buf * BSZ));
+        } else {
+            ra.store(As + buf * ASZ);
+            rb.store(Bs + buf * BSZ);
         }
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) ld(sa[d], sb[d], d);
+    st(sa[0], sb[0], 0);
+    __syncthreads();
+    for (int it0 = 0; it0 < kiters; it0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+        const int it = it0 + d;
+        if (it >= kiters) break;
+        const int buf = it & 1;
+#ifndef TAG_GEMM_ABL     // ablation builds (tools/README.md): 1 = no staging after the first chunk, 2 = and no barrier
+        ld(sa[d], sb[d], it + PD);                 // chunk `it` of this register set is already in LDS
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BF) {
             const unsigned char* a = reinterpret_cast<const unsigned char*>(As + buf * ASZ) + (wm0 + ml) * BFROW + kl * 16;
@@ -233,11 +259,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < kiters) {
-            st_a(As + (buf ^ 1) * ASZ);
-            st_b(Bs + (buf ^ 1) * BSZ);
-        }
+#ifndef TAG_GEMM_ABL
+        if (it + 1 < kiters) st(sa[(d + 1) % PD], sb[(d + 1) % PD], buf ^ 1);
+#endif
+#if !defined(TAG_GEMM_ABL) || TAG_GEMM_ABL < 2
         __syncthreads();
+#endif
+        }
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -311,8 +339,21 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
     const int grid = ((M + T - 1) / T) * ((N + T - 1) / T) * splits;
     int kchunk = (K + splits - 1) / splits;
     kchunk = (kchunk + GK - 1) / GK * GK;
-    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
-                       a_al, b_al, splits, kchunk, partial);
+    // whole tiles, whole K chunks, no empty K slice, 16-byte aligned rows: the loader without tail handling
+    const bool fast = a_al && b_al && M % T == 0 && N % T == 0 && K % GK == 0 && (long)(splits - 1) * kchunk < K;
+    if (fast) {
+        static bool fast_attr_set = false;
+        if (!fast_attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            fast_attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, true>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N,
+                           K, ep, a_al, b_al, splits, kchunk, partial);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
+                           a_al, b_al, splits, kchunk, partial);
+    }
     if (splits > 1) {
         long nb = ((long)M * N + 255) / 256;
         if (nb > 2048) nb = 2048;
@@ -328,8 +369,10 @@ int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     // A stored (M,K) -> k-contiguous; transA: stored (K,M) -> m-contiguous
     // B stored (K,N) -> n-contiguous; transB: stored (N,K) -> k-contiguous
     const bool akc = !transA, bkc = transB != 0;
-    // 128x128 tiles once they still fill the 256 CUs, 64x64 tiles for the small problems
-    const bool big = splits == 1 && (long)((M + 127) / 128) * ((N + 127) / 128) >= 192;
+    // 128x128 tiles only when they still make >= 4 residency rounds: below that the 64-tiles (4 workgroups per CU, two rounds
+    // whose epilogue stores overlap the next tiles' products) are 3-8 % faster at the step's shapes (tools/gemm_bench.py)
+    static const int big_min = getenv("TAG_GEMM_BIG_MIN") ? atoi(getenv("TAG_GEMM_BIG_MIN")) : 2048;
+    const bool big = splits == 1 && (long)((M + 127) / 128) * ((N + 127) / 128) >= big_min;
 #define GEMM_DISPATCH(AK, BK_)                                                                                        \
     if (bf) {                                                                                                         \
         if (big) launch_gemm_t<AK, BK_, 128, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st);  \

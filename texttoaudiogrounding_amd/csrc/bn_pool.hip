@@ -318,6 +318,30 @@ struct ParamGradFn {   // plain affine BN (bn0): a = dy, b = dy * xhat
 // on the first two blocks).  The fp32 instances already run at 5.6 TB/s and LOSE 3-7 % to the extra registers, and so does
 // the backward apply pass in both storage types: they keep the plain loop.
 template <class TS> constexpr bool pool_pipelined() { return Act<TS>::is_bf16; }
+// Slot r = (b * Hs + hs) * Ws + ws of a thread that walks the slots with a fixed stride: the decomposition is carried from
+// slot to slot (two 32-bit divisions per thread, none in the loop -- the 64-bit r / Ws, r % Ws of every load and finish were
+// most of the VALU time of the bf16 pool passes).  Pixel and slot counts are < 2^31 (checked by the launchers).
+struct SlotIx {
+    int b, hs, ws;
+    __device__ __forceinline__ void set(long r, int Hs, int Ws) {
+        const unsigned ur = (unsigned)r, q = ur / (unsigned)Ws;
+        ws = (int)(ur - q * (unsigned)Ws);
+        b = (int)(q / (unsigned)Hs);
+        hs = (int)(q - (unsigned)b * (unsigned)Hs);
+    }
+    // *this + d (d = the decomposed stride), with carries
+    __device__ __forceinline__ SlotIx plus(const SlotIx& d, int Hs, int Ws) const {
+        SlotIx o;
+        o.ws = ws + d.ws;
+        int carry = o.ws >= Ws ? 1 : 0;
+        o.ws -= carry ? Ws : 0;
+        o.hs = hs + d.hs + carry;
+        carry = o.hs >= Hs ? 1 : 0;
+        o.hs -= carry ? Hs : 0;
+        o.b = b + d.b + carry;
+        return o;
+    }
+};
 template <int PH, int PW, class TS = float, int NC = 4>
 __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restrict__ y,
                                                              const float* __restrict__ scale,
@@ -332,17 +356,16 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
     float s[NC], t[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) { s[j] = scale ? scale[c + j] : 1.0f; t[j] = scale ? shift[c + j] : 0.0f; }
-    auto load = [&](long r, raw_t (&raw)[PH][PW]) {
-        const int wo = (int)(r % Wo); const long q = r / Wo;
-        const int ho = (int)(q % Ho), b = (int)(q / Ho);
+    auto load = [&](const SlotIx& ix, raw_t (&raw)[PH][PW]) {
+        const unsigned px = ((unsigned)ix.b * H + ix.hs * PH) * W + ix.ws * PW;      // first input pixel of the window
+        const TS* p = y + (size_t)px * C + c;
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
-            for (int dw = 0; dw < PW; ++dw)
-                raw[dh][dw] = ActN<TS, NC>::ldraw(y + (((size_t)b * H + (ho * PH + dh)) * W + (wo * PW + dw)) * C + c);
+            for (int dw = 0; dw < PW; ++dw) raw[dh][dw] = ActN<TS, NC>::ldraw(p + (size_t)(dh * W + dw) * C);
     };
     auto finish = [&](long r, const raw_t (&raw)[PH][PW]) {
-        const long e0 = r * C + c;                    // flat index of the thread's first output element
+        const size_t e0 = (size_t)(unsigned)r * C + c;   // flat index of the thread's first output element
         float sum[NC], mx[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) { sum[j] = 0.0f; mx[j] = 0.0f; }
@@ -377,17 +400,22 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
     };
     raw_t ra[PH][PW], rb[PH][PW];
     long r = (long)blockIdx.x * rpi + rsub;
+    SlotIx ia, ib, dstep;
+    ia.set(r < slots ? r : 0, Ho, Wo);
+    dstep.set(stride, Ho, Wo);
     if constexpr (pool_pipelined<TS>()) {
-        if (r < slots) load(r, ra);
+        if (r < slots) load(ia, ra);
         for (; r < slots; r += 2 * stride) {
             const long r2 = r + stride, r3 = r2 + stride;
-            if (r2 < slots) load(r2, rb);
+            ib = ia.plus(dstep, Ho, Wo);
+            if (r2 < slots) load(ib, rb);
             finish(r, ra);
-            if (r3 < slots) load(r3, ra);
+            ia = ib.plus(dstep, Ho, Wo);
+            if (r3 < slots) load(ia, ra);
             if (r2 < slots) finish(r2, rb);
         }
     } else {
-        for (; r < slots; r += stride) { load(r, ra); finish(r, ra); }
+        for (; r < slots; r += stride) { load(ia, ra); finish(r, ra); ia = ia.plus(dstep, Ho, Wo); }
     }
 }
 
@@ -410,16 +438,24 @@ struct PoolBwdCtx {
     struct Raw { raw_t v[PH][PW]; raw_t g; };
     // the loads of the slot (b, hs, ws, c..c+NC-1): positions outside the image load nothing (partial slots of the
     // floor-dropped last row / column), only full slots have an upstream gradient
+    // 32-bit pixel indices (pixel counts < 2^31: launcher), one widening multiply per tensor, window positions at uniform offsets
+    __device__ __forceinline__ size_t in_elem(int b, int hs, int ws, int c) const {
+        return (size_t)(((unsigned)b * H + hs * PH) * W + ws * PW) * C + c;
+    }
+    __device__ __forceinline__ size_t out_elem(int b, int hs, int ws, int c) const {
+        return (size_t)(((unsigned)b * (H / PH) + hs) * (W / PW) + ws) * C + c;
+    }
     __device__ void load(int b, int hs, int ws, int c, Raw& raw) const {
         const int Ho = H / PH, Wo = W / PW;
+        const TS* p = y + in_elem(b, hs, ws, c);
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
                 const int h = hs * PH + dh, w = ws * PW + dw;
-                raw.v[dh][dw] = (h < H && w < W) ? ActN<TS, NC>::ldraw(y + (((size_t)b * H + h) * W + w) * C + c) : ActN<TS, NC>::zero();
+                raw.v[dh][dw] = (h < H && w < W) ? ActN<TS, NC>::ldraw(p + (size_t)(dh * W + dw) * C) : ActN<TS, NC>::zero();
             }
-        raw.g = (hs < Ho && ws < Wo) ? ActN<TS, NC>::ldraw(dout + (((size_t)b * Ho + hs) * Wo + ws) * C + c) : ActN<TS, NC>::zero();
+        raw.g = (hs < Ho && ws < Wo) ? ActN<TS, NC>::ldraw(dout + out_elem(b, hs, ws, c)) : ActN<TS, NC>::zero();
     }
     // dz for the slot from its loaded values; ex[dh][dw] tells which positions exist
     __device__ void compute(const Raw& raw, int b, int hs, int ws, int c, float dz[PH][PW][NC], float xh[PH][PW][NC],
@@ -443,7 +479,7 @@ struct PoolBwdCtx {
                 }
             }
         if (!full) return;
-        const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
+        const size_t oi = out_elem(b, hs, ws, c);
         float g[NC];
         ActN<TS, NC>::unpack(raw.g, g);
         const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -483,14 +519,10 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW,
     ctx.prep(c);
     typedef typename PoolBwdCtx<PH, PW, TS, NC>::Raw Raw;
     const long stride = (long)gridDim.x * rpi;
-    auto load = [&](long r, Raw& raw) {
-        const int ws = (int)(r % Wo); const long q = r / Wo;
-        ctx.load((int)(q / Ho), (int)(q % Ho), ws, c, raw);
-    };
-    auto finish = [&](long r, const Raw& raw) {
-        const int ws = (int)(r % Wo); const long q = r / Wo;
+    auto load = [&](const SlotIx& ix, Raw& raw) { ctx.load(ix.b, ix.hs, ix.ws, c, raw); };
+    auto finish = [&](const SlotIx& ix, const Raw& raw) {
         float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
-        ctx.compute(raw, (int)(q / Ho), (int)(q % Ho), ws, c, dz, xh, ex);
+        ctx.compute(raw, ix.b, ix.hs, ix.ws, c, dz, xh, ex);
         // per-slot sums in fp32 (PH * PW terms), folded into the thread's fp64 running sums once per slot
         float f1[NC], f2[NC];
 #pragma unroll
@@ -507,17 +539,23 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(PoolBwdCtx<PH, PW,
     {
         Raw ra, rb;
         long r = (long)blockIdx.x * rpi + rsub;
+        SlotIx ia, ib, ic, dstep;
+        ia.set(r < slots ? r : 0, Ho, Wo);
+        dstep.set(stride, Ho, Wo);
         if constexpr (pool_pipelined<TS>()) {
-            if (r < slots) load(r, ra);
+            if (r < slots) load(ia, ra);
             for (; r < slots; r += 2 * stride) {
                 const long r2 = r + stride, r3 = r2 + stride;
-                if (r2 < slots) load(r2, rb);
-                finish(r, ra);
-                if (r3 < slots) load(r3, ra);
-                if (r2 < slots) finish(r2, rb);
+                ib = ia.plus(dstep, Ho, Wo);
+                if (r2 < slots) load(ib, rb);
+                finish(ia, ra);
+                ic = ib.plus(dstep, Ho, Wo);
+                if (r3 < slots) load(ic, ra);
+                if (r2 < slots) finish(ib, rb);
+                ia = ic;
             }
         } else {
-            for (; r < slots; r += stride) { load(r, ra); finish(r, ra); }
+            for (; r < slots; r += stride) { load(ia, ra); finish(ia, ra); ia = ia.plus(dstep, Ho, Wo); }
         }
     }
     double* mine = sred + threadIdx.x * 2 * NC;
@@ -556,29 +594,28 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(PoolBwdCtx<PH, PW, 
     }
     typedef typename PoolBwdCtx<PH, PW, TS, NC>::Raw Raw;
     const long stride = (long)gridDim.x * rpi;
-    auto load = [&](long r, Raw& raw) {
-        const int ws = (int)(r % Ws); const long q = r / Ws;
-        ctx.load((int)(q / Hs), (int)(q % Hs), ws, c, raw);
-    };
-    auto finish = [&](long r, const Raw& raw) {
-        const int ws = (int)(r % Ws); const long q = r / Ws;
-        const int hs = (int)(q % Hs), b = (int)(q / Hs);
+    auto load = [&](const SlotIx& ix, Raw& raw) { ctx.load(ix.b, ix.hs, ix.ws, c, raw); };
+    auto finish = [&](const SlotIx& ix, const Raw& raw) {
         float dz[PH][PW][NC], xh[PH][PW][NC]; bool ex[PH][PW];
-        ctx.compute(raw, b, hs, ws, c, dz, xh, ex);
+        ctx.compute(raw, ix.b, ix.hs, ix.ws, c, dz, xh, ex);
+        TS* p = dy + ctx.in_elem(ix.b, ix.hs, ix.ws, c);
 #pragma unroll
         for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
             for (int dw = 0; dw < PW; ++dw) {
                 if (!ex[dh][dw]) continue;
-                const int h = hs * PH + dh, w = ws * PW + dw;
                 float o[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) o[j] = k0[j] * (dz[dh][dw][j] - k1[j] - xh[dh][dw][j] * k2[j]);
-                ActN<TS, NC>::st(dy + (((size_t)b * ctx.H + h) * ctx.W + w) * C + c, o);
+                ActN<TS, NC>::st(p + (size_t)(dh * ctx.W + dw) * C, o);
             }
     };
     Raw ra;
-    for (long r = (long)blockIdx.x * rpi + rsub; r < slots; r += stride) { load(r, ra); finish(r, ra); }
+    long r = (long)blockIdx.x * rpi + rsub;
+    SlotIx ia, dstep;
+    ia.set(r < slots ? r : 0, Hs, Ws);
+    dstep.set(stride, Hs, Ws);
+    for (; r < slots; r += stride) { load(ia, ra); finish(ia, ra); ia = ia.plus(dstep, Hs, Ws); }
 }
 
 // plain relu(bn(y)) backward (no pooling)
@@ -914,6 +951,7 @@ static int bnact_pool_forward_impl(const TS* y, const float* scale, const float*
     TAG_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     TAG_CHECK_ARG(H / ph > 0 && W / pw > 0);
     TAG_CHECK_ARG(vec_ok(C));
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31));          // 32-bit pixel indices in the kernel
     bool launched = false;
     const bool nc8 = pool_nc8_type<TS>() && pool_nc8_ok(C);
     const int nb = apply_blocks((long)B * (H / ph) * (W / pw), C, nc8 ? 8 : 4);
@@ -962,6 +1000,7 @@ static int bnrelu_pool_backward_impl(const TS* y, const float* scale, const floa
     TAG_CHECK_ARG(pool == 0 || pool == 2 || pool == 3);
     const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
     TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31));          // 32-bit pixel indices in the kernels
     double* partials = static_cast<double*>(ws);
     const long slots = (long)B * (H / ph) * (W / pw);
     const bool nc8 = pool_nc8_type<TS>() && pool_nc8_ok(C) && TAG_POOL_BWD_NC8;

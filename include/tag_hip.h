@@ -217,8 +217,13 @@ int tag_bn_act_backward(const float* x, int pre_op, const float* mean, const flo
 /* backward of dropout(LPPool2d(4,(ph,pw))(leaky_relu(y,0.1))) (forward: tag_bnact_pool_forward act=2 pool=1) */
 int tag_lppool_leaky_backward(const float* y, const float* dout, float* dy, int B, int H, int W, int C,
                               int ph, int pw, float drop_p, uint64_t seed, void* stream);
-/* materialise the dropout keep-mask (0/1 bytes) the kernels above use, for parity tests */
+/* materialise the dropout keep-masks (0/1 bytes) the kernels use, for parity tests.  tag_dropout_mask: one splitmix64 per
+ * element, 24-bit uniform (tag_mean_w_*, tag_dropout_*, the attention heads); tag_dropout_mask_pooled: the mask of the pooled
+ * activations (tag_bnact_pool_forward, tag_bnrelu_pool_backward, tag_lppool_leaky_backward): one splitmix64 per 4 consecutive
+ * elements, 16-bit uniform each (csrc/tag_common.h tag_keep4; F.dropout in models/audio_encoder.py:203-210 draws from
+ * torch's Philox stream instead -- masks are replayed by seed, never compared with torch's) */
 int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream);
+int tag_dropout_mask_pooled(uint64_t seed, long n, float p, uint8_t* mask, void* stream);
 
 /* A3: mean over W then dropout: x (rows, W, C) -> (rows, C)   models/audio_encoder.py:212-215 */
 int tag_mean_w_forward(const float* x, long rows, int W, int C, float drop_p, uint64_t seed, float* out,

@@ -241,6 +241,23 @@ def dropout_keep_mask(seed: int, n: int, p: float) -> np.ndarray:
     return u >= np.float32(p)
 
 
+def dropout_keep_mask4(seed: int, n: int, p: float) -> np.ndarray:
+    """The keep mask of the POOLED activations' dropout (csrc/tag_common.h tag_keep4_bits / tag_keep4): one splitmix64 per 4
+    consecutive elements, element i kept iff ((splitmix64(seed * 0xD1342543DE82EF95 + (i >> 2)) >> 16 (i & 3)) & 0xFFFF) >=
+    ceil(p * 2^16), p in fp32."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    ng = (n + 3) // 4
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + np.arange(ng, dtype=np.uint64)) & M
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        z = z ^ (z >> np.uint64(31))
+    u = np.stack([(z >> np.uint64(16 * j)) & np.uint64(0xFFFF) for j in range(4)], axis=1).reshape(-1)[:n]
+    thr = np.uint64(int(np.ceil(np.float32(p) * np.float32(65536.0))))
+    return u >= thr
+
+
 def cnn8rnn_dropout_masks(seeds, B: int, n_frames: int, p_drop=(0.2, 0.5), dtype=torch.float32):
     """The five keep masks of one Cnn8Rnn training step for the HIP path's seeds, in the oracle's NCHW layout
     (the HIP kernels index the channels-last pooled outputs (B,H,W,C) and the (B*T',512) mean-pooled rows flat)."""
@@ -250,7 +267,7 @@ def cnn8rnn_dropout_masks(seeds, B: int, n_frames: int, p_drop=(0.2, 0.5), dtype
         shapes.append((B, H, W, 64 << i))
     masks = {}
     for i, shp in enumerate(shapes):
-        m = dropout_keep_mask(seeds[i], int(np.prod(shp)), p_drop[0]).reshape(shp)
+        m = dropout_keep_mask4(seeds[i], int(np.prod(shp)), p_drop[0]).reshape(shp)
         masks[f"drop{i + 1}"] = torch.from_numpy(m).permute(0, 3, 1, 2).to(dtype)
     m = dropout_keep_mask(seeds[4], B * shapes[3][1] * 512, p_drop[1]).reshape(B, shapes[3][1], 512)
     masks["drop5"] = torch.from_numpy(m).to(dtype)

@@ -57,7 +57,7 @@ def crnn_dropout_mask(seed, batch, n_frames, dtype=torch.float32):
     """Keep mask of CrnnEncoder's Dropout(0.3) for the HIP path's seed: the kernel indexes the channels-last pooled
     output (B, T', 1, 128) flat; the oracle applies it to (B, 128, T', 1)."""
     tp = (n_frames // 2) // 2
-    m = O.dropout_keep_mask(seed, batch * tp * 128, P_DROP).reshape(batch, tp, 1, 128)
+    m = O.dropout_keep_mask4(seed, batch * tp * 128, P_DROP).reshape(batch, tp, 1, 128)
     return {"drop": torch.from_numpy(m).permute(0, 3, 1, 2).to(dtype)}
 
 

@@ -492,7 +492,7 @@ def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
     seed = 12345
     out = ops.bnact_pool(yh, st, ph, pw, 1, 0, p, seed)
     Ho, Wo = H // ph, W // pw
-    mask = ops.dropout_mask(seed, (B, Ho, Wo, C), p, dev).cpu().permute(0, 3, 1, 2) if p > 0 else None
+    mask = ops.dropout_mask(seed, (B, Ho, Wo, C), p, dev, pooled=True).cpu().permute(0, 3, 1, 2) if p > 0 else None
     yd = y.double().requires_grad_(True)
     gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
     a = F.relu(F.batch_norm(yd, rm.double().clone(), rv.double().clone(), gd, bd, train, 0.1, 1e-5))
@@ -632,7 +632,7 @@ def test_lppool_leaky_fwd_bwd(ops, dev, H, W, C, ph, pw, p):
     yd = y.double().requires_grad_(True)
     ref = F.lp_pool2d(F.leaky_relu(yd, 0.1), 4.0, (ph, pw))
     if p > 0:
-        mask = ops.dropout_mask(seed, (B, H // ph, W // pw, C), p, dev).cpu().permute(0, 3, 1, 2)
+        mask = ops.dropout_mask(seed, (B, H // ph, W // pw, C), p, dev, pooled=True).cpu().permute(0, 3, 1, 2)
         ref = ref * mask.double() / (1 - p)
     assert relerr(nchw(out), ref) < 2e-6
     dout = torch.randn(ref.shape, generator=g)

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
     const int c = (threadIdx.x % CN) * NC, rsub = threadIdx.x / CN;
     const long slots = (long)B * Ho * Wo, stride = (long)gridDim.x * rpi;
     const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const unsigned keep_thr = tag_keep4_threshold(drop_p);
     float s[NC], t[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) { s[j] = scale ? scale[c + j] : 1.0f; t[j] = scale ? shift[c + j] : 0.0f; }
@@ -394,7 +395,14 @@ __global__ __launch_bounds__(256) void bnact_pool_fwd_kernel(const TS* __restric
             // pool: 0 avg+max | 1 LPPool(4) | 2 avg | 3 max  (models/panns.py:51-60)
             rr[j] = (pool == 0) ? sum[j] * (1.0f / (PH * PW)) + mx[j]
                   : (pool == 2) ? sum[j] * (1.0f / (PH * PW)) : (pool == 3) ? mx[j] : sqrtf(sqrtf(sum[j]));
-            if (drop_p > 0.0f) rr[j] = tag_keep(seed, (uint64_t)e0 + j, drop_p) ? rr[j] * keep_scale : 0.0f;
+        }
+        if (drop_p > 0.0f) {
+#pragma unroll
+            for (int q = 0; q < NC / 4; ++q) {
+                const uint64_t bits = tag_keep4_bits(seed, (uint64_t)(e0 >> 2) + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[4 * q + j] = tag_keep4(bits, j, keep_thr) ? rr[4 * q + j] * keep_scale : 0.0f;
+            }
         }
         ActN<TS, NC>::st(out + e0, rr);
     };
@@ -483,9 +491,17 @@ struct PoolBwdCtx {
         float g[NC];
         ActN<TS, NC>::unpack(raw.g, g);
         const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+        if (drop_p > 0.0f) {
+            const unsigned keep_thr = tag_keep4_threshold(drop_p);
+#pragma unroll
+            for (int q = 0; q < NC / 4; ++q) {
+                const uint64_t bits = tag_keep4_bits(seed, (uint64_t)(oi >> 2) + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[4 * q + j] = tag_keep4(bits, j, keep_thr) ? g[4 * q + j] * keep_scale : 0.0f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            if (drop_p > 0.0f) g[j] = tag_keep(seed, (uint64_t)oi + j, drop_p) ? g[j] * keep_scale : 0.0f;
             // first maximum in scan order (h then w), as ATen's max_pool2d picks it
             int am = 0; float best = fmaxf(a[0][0][j], 0.0f);
 #pragma unroll
@@ -763,9 +779,10 @@ __global__ __launch_bounds__(256) void lppool_leaky_bwd_kernel(const float* __re
             const size_t oi = (((size_t)b * Ho + hs) * Wo + ws) * C + c;
             const float4 g4 = *reinterpret_cast<const float4*>(dout + oi);
             float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const uint64_t bits = drop_p > 0.0f ? tag_keep4_bits(seed, (uint64_t)(oi >> 2)) : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (drop_p > 0.0f) g[j] = tag_keep(seed, (uint64_t)oi + j, drop_p) ? g[j] * keep_scale : 0.0f;
+                if (drop_p > 0.0f) g[j] = tag_keep4(bits, j, tag_keep4_threshold(drop_p)) ? g[j] * keep_scale : 0.0f;
                 const float out = sqrtf(sqrtf(sum[j]));
                 k[j] = out > 0.0f ? g[j] / (out * out * out) : 0.0f;
             }
@@ -788,9 +805,10 @@ __global__ __launch_bounds__(256) void lppool_leaky_bwd_kernel(const float* __re
     }
 }
 
-__global__ void dropout_mask_kernel(uint64_t seed, long n, float p, uint8_t* mask) {
+__global__ void dropout_mask_kernel(uint64_t seed, long n, float p, uint8_t* mask, int pooled) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        mask[i] = tag_keep(seed, (uint64_t)i, p) ? 1 : 0;
+        mask[i] = (pooled ? tag_keep4(tag_keep4_bits(seed, (uint64_t)i >> 2), (int)(i & 3), tag_keep4_threshold(p))
+                          : tag_keep(seed, (uint64_t)i, p)) ? 1 : 0;
 }
 
 // mean over W then dropout: x (rows, W, C) -> (rows, C)
@@ -1126,7 +1144,13 @@ extern "C" int tag_bnrelu_backward_apply_bf16(const void* y, const float* scale,
 
 extern "C" int tag_dropout_mask(uint64_t seed, long n, float p, uint8_t* mask, void* stream) {
     TAG_CHECK_ARG(mask && n > 0);
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), seed, n, p, mask);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), seed, n, p, mask, 0);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_dropout_mask_pooled(uint64_t seed, long n, float p, uint8_t* mask, void* stream) {
+    TAG_CHECK_ARG(mask && n > 0);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), seed, n, p, mask, 1);
     TAG_LAUNCH_CHECK();
     return 0;
 }

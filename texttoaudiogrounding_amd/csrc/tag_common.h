@@ -49,6 +49,19 @@ __host__ __device__ __forceinline__ bool tag_keep(uint64_t seed, uint64_t idx, f
     return u >= p;
 }
 
+// Dropout of the POOLED activations (bn_pool.hip: one mask for the forward, the backward sums and the backward apply):
+// ONE splitmix64 per 4 consecutive elements and a 16-bit uniform each -- element i is kept iff
+//   ((mix64(seed * 0xD1342543DE82EF95 + (i >> 2)) >> 16 (i & 3)) & 0xFFFF) >= ceil(p * 2^16)        (u / 2^16 >= p).
+// One hash per element (two 64-bit multiplies of quarter-rate integer ops each) was a quarter of the VALU time of the bf16
+// pool passes, which are VALU-bound.  oracle/tag_oracle.py dropout_keep_mask4 restates it.
+__host__ __device__ __forceinline__ uint64_t tag_keep4_bits(uint64_t seed, uint64_t group) {
+    return tag_mix64(seed * 0xD1342543DE82EF95ull + group);
+}
+__host__ __device__ __forceinline__ unsigned tag_keep4_threshold(float p) { return (unsigned)ceilf(p * 65536.0f); }
+__host__ __device__ __forceinline__ bool tag_keep4(uint64_t bits, int j, unsigned thr) {
+    return (unsigned)((bits >> (16 * j)) & 0xFFFFull) >= thr;
+}
+
 // ---- wave / block reductions (wave = 64) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -64,6 +64,7 @@ _SIGS = {
     "tag_bn_act_backward": (c_int, [P, c_int, P, P, P, P, P, P, P, c_long, c_int, c_int, P, P]),
     "tag_lppool_leaky_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),
     "tag_dropout_mask": (c_int, [c_uint64, c_long, c_float, P, P]),
+    "tag_dropout_mask_pooled": (c_int, [c_uint64, c_long, c_float, P, P]),
     "tag_mean_w_forward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_mean_w_backward": (c_int, [P, c_long, c_int, c_int, c_float, c_uint64, P, P]),
     "tag_gemm_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

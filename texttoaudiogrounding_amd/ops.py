@@ -541,10 +541,12 @@ def bn_param_grad(x2d, dy2d, st: BNStat, dg_out=None, db_out=None):
     return dg, db
 
 
-def dropout_mask(seed, shape, p, device):
+def dropout_mask(seed, shape, p, device, pooled=False):
+    """The keep mask (0/1 bytes) a kernel draws for `seed`; pooled=True: the generator of the pooled activations' dropout
+    (one hash per 4 elements; bnact_pool / bnrelu_pool_backward), else the per-element one (mean_w, dropout, attention)."""
     n = int(math.prod(shape))
     m = torch.empty(n, device=device, dtype=torch.uint8)
-    call("tag_dropout_mask", seed, n, float(p), ptr(m))
+    call("tag_dropout_mask_pooled" if pooled else "tag_dropout_mask", seed, n, float(p), ptr(m))
     return m.view(*shape)
 
 

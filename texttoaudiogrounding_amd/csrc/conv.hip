@@ -1297,9 +1297,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
 // batch 64) produces both dw (64 x 9) and dx (the gradient of the bn0 output, needed for bn0's weight / bias).
 // A workgroup walks down a strip of rows of one image; per row (64 pixels x 64 couts = 16 KB, one float4 per thread
 // and 16-pixel quarter) every dy value is read once and feeds
-//   wgrad:  acc[j][tap] += xin[h+ky-1][w+kx-1] * dy[h][w][c+j]            (xin rows in an LDS ring, bn0 affine applied)
-//   dgrad:  G[h][w][tap] = sum_co dy[h][w][co] * wgt[co][tap]  (16-lane butterfly), kept in an LDS ring of 4 rows;
-//           dx[h-1][w] = sum_tap G[h-1-(ky-1)][w-(kx-1)][tap] once row h is in.
+//   wgrad:  dw[co][tap] += xin[h+ky-1][w+kx-1] * dy[h][w][co]             (xin rows in an LDS ring, bn0 affine applied)
+//   dgrad:  G[h][w][tap] = sum_co dy[h][w][co] * wgt[co][tap], kept in an LDS ring of 4 rows;
+//           dx[h-1][w] = sum_tap G[h-1-(ky-1)][w-(kx-1)][tap] once row h is in
+// -- both products on v_mfma_f32_16x16x4_f32 (operand mapping inside the kernel).
 // The next row's dy is in flight while the current one is processed; one barrier per row.
 // sum over each aligned group of 16 lanes, result in all 16 (DPP: quad swaps, then half-row and row mirrors)
 template <int CTRL>
@@ -1338,16 +1339,24 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
     if (r1 > H) r1 = H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cq = lane & 15, c = cq << 2, psub = lane >> 4;             // channel quad, pixel inside a 4-pixel load
-    float wr[4][9];
+    // Both contractions run on v_mfma_f32_16x16x4_f32 (A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16],
+    // D[i = 4 (lane / 16) + r][j = lane % 16]); a wave owns 16 pixels of the row.
+    //   wgrad  dw[co][tap] += sum_px dy[px][co] * xin[px + shift(tap)]: the loaded layout IS the A operand (row = channel quad cq,
+    //          k = pixel psub, one MFMA per item i and channel j); B = the input value under this lane's tap (tap = lane % 16);
+    //   dgrad  G[px][tap]   = sum_co dy[px][co] * wgt[co][tap]: the contraction index has to move from lane % 16 to lane / 16, so the
+    //          wave's 16 x 64 gradient tile goes through a wave-private LDS tile (68-float rows: conflict-free both ways) and
+    //          comes back as A[row = pixel][k = channel], 16 MFMAs against the weights held as B fragments.
+    // (The scalar form -- 36 FMAs, 36 DPP adds and 36 masked LDS stores per 4-channel item -- was VALU-bound at 2 x the HBM time.)
+    const int tapl = lane & 15, kg = lane >> 4;
+    const bool tap_ok = tapl < 9;
+    const int tky = tap_ok ? tapl / 3 : 0, tkx = tap_ok ? tapl % 3 : 0;
+    float wB[16];                                                        // B fragments of the dgrad product: wgt[kg*16 + step][tap]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int q = 0; q < 16; ++q) wB[q] = tap_ok ? wgt[(kg * 16 + q) * 9 + tapl] : 0.0f;
+    f32x4 accW[4];                                                       // dw[co = (4 kg + r) * 4 + j][tap = tapl] in accW[j][r]
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wr[j][t] = wgt[(c + j) * 9 + t];
-    float acc[4][9];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[j][t] = 0.0f;
+    for (int j = 0; j < 4; ++j) accW[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    __shared__ __attribute__((aligned(16))) float Ts[4][16][68];
     for (int i = tid; i < 4 * C1B_GW * C1B_GT; i += 256) (&Gs[0][0][0])[i] = 0.0f;      // halo columns stay zero
     const float* ximg = x + (size_t)img * H * W;
     const TS* dimg = dy + (size_t)img * H * W * Cout;
@@ -1431,32 +1440,33 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
         if (h < r1) load_dy(h + 1);
         const bool own = h >= r0 && h < r1;
         const int gs = (h + 8) & 3;
+        if (own) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = wid * 16 + i * 4 + psub;
-            const float gv[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
-            float gp[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float sgp = gv[0] * wr[0][t];
-                sgp = fmaf(gv[1], wr[1][t], sgp);
-                sgp = fmaf(gv[2], wr[2][t], sgp);
-                sgp = fmaf(gv[3], wr[3][t], sgp);
-                gp[t] = sgp;
+            for (int i = 0; i < 4; ++i) {
+                const float xb = tap_ok ? Xs[(h + tky - 1 + 8) & 3][wid * 16 + i * 4 + psub + tkx] : 0.0f;
+                accW[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i].x, xb, accW[0], 0, 0, 0);
+                accW[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i].y, xb, accW[1], 0, 0, 0);
+                accW[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i].z, xb, accW[2], 0, 0, 0);
+                accW[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i].w, xb, accW[3], 0, 0, 0);
             }
-            if (own) {
+        }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float xv = Xs[(h + t / 3 - 1 + 8) & 3][px + t % 3];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Ts[wid][i * 4 + psub][c]) = g[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // the tile is wave-private: no barrier
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 accG = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j][t] = fmaf(xv, gv[j], acc[j][t]);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float v = sum16(gp[t]);
-                if (cq == t) Gs[gs][px + 1][t] = v;
-            }
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Ts[wid][tapl][kg * 16 + 4 * q4]);
+            accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, wB[4 * q4 + 0], accG, 0, 0, 0);
+            accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, wB[4 * q4 + 1], accG, 0, 0, 0);
+            accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, wB[4 * q4 + 2], accG, 0, 0, 0);
+            accG = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, wB[4 * q4 + 3], accG, 0, 0, 0);
+        }
+        if (tap_ok) {
+            float* gp = &Gs[gs][wid * 16 + 4 * kg + 1][tapl];             // G[px = 4 kg + r][tap] in accG[r]
+            gp[0] = accG.x; gp[C1B_GT] = accG.y; gp[2 * C1B_GT] = accG.z; gp[3 * C1B_GT] = accG.w;
         }
         __syncthreads();
         const int ho = h - 1;                                             // output row whose three G rows are now present
@@ -1469,16 +1479,16 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const float* __restric
         }
         if (h < r1) take((unsigned)(h + 1) < (unsigned)H);
     }
-    // dw partial of this workgroup: fold the 4 pixel sub-lanes, then the 4 waves (fixed order), in fp64 across workgroups
+    // dw partial of this workgroup: the MFMA has summed the wave's pixels; fold the 4 waves (fixed order), in fp64 across workgroups
+    if (tap_ok) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float v = acc[j][t];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (psub == 0) red[wid][cq][j * 9 + t] = v;
+        for (int j = 0; j < 4; ++j) {
+            red[wid][4 * kg + 0][j * 9 + tapl] = accW[j].x;
+            red[wid][4 * kg + 1][j * 9 + tapl] = accW[j].y;
+            red[wid][4 * kg + 2][j * 9 + tapl] = accW[j].z;
+            red[wid][4 * kg + 3][j * 9 + tapl] = accW[j].w;
         }
+    }
     __syncthreads();
     for (int e = tid; e < 16 * 36; e += 256) {
         const int q = e / 36, r = e % 36;

@@ -502,21 +502,25 @@ struct PoolBwdCtx {
         }
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            // first maximum in scan order (h then w), as ATen's max_pool2d picks it
-            int am = 0; float best = fmaxf(a[0][0][j], 0.0f);
+            // The max-pool gradient goes to the first maximum of relu(a) in scan order (h then w), as ATen's max_pool2d picks it.
+            // Where that maximum is positive it is the first position with a == max(a); where it is zero every dz of the slot
+            // is zero anyway (a <= 0 everywhere), so the raw maximum decides: one compare per position, the first-hit
+            // bookkeeping on the scalar unit, two selects.
+            float m = a[0][0][j];
+#pragma unroll
+            for (int dh = 0; dh < PH; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < PW; ++dw) m = fmaxf(m, a[dh][dw][j]);
+            const float gw = g[j] * wavg, gwm = g[j] * (wavg + wmax);
+            bool found = false;
 #pragma unroll
             for (int dh = 0; dh < PH; ++dh)
 #pragma unroll
                 for (int dw = 0; dw < PW; ++dw) {
-                    const float r = fmaxf(a[dh][dw][j], 0.0f);
-                    if (r > best) { best = r; am = dh * PW + dw; }
-                }
-#pragma unroll
-            for (int dh = 0; dh < PH; ++dh)
-#pragma unroll
-                for (int dw = 0; dw < PW; ++dw) {
-                    const float da = g[j] * (wavg + ((am == dh * PW + dw) ? wmax : 0.0f));
-                    dz[dh][dw][j] = a[dh][dw][j] > 0.0f ? da : 0.0f;
+                    const bool eq = a[dh][dw][j] == m;
+                    const bool hit = eq && !found;
+                    found = found || eq;
+                    dz[dh][dw][j] = a[dh][dw][j] > 0.0f ? (hit ? gwm : gw) : 0.0f;
                 }
         }
     }

@@ -74,10 +74,15 @@ struct Stage {
 // (kl, ml) = row ml, k = 8 kl .. 8 kl + 7 of a k16 step -- is ONE 16-byte LDS read.  Operands are rounded to bf16 (nearest-even)
 // on their way into LDS.  A k-contiguous operand stores 4 k of one row as 8 bytes; an mn-contiguous one loads the same 4 rows
 // at k and k + 1 and stores four (k, k+1) pairs.
-constexpr int BFROW = 80;
+// K chunk of the bf16 variant.  64 (144-byte rows, 4 MFMAs per wave of a 64-tile between two barriers instead of 2) was
+// measured 8-20 % SLOWER at the step's shapes than 32 (tools/gemm_bench.py: 0.546 vs 0.50 ms for the nine GEMMs) -- the longer
+// load -> convert -> store chain per chunk costs more than the halved barrier count buys -- so 32 stays.
+constexpr int GKB = 32;
+constexpr int BFROW = 2 * GKB + 16;        // 80-byte rows: (5 r) mod 16 is a bijection on the 16-byte slots of a lane group
 template <bool KC, int T>
 struct StageBF {
-    static constexpr int NL = T / 32;
+    static constexpr int NL = T * GKB / 1024;           // float4 per thread per chunk
+    static constexpr int RQ = GKB / 4;                  // float4 per row of a k-contiguous operand
     f32x4 reg[NL];
     template <bool FAST>
     __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool al) {
@@ -86,7 +91,7 @@ struct StageBF {
             float4 v;
             if (KC) {
                 const int idx = threadIdx.x + 256 * i;
-                const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                const int r = r0 + idx / RQ, k = k0 + (idx % RQ) * 4;
                 if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)r * ld + k);
                 else v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
             } else {
@@ -103,7 +108,7 @@ struct StageBF {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const int idx = threadIdx.x + 256 * i;
-                const int r = idx >> 3, k = (idx & 7) * 4;
+                const int r = idx / RQ, k = (idx % RQ) * 4;
                 *reinterpret_cast<tag_u32x2*>(s + r * BFROW + k * 2) =
                     (tag_u32x2){tag_pack_bf16(reg[i].x, reg[i].y), tag_pack_bf16(reg[i].z, reg[i].w)};
             }
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                                                    Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
                                                    float* __restrict__ partial) {
     constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
+    constexpr int KCH = BF ? GKB : GK;     // K chunk per barrier
     constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
     constexpr int ASZ = BF ? T * BFROW / 4 : ((GK * LDSA + 3) / 4) * 4;               // floats per buffer (16-byte aligned)
     constexpr int BSZ = BF ? T * BFROW / 4 : ((GK * LDSB + 3) / 4) * 4;
@@ -183,12 +189,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int kiters = (kend - kbeg + GK - 1) / GK;
+    const int kiters = (kend - kbeg + KCH - 1) / KCH;
     auto ld = [&](auto& ra, auto& rb, int chunk) {
         // FAST loads carry no bounds tests: past the last chunk the last one is requested again (and never used)
         const int c = FAST ? (chunk < kiters ? chunk : kiters - 1) : chunk;
-        ra.template load<FAST>(A, lda, m0, M, kbeg + c * GK, kend, a_al);
-        rb.template load<FAST>(B, ldb, n0, N, kbeg + c * GK, kend, b_al);
+        ra.template load<FAST>(A, lda, m0, M, kbeg + c * KCH, kend, a_al);
+        rb.template load<FAST>(B, ldb, n0, N, kbeg + c * KCH, kend, b_al);
     };
     auto st = [&](const auto& ra, const auto& rb, int buf) {
         if constexpr (BF) {
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             const unsigned char* a = reinterpret_cast<const unsigned char*>(As + buf * ASZ) + (wm0 + ml) * BFROW + kl * 16;
             const unsigned char* b = reinterpret_cast<const unsigned char*>(Bs + buf * BSZ) + (wn0 + ml) * BFROW + kl * 16;
 #pragma unroll
-            for (int ks = 0; ks < GK / 16; ++ks) {
+            for (int ks = 0; ks < GKB / 16; ++ks) {
                 gemm_u32x4 af[TT], bfr[TT];
 #pragma unroll
                 for (int i = 0; i < TT; ++i) af[i] = *reinterpret_cast<const gemm_u32x4*>(a + i * 32 * BFROW + ks * 32);
@@ -337,10 +343,11 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
         attr_set = true;
     }
     const int grid = ((M + T - 1) / T) * ((N + T - 1) / T) * splits;
+    constexpr int KCH = BF ? GKB : GK;
     int kchunk = (K + splits - 1) / splits;
-    kchunk = (kchunk + GK - 1) / GK * GK;
+    kchunk = (kchunk + KCH - 1) / KCH * KCH;
     // whole tiles, whole K chunks, no empty K slice, 16-byte aligned rows: the loader without tail handling
-    const bool fast = a_al && b_al && M % T == 0 && N % T == 0 && K % GK == 0 && (long)(splits - 1) * kchunk < K;
+    const bool fast = a_al && b_al && M % T == 0 && N % T == 0 && K % KCH == 0 && (long)(splits - 1) * kchunk < K;
     if (fast) {
         static bool fast_attr_set = false;
         if (!fast_attr_set) {

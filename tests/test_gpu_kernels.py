@@ -704,6 +704,34 @@ def test_gemm_bf16_mode(ops, dev, monkeypatch, M, N, K, ta, tb):
     assert relerr(ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb), exact) < 2e-6
 
 
+@pytest.mark.parametrize("math_", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K,ta,tb", [(256, 128, 512, False, True), (128, 192, 320, False, False), (192, 64, 2048, True, False),
+                                         (64, 64, 64, True, True)])
+def test_gemm_whole_tile_loader_is_the_same_arithmetic(ops, dev, monkeypatch, math_, M, N, K, ta, tb):
+    """Whole, 16-byte-aligned problems take the kernel variant whose loader has no tail handling (gemm.hip FAST).  The same
+    operands placed 4 bytes off a 16-byte boundary force the tail-aware loader: identical K order, identical products ->
+    the two results are bit-identical (fp32 MFMA and bf16-operand MFMA, every transposition, split-K included)."""
+    monkeypatch.setattr(ops, "GEMM_MATH", math_)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g).to(dev)
+
+    def off4(t):                                       # same values, storage starting 4 bytes after a 16-byte boundary
+        buf = torch.empty(t.numel() + 8, device=dev)
+        start = 1 + ((-(buf.data_ptr() // 4)) % 4)
+        v = buf[start:start + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    fast = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, ta, tb, bias=bias, act=1)
+    slow = ops.gemm(off4(A), off4(Bm), M, N, K, ta, tb, bias=bias, act=1)
+    assert torch.equal(fast, slow)
+    exact = F.relu((A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double()) + bias.cpu().double())
+    assert relerr(fast, exact) < (2e-6 if math_ == "fp32" else 2e-2)
+    ops.check_async_errors()
+
+
 # ------------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (18, 6, 512, 256), (64, 40, 512, 256), (5, 33, 128, 128),
                                      (130, 5, 64, 256)])

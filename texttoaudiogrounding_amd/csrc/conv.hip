@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 #ifndef TAG_HALO_NB
 #define TAG_HALO_NB 1
 #endif
+// weight-chunk buffers of the 64-cout tiles (their own knob: a second 8 KB buffer still leaves 3 workgroups per CU, and a
+// 64-cout tap is only 32 MFMAs per wave between the barriers).  Measured with 2: 64 -> 64 at W = 64 2.59 -> 2.61 ms,
+// 128 -> 64 at W = 32 1.17 -> 1.23 ms -- the second barrier per tap is not what holds these tiles at 0.77 MFMA busy.
+#ifndef TAG_HALO_NB64
+#define TAG_HALO_NB64 1
+#endif
+template <int BN_> constexpr int halo_nb() { return BN_ == 64 ? TAG_HALO_NB64 : TAG_HALO_NB; }
 // -DTAG_HALO_PROF (tools/run_halo_prof.sh, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
 #ifdef TAG_HALO_PROF
 __device__ unsigned long long tag_halo_prof[8];
@@ -278,13 +285,13 @@ struct BnBwdEpi {
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
-__global__ __launch_bounds__(256, TAG_HALO_NB == 2 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
                                                               int Cin, int Cout) {
     using G = HaloGeom<TW>;
-    constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = TAG_HALO_NB;
+    constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = halo_nb<BN_>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ASZ = ((BK * G::LDP + 3) / 4) * 4;
     float* As = smem;                          // [BK][LDP] patch, k-major
@@ -1563,7 +1570,9 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
                         const BnBwdEpi* epi, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = HaloGeom<TW>;
     const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
-    const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + TAG_HALO_NB * BK * BN_ + 2 * 512) * sizeof(float);
+    // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
+    // third workgroup of a CU fits only without the unused part of a 512-channel table)
+    const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + halo_nb<BN_>() * BK * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
     if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
         static bool attr_set = false;
         if (!attr_set) {

@@ -166,8 +166,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
     const int n_tiles = (N + T - 1) / T, m_tiles = (M + T - 1) / T;
     int L = xcd_remap(blockIdx.x, n_tiles * m_tiles * splits);
-    const int split = L % splits;            // K slices of one tile are neighbours (same XCD, shared operands in L2)
-    L /= splits;
+    // split-K: all tiles of ONE K slice are neighbours -- they read the same A and B slices, and xcd_remap gives an XCD a
+    // contiguous run of L, i.e. whole K slices whose operands are then fetched once into that XCD's L2 (the tile-major order
+    // put the K slices of one tile side by side, which share nothing: 4 x the algorithmic fetch on the weight-gradient GEMMs)
+    const int split = L / (n_tiles * m_tiles);
+    L -= split * (n_tiles * m_tiles);
     const int n0 = (L % n_tiles) * T, m0 = (L / n_tiles) * T;
     const int kbeg = split * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;

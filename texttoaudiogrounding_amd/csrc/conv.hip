@@ -1309,19 +1309,6 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_rows_kernel(const float* __re
 //           dx[h-1][w] = sum_tap G[h-1-(ky-1)][w-(kx-1)][tap] once row h is in
 // -- both products on v_mfma_f32_16x16x4_f32 (operand mapping inside the kernel).
 // The next row's dy is in flight while the current one is processed; one barrier per row.
-// sum over each aligned group of 16 lanes, result in all 16 (DPP: quad swaps, then half-row and row mirrors)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-    return v + __int_as_float(t);
-}
-__device__ __forceinline__ float sum16(float v) {
-    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);       // row_half_mirror
-    v = dpp_add<0x140>(v);       // row_mirror
-    return v;
-}
 // FUSE: `dy` holds da = dL/d relu(bn1(yref)) (the raw dgrad output of block 1's second conv) and the backward of that
 // BatchNorm + ReLU is applied as the values arrive -- dy = k0 * (dz - k1 - xhat * k2), dz = da where bn1(yref) > 0, the
 // arithmetic of bnrelu_bwd_apply_kernel (bn_pool.hip) -- so the separate apply pass over the largest activation of the

@@ -731,9 +731,21 @@ def gru_bidir_forward(x2d, rnn, B, T, need_grad):
     return y, (dict(gates=gates, y=y, w_ih=w_ih, w_hh=w_hh, Hh=Hh) if need_grad else None)
 
 
-def gru_bidir_backward(dy, x2d, sv, outs=None):
+def _adjacent_view(a, b, shape):
+    """The view over ``a`` and ``b`` as ONE tensor when b lies right behind a in the same storage, else None."""
+    if (a is not None and b is not None and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+            and a.device == b.device and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        return torch.empty(0, device=a.device, dtype=a.dtype).set_(a.untyped_storage(), a.storage_offset(), tuple(shape))
+    return None
+
+
+def gru_bidir_backward(dy, x2d, sv, outs=None, side=None):
     """Returns (dx2d, [8 parameter gradients in nn.GRU order]).  outs: optional 8 destination tensors (flat-gradient
-    views); a gradient whose destination is given is written there directly."""
+    views); a gradient whose destination is given is written there directly -- the bias gradients too when the two
+    directions' sinks are adjacent (runner.FlatParams lays them out that way): one column sum fills both.
+    side: a _SideWgrad; when EVERY gradient has its destination, the parameter-gradient work (2 column sums + 4 GEMMs, all
+    off the dx chain) runs on its side stream beside the memory-bound passes that follow on the main stream."""
     Hh, y, gates = sv["Hh"], sv["y"], sv["gates"]
     B, T, _ = y.shape
     M = B * T
@@ -744,18 +756,27 @@ def gru_bidir_backward(dy, x2d, sv, outs=None):
     call("tag_gru_backward", ptr(dy), ptr(y), ptr(gates), ptr(sv["w_hh"]), ptr(dgi), ptr(dgh), ptr(hprev),
          ptr(scratch), B, T, Hh)
     I = x2d.shape[1]
-    outs = outs if outs is not None else [None] * 8
+    outs = list(outs) if outs is not None else [None] * 8
     g = [None] * 8
-    db_ih = colsum(dgi, M, 6 * Hh)
-    db_hh = colsum(dgh, M, 6 * Hh)
-    for d in range(2):
-        ai = dgi.view(M, 6 * Hh)[:, d * 3 * Hh:]
-        a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
-        hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
-        g[4 * d + 0] = gemm(ai, x2d, 3 * Hh, I, M, transA=True, lda=6 * Hh, out=outs[4 * d + 0])
-        g[4 * d + 1] = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh, out=outs[4 * d + 1])
-        g[4 * d + 2] = db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
-        g[4 * d + 3] = db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
+    bih_sink = _adjacent_view(outs[2], outs[6], (6 * Hh,))
+    bhh_sink = _adjacent_view(outs[3], outs[7], (6 * Hh,))
+    all_direct = bih_sink is not None and bhh_sink is not None and all(o is not None for o in outs)
+
+    def param_grads():
+        db_ih = colsum(dgi, M, 6 * Hh, out=bih_sink)
+        db_hh = colsum(dgh, M, 6 * Hh, out=bhh_sink)
+        for d in range(2):
+            ai = dgi.view(M, 6 * Hh)[:, d * 3 * Hh:]
+            a = dgh.view(M, 6 * Hh)[:, d * 3 * Hh:]
+            hb = hprev.view(M, 2 * Hh)[:, d * Hh:]
+            g[4 * d + 0] = gemm(ai, x2d, 3 * Hh, I, M, transA=True, lda=6 * Hh, out=outs[4 * d + 0])
+            g[4 * d + 1] = gemm(a, hb, 3 * Hh, Hh, M, transA=True, lda=6 * Hh, ldb=2 * Hh, out=outs[4 * d + 1])
+            g[4 * d + 2] = outs[4 * d + 2] if bih_sink is not None else db_ih[d * 3 * Hh:(d + 1) * 3 * Hh]
+            g[4 * d + 3] = outs[4 * d + 3] if bhh_sink is not None else db_hh[d * 3 * Hh:(d + 1) * 3 * Hh]
+    if side is not None and all_direct:
+        side.run(param_grads, (dgi, dgh, hprev, x2d))
+    else:
+        param_grads()
     dx = gemm(dgi, sv["w_ih"], M, I, 6 * Hh)
     return dx, g
 
@@ -793,6 +814,13 @@ def side_streams(device):
 WGRAD_LAG = _os.environ.get("TAG_WGRAD_LAG", "0") != "0"     # measured: 57.7 ms lagged vs 57.2 ms not -- off by default
 
 
+#: parameter-gradient work of the GRU (1) -- and of fc1 (2) -- on the wgrad side stream; 0 = on the main stream
+#: (TAG_SIDE_PARAM_GRADS).  Measured on one box, B = 64 (fp32 / bf16 mode ms per step): 0: 54.64-54.75 / 11.23-11.30,
+#: 1: 54.57-54.69 / 11.02-11.11, 2: 54.91-55.20 / 11.08-11.13 -- fc1's GEMM on the side stream delays the block-4 wgrads more
+#: than it overlaps, so the default stops at the GRU.
+SIDE_PARAM_GRADS = int(os.environ.get("TAG_SIDE_PARAM_GRADS", "1"))
+
+
 class _SideWgrad:
     """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them."""
 
@@ -810,6 +838,20 @@ class _SideWgrad:
         if not WGRAD_LAG:
             self.release()
         return dw
+
+    def run(self, fn, tensors=()):
+        """``fn()`` on the side stream, ordered after everything enqueued on the main stream so far (inline when the side
+        stream is off).  ``tensors``: main-stream allocations fn reads (kept alive for the side stream)."""
+        if not self.on:
+            fn()
+            return
+        self.release()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
 
     def release(self):
         """Launch the queued wgrads on the side stream, ordered after everything enqueued on the main stream so far."""
@@ -899,15 +941,23 @@ class Cnn8RnnFunction(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * len(p)
         sk, prm = sv["sinks"], sv["params"]
         fc = sv["fc"]
-        dfc, ggru = gru_bidir_backward(dy, fc, sv["gsave"], outs=sk[28:36])
+        sw = _SideWgrad(dy.device)
+        dfc, ggru = gru_bidir_backward(dy, fc, sv["gsave"], outs=sk[28:36], side=sw if SIDE_PARAM_GRADS >= 1 else None)
         for k in range(8):
             _deliver(grads, sk, 28 + k, ggru[k])
         M = fc.shape[0]
         dfc = relu_backward(fc, dfc)
         xm = sv["xm"]
         fc_w = p[26]
-        _deliver(grads, sk, 26, gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0], out=sk[26]))
-        _deliver(grads, sk, 27, colsum(dfc, M, fc_w.shape[0], out=sk[27]))
+        if SIDE_PARAM_GRADS >= 2 and sk[26] is not None and sk[27] is not None:
+            # fc1's parameter gradients are off the dx chain too: beside the passes below, on the side stream
+            sw.run(lambda: (gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0], out=sk[26]),
+                            colsum(dfc, M, fc_w.shape[0], out=sk[27])), (dfc, xm))
+            _deliver(grads, sk, 26, sk[26])
+            _deliver(grads, sk, 27, sk[27])
+        else:
+            _deliver(grads, sk, 26, gemm(dfc, xm, fc_w.shape[0], fc_w.shape[1], M, transA=True, lda=fc_w.shape[0], out=sk[26]))
+            _deliver(grads, sk, 27, colsum(dfc, M, fc_w.shape[0], out=sk[27]))
         if prm is not None:
             # the persistent GRU backward is enqueued: from here on a bucket's all-reduce may run beside the kernels of
             # this stream (never beside the spinning GRU workgroups: the collective is ordered after them)
@@ -920,7 +970,6 @@ class Cnn8RnnFunction(torch.autograd.Function):
         call("tag_mean_w_backward" + _sfx(dx), ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
         # ---- conv blocks, last to first ----
         lm, st0 = sv["lm"], sv["st0"]
-        sw = _SideWgrad(dy.device)
         for i in range(3, -1, -1):
             x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
             c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]

@@ -1,0 +1,67 @@
+// Sustained MFMA rate of register-resident operands (no LDS, no memory): what the matrix pipe delivers on this part once
+// a whole chip of it runs for milliseconds -- the practical ceiling beside the datasheet peaks bench.py prices against.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_peak tools/mfma_peak.hip && tools/bin/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NACC, bool BF>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float seed) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 1e-3f;
+    bf16x8 ab, bb;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ab[k] = (__bf16)(a + k); bb[k] = (__bf16)(b - k); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                if constexpr (BF) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[0] = s;              // keep the accumulators alive
+}
+
+template <int NACC, bool BF>
+static void run(const char* name, int blocks_per_cu, int iters) {
+    float* out;
+    hipMalloc(&out, 4);
+    const int grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma_loop<NACC, BF>), dim3(grid), dim3(256), 0, 0, out, iters / 10, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma_loop<NACC, BF>), dim3(grid), dim3(256), 0, 0, out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop_per_mfma = BF ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;
+    const double flops = (double)grid * 4 * iters * 8 * NACC * flop_per_mfma;
+    printf("%-34s %d workgroup(s)/CU, %d accumulators/wave: %7.2f ms  %8.1f TFLOP/s\n", name, blocks_per_cu, NACC, ms,
+           flops / ms * 1e-9);
+    hipFree(out);
+}
+
+int main() {
+    for (int bpc = 1; bpc <= 4; bpc *= 2) {
+        run<4, false>("v_mfma_f32_32x32x2_f32", bpc, 20000 / bpc);
+        run<4, true>("v_mfma_f32_32x32x16_bf16", bpc, 40000 / bpc);
+    }
+    run<2, true>("v_mfma_f32_32x32x16_bf16", 2, 20000);
+    run<1, true>("v_mfma_f32_32x32x16_bf16", 4, 10000);
+    return 0;
+}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TAG_ABI_VERSION 1
+#define TAG_ABI_VERSION 2   /* bump whenever an existing entry point changes its argument list (lib.py checks it) */
 #define TAG_EINVAL (-1) /* bad argument (shape not supported, null pointer, ...) */
 #define TAG_ELAUNCH (-2)
 
@@ -281,6 +281,10 @@ int tag_gru_backward(const float* dy, const float* y, const float* gates, const 
                      float* dgi, float* dgh, float* hprev, void* scratch /* tag_gru_ws_bytes */, int B, int T,
                      int H, void* stream);
 int tag_gru_timed_out(const void* host_copy_of_err_word);
+/* After a timeout: make every later persistent GRU launch of this process publish its exchange granules write-through
+ * (agent scope) instead of L2-resident on one XCD -- the fast form depends on gfx950 cache behaviour (SPX partition mode,
+ * MTYPE_RW) beyond the HIP memory model; a stale granule can only show as a timeout.  Returns the previous setting. */
+int tag_gru_disable_xcd_fast(void);
 
 /* ---------------------------------------------------------------------------------------------
  * T1 + T2: nn.Embedding gather + mean over valid tokens

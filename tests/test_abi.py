@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (tag_[a-z0-9_]+)", out))
     assert set(syms) <= exported
-    assert handle.tag_abi_version() == 1
+    assert handle.tag_abi_version() == lib.ABI_VERSION == 2
 
 
 def test_code_object_is_gfx950_only():

@@ -840,10 +840,15 @@ bool gru_tile4_enabled() {
     return v == 1;
 }
 // TAG_GRU_XCD=0: never use the L2-resident (same-XCD) publishing, for A/B timing
+// The L2-resident publishing relies on gfx950 behaviour beyond the HIP memory model (workgroup-scope sc0 stores of one
+// workgroup being served to agent-scope sc1 loads of another workgroup on the SAME XCD out of that XCD's L2; partition mode
+// SPX, MTYPE_RW) and is gated by the run-time HW_REG_XCC_ID check in the kernels.  A stale read shows as a tag mismatch ->
+// bounded spin -> sticky timeout word; the host then calls tag_gru_disable_xcd_fast() (ops._check_gru_word) and every later
+// launch of the process publishes write-through (sc1), which is correct under every placement.
+static int g_gru_xcd_fast = -1;
 bool gru_xcd_fast_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TAG_GRU_XCD"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
+    if (g_gru_xcd_fast < 0) { const char* e = getenv("TAG_GRU_XCD"); g_gru_xcd_fast = (e && e[0] == '0') ? 0 : 1; }
+    return g_gru_xcd_fast == 1;
 }
 bool gru_coop_enabled() {
     static int v = -1;
@@ -994,6 +999,13 @@ extern "C" int tag_gru_backward(const float* dy, const float* y, const float* ga
     }
     TAG_LAUNCH_CHECK();
     return 0;
+}
+
+// after a timeout: never use the L2-resident publishing again in this process (returns the previous setting)
+extern "C" int tag_gru_disable_xcd_fast(void) {
+    const int was = gru_xcd_fast_enabled() ? 1 : 0;
+    g_gru_xcd_fast = 0;
+    return was;
 }
 
 // last persistent GRU launch that used this scratch timed out waiting for a neighbour (host-side check after a sync)

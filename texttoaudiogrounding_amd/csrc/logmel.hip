@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void waveform_f16_unpack_kernel(const _Float16
                                                                   float* __restrict__ out, long* __restrict__ len_out) {
     const int b = blockIdx.y;
     const long o0 = off[b], n = off[b + 1] - o0;
-    if (len_out && blockIdx.x == 0 && threadIdx.x == 0) len_out[b] = n;
+    if (len_out && blockIdx.x == 0 && threadIdx.x == 0) len_out[b] = n < S ? n : S;   // a clip cut to S reports the cut length (the reference's collate never yields len > width)
     const _Float16* src = packed + o0;
     float* dst = out + (size_t)b * S;
     // head: scalar samples until the SOURCE is 16-byte aligned (ragged offsets), then 8-sample vector items

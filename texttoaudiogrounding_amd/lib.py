@@ -16,6 +16,10 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtag_hip.so")
 
+# = TAG_ABI_VERSION of include/tag_hip.h: bumped whenever an EXISTING entry point changes its argument list, so that a stale
+# libtag_hip.so (git-ignored, shipped separately) is refused instead of being called with shifted arguments
+ABI_VERSION = 2
+
 P = c_void_p
 _SIGS = {
     "tag_abi_version": (c_int, []),
@@ -75,6 +79,7 @@ _SIGS = {
     "tag_relu_backward": (c_int, [P, P, P, c_long, P]),
     "tag_gru_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tag_gru_timed_out": (c_int, [P]),
+    "tag_gru_disable_xcd_fast": (c_int, []),
     "tag_gru_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_gru_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "tag_embed_mean_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -159,8 +164,9 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.tag_abi_version() != 1:
-        raise RuntimeError("libtag_hip.so ABI version mismatch")
+    if lib.tag_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libtag_hip.so ABI version {lib.tag_abi_version()} != {ABI_VERSION} expected by lib.py: the "
+                           "shared library is stale, rebuild it (make -C texttoaudiogrounding_amd/csrc)")
     _lib = lib
     return lib
 

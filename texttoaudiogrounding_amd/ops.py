@@ -120,10 +120,45 @@ class _LazySinks:
         return self._one(self.params[i])
 
 
+#: True while the outermost tag autograd node being applied records a graph (set by TagFunction.apply): inside
+#: Function.forward grad mode is always off and ctx.needs_input_grad only mirrors requires_grad, so this is the one place
+#: the caller's ``torch.no_grad()`` is visible
+_RECORDING = True
+
+
+class TagFunction(torch.autograd.Function):
+    """Base of the autograd nodes of this module: remembers whether the CALLER records a graph."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        global _RECORDING
+        prev, _RECORDING = _RECORDING, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _RECORDING = prev
+
+
 def _sinks(params):
     """Per input parameter: its flat-gradient view, or None (frozen parameter / direct gradients off / a parameter claimed
-    by more than one node in this forward pass)."""
-    return _LazySinks(params, DIRECT_GRADS)
+    by more than one node in this forward pass).  A forward pass that records no graph (``torch.no_grad()``, the first pass of
+    a checkpointed segment) claims nothing -- its node never runs backward, and a claim would silently switch the
+    parameter's real node to the AccumulateGrad route and disable the early bucket launch."""
+    return _LazySinks(params, DIRECT_GRADS and _RECORDING)
+
+
+def second_writer_guard(p):
+    """Tensor hook of every flat-buffer parameter (runner.FlatParams): it sees the gradient autograd is about to accumulate
+    into ``p.grad`` -- None when every node delivered in place.  A parameter claimed by exactly ONE HIP node is delivered in
+    place, so a defined gradient arriving for it means a second, plain-torch consumer of the same parameter (a tied weight,
+    a regulariser on p) is adding into the very view the node overwrites with copy_: the sum would depend on the order of
+    the two writes.  Raise instead of training on a silently wrong gradient."""
+    def hook(g):
+        if g is not None and DIRECT_GRADS and _CLAIMS.get(id(p), 0) == 1:
+            raise RuntimeError("direct gradients: a parameter delivered in place by a HIP autograd node also received a "
+                               "gradient through plain autograd (tied weight / regulariser on the parameter); the two "
+                               "writers race on one flat-gradient view -- run this model with ops.DIRECT_GRADS off")
+    return hook
 
 
 def _deliver(grads, sinks, i, val):
@@ -644,8 +679,11 @@ def _check_gru_word(key, ws):
     err = word.cpu()
     if query("tag_gru_timed_out", err.data_ptr()):
         word.zero_()
+        was_fast = query("tag_gru_disable_xcd_fast")      # later launches publish write-through (correct under every placement)
         raise RuntimeError(f"persistent GRU kernel timed out waiting for a neighbouring workgroup (B,H,pass = {key[2:]}): "
-                           "its workgroups were not co-resident; outputs of that step are NaN and the optimiser skipped it")
+                           "its workgroups were not co-resident or an L2-resident exchange granule was read stale; outputs of "
+                           "that step are NaN and the optimiser skipped it"
+                           + ("; the same-XCD L2 publishing is now OFF for this process" if was_fast else ""))
 
 
 def check_async_errors():
@@ -873,7 +911,7 @@ class _SideWgrad:
             self.main.wait_stream(self.side)
 
 
-class Cnn8RnnFunction(torch.autograd.Function):
+class Cnn8RnnFunction(TagFunction):
     """params order: bn0.w, bn0.b, 4 x (conv1.w, bn1.w, bn1.b, conv2.w, bn2.w, bn2.b), fc1.w, fc1.b,
     rnn (w_ih, w_hh, b_ih, b_hh) x (fwd, reverse)."""
 
@@ -1084,7 +1122,7 @@ def lppool_leaky_backward(y, dout, ph, pw, drop_p=0.0, seed=0):
 CRNN_POOLS = [(2, 4), (2, 4), (1, 4)]
 
 
-class CrnnFunction(torch.autograd.Function):
+class CrnnFunction(TagFunction):
     """params order: 5 x (bn.w, bn.b, conv.w) for cnn.{0,2,3,5,6}, then gru (w_ih, w_hh, b_ih, b_hh) x (fwd, reverse).
 
     Layer plan (channels-last): lm -> [bn0 scalar | conv 1->32] -> LP(2,4) -> [bn | conv 32->128] -> [leaky,bn | conv]
@@ -1190,7 +1228,7 @@ class CrnnFunction(torch.autograd.Function):
 # small heads
 # ------------------------------------------------------------------------------------------------
 
-class LinearFunction(torch.autograd.Function):
+class LinearFunction(TagFunction):
     """nn.Linear on the MFMA GEMM (audio_proj / text_proj, models/audio_text_model.py:45-46,78-87)."""
 
     @staticmethod
@@ -1255,7 +1293,7 @@ def embed_mean_backward_into(dtab, dseq, dtok, text, text_len):
     return dtab
 
 
-class EmbedMeanFunction(torch.autograd.Function):
+class EmbedMeanFunction(TagFunction):
     """embed_mean with direct gradients (StrongRunner): the table gradient is scattered straight into the (zeroed)
     flat-gradient rows; same kernels as torch.ops.tag.embed_mean."""
 
@@ -1357,7 +1395,7 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gnorm_sq=None, max_norm=0
          float(max_norm), float(grad_scale))
 
 
-class Seq2SeqAttentionFunction(torch.autograd.Function):
+class Seq2SeqAttentionFunction(TagFunction):
     """Seq2SeqAttention.forward (models/cross_encoder.py:11-42): additive attention of every query row over the key/value
     rows, ``score[b,q,k] = v . tanh(W [query_q ; kv_k] + b)``, the two -1e10 mask fills, softmax over k, ``out = attn @ kv``.
     The reference materialises the (B, Lq*Lk, Dq+Dkv) concatenation; here ``W = [Wq | Wk]`` is applied as two MFMA GEMMs and
@@ -1411,7 +1449,7 @@ class Seq2SeqAttentionFunction(torch.autograd.Function):
         return (da, dkv, None, None, *g)
 
 
-class CrossGatingFunction(torch.autograd.Function):
+class CrossGatingFunction(TagFunction):
     """CrossGating.forward (models/cross_encoder.py:45-57): ``s_out = s * sigmoid(fc_u(u))``, ``u_out = u * sigmoid(fc_s(s))``
     -- two MFMA GEMMs with the sigmoid epilogue + tag_mul / tag_gate_backward.  u, s (..., D) -> (u_out, s_out)."""
 
@@ -1456,7 +1494,7 @@ class CrossGatingFunction(torch.autograd.Function):
         return (da, dcx, *g)
 
 
-class CrossAttentionHeadFunction(torch.autograd.Function):
+class CrossAttentionHeadFunction(TagFunction):
     """match.CrossAttention (models/match.py:63-88): nn.MultiheadAttention(E, H, p, batch_first, kdim = vdim = kvdim) of every
     audio frame over the phrase tokens, ``audio + dropout(out)``, LayerNorm, Linear(E,1), sigmoid -> (B,T).
     params = (wq (E,E), wk (E,Dk), wv (E,Dk), in_proj_bias (3E), out_proj.weight, out_proj.bias, norm.weight, norm.bias,
@@ -1530,7 +1568,7 @@ class CrossAttentionHeadFunction(torch.autograd.Function):
         return (da, dt.view(B, L, Dk), None, None, None, None, *grads)
 
 
-class RowDotFunction(torch.autograd.Function):
+class RowDotFunction(TagFunction):
     """match.DotProduct with text_level='token' after a cross-encoder: one text vector per frame (models/match.py:43-60)."""
 
     @staticmethod
@@ -1552,7 +1590,7 @@ class RowDotFunction(torch.autograd.Function):
         return da, dt, None
 
 
-class RowPairFunction(torch.autograd.Function):
+class RowPairFunction(TagFunction):
     """Either head with text_level='token' in general (models/match.py:16-33, 43-60): text (B,T,D) holds one vector per frame.
     kind 0 = DotProduct, 1 = ExpNegL2; optional F.normalize of both operands."""
 
@@ -1575,7 +1613,7 @@ class RowPairFunction(torch.autograd.Function):
         return da, dt, None, None, None
 
 
-class MatchGroupFunction(torch.autograd.Function):
+class MatchGroupFunction(TagFunction):
     """DotProduct head of MultiTextBiEncoder (models/audio_text_model.py:150-190): N phrases per clip scored against the
     same audio embedding.  audio (B,T,D), text (B*N,D) -> sim (B*N,T)."""
 
@@ -1601,7 +1639,7 @@ class MatchGroupFunction(torch.autograd.Function):
         return da, dt, None, None
 
 
-class LinearSoftmaxPoolFunction(torch.autograd.Function):
+class LinearSoftmaxPoolFunction(TagFunction):
     """linear_softmax_with_lens (models/utils.py:75-76): rows (R,T) of frame probabilities -> (R,), row r uses
     length[r // group]."""
 
@@ -1624,7 +1662,7 @@ class LinearSoftmaxPoolFunction(torch.autograd.Function):
         return dfs, None, None
 
 
-class MeanMeanPoolFunction(torch.autograd.Function):
+class MeanMeanPoolFunction(TagFunction):
     """sim_pooling.AudioMeanTextMean (models/sim_pooling.py:6-22): (B,B,T,N) -> (B,B)."""
 
     @staticmethod
@@ -1646,7 +1684,7 @@ class MeanMeanPoolFunction(torch.autograd.Function):
         return dsim, None, None
 
 
-class AttnPoolFunction(torch.autograd.Function):
+class AttnPoolFunction(TagFunction):
     """AttentionPooling (models/text_encoder.py:46-58): softmax(fc(x)) over the valid tokens, weighted sum -> (B,D)."""
 
     @staticmethod
@@ -1674,7 +1712,7 @@ class AttnPoolFunction(torch.autograd.Function):
         return dx, None, g[0], g[1]
 
 
-class UpsampleLinearFunction(torch.autograd.Function):
+class UpsampleLinearFunction(TagFunction):
     """F.interpolate(x.unsqueeze(1), T * ratio, mode="linear", align_corners=False).squeeze(1) on (R,T) frame scores."""
 
     @staticmethod
@@ -1694,7 +1732,7 @@ class UpsampleLinearFunction(torch.autograd.Function):
         return dx, None
 
 
-class GroupExpandFunction(torch.autograd.Function):
+class GroupExpandFunction(TagFunction):
     """(B, ...) -> (B*N, ...): every clip's rows repeated for its N phrases (MultiTextBiEncoder with a cross-encoder,
     models/audio_text_model.py:165-168); backward sums the N copies in a fixed order."""
 
@@ -1716,7 +1754,7 @@ class GroupExpandFunction(torch.autograd.Function):
         return dx, None
 
 
-class SimPoolFunction(torch.autograd.Function):
+class SimPoolFunction(TagFunction):
     """General similarity pooling (tag_sim_pool_*): sim (R,T,N) -> (R) or, with tmode = -1, (R,N).
     amode 0 mean / 1 max / 2 linear_softmax / 3 exp_softmax over the frames < alen[r // a_div];
     tmode 0 mean / 1 sum / 2 max / 3 mean+sum over the tokens < tlen[r % t_mod]."""
@@ -1746,7 +1784,7 @@ POOL_MODES = {"mean": 0, "max": 1, "linear_softmax": 2, "exp_softmax": 3}
 TEXT_MODES = {"mean": 0, "sum": 1, "max": 2, "mean_sum": 3}
 
 
-class MaxMarginFunction(torch.autograd.Function):
+class MaxMarginFunction(TagFunction):
     """MaxMarginRankingLoss (losses.py:226-264) on an (n,n) similarity matrix; fix_norm drops the diagonal pairs."""
 
     @staticmethod

@@ -52,6 +52,8 @@ class FlatParams:
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
             p._tag_grad_sink = p.grad
+            if getattr(p, "_tag_guard_hook", None) is None:       # one hook per parameter however often a runner is rebuilt
+                p._tag_guard_hook = p.register_hook(ops.second_writer_guard(p))
             off += k
         self.numel = n
 

@@ -91,6 +91,160 @@ def cpu_baseline(batch=16, iters=5):
                               "sample": f"same step, B=2, median of {iters} after 1 warm-up"}}
 
 
+def families(prof):
+    """ops.PROFILE (key -> [(start event, end event, algorithmic FLOP)]) folded per kernel family."""
+    fam = {}
+    for key, evs in prof.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        fl = sum(f for _, _, f in evs)
+        d = fam.setdefault(key[0], {"ms": 0.0, "flop": 0.0, "launches": 0})
+        d["ms"] += ms; d["flop"] += fl; d["launches"] += len(evs)
+    return fam
+
+
+def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
+    """`roofline` object of the dominant MFMA kernel family of a timed leg: achieved = sum of the algorithmic FLOP of its
+    launches / sum of their HIP-event durations (events on the launch stream).  mode = "fp32" | "bf16" selects the committed PMC
+    traffic profile (profiles/r*_pmc_hbm_traffic_<mode>.json); the profile is only quoted when it was collected on the kernel
+    sources this library was built from (csrc sha256)."""
+    if not fam:
+        return None
+    dom = max(fam, key=lambda k: fam[k]["flop"])
+    ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
+    iso = fam_iso[dom]["flop"] / (fam_iso[dom]["ms"] * 1e-3) / 1e12
+    # HBM bytes per launch of the dominant family: PMC counters cannot be collected from inside this process, so the
+    # figure is read from the committed profile of the SAME command (tools/collect_profiles.sh: two separate --pmc passes,
+    # FETCH_SIZE x2 + WRITE_SIZE) and labelled with where and when it was collected -- it is offline data.
+    traffic, traffic_src = None, None
+    from texttoaudiogrounding_amd.lib import csrc_sha256
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{mode}.json")), reverse=True)
+    if not cands or conv_math not in ("fp32", "bf16"):
+        traffic_src = {"reason": "no PMC traffic profile for this arithmetic under profiles/"}
+    else:
+        tj = json.load(open(cands[0]))
+        meta = tj.pop("_meta", {})
+        tname = os.path.basename(cands[0])
+        if meta.get("csrc_sha256") != csrc_sha256():
+            # a profile of OTHER kernel sources says nothing about this build: no number rather than a stale one
+            traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
+                           "reason": "profile was collected on different kernel sources (csrc sha256 "
+                                     f"{str(meta.get('csrc_sha256'))[:12]} != built {csrc_sha256()[:12]}); re-run "
+                                     "tools/collect_profiles.sh"}
+        else:
+            rows = [v for k, v in tj.items() if k.startswith(dom)]
+            n = sum(v["launches_in_run"] for v in rows)
+            if n:
+                traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
+                                    for v in rows) / n, 3)
+                traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
+                               "csrc_sha256": meta.get("csrc_sha256"), "measured_in_this_run": False,
+                               "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
+                               "algorithmic_lower_bound_GB_per_step": round((0.082 if mode == "bf16" else 0.164) * batch, 2)}
+    # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
+    nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(conv_math, 6.0)
+    peak = PEAK_FP32_MFMA if not dom.startswith("conv3x3_x3") and not dom.startswith("conv3x3_pc") else round(2500.0 / nprod, 1)
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC, offline profile)",
+            "traffic_source": traffic_src,
+            "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
+            "launches_per_step": fam[dom]["launches"] // steps,
+            "streams": "overlapped (wgrad on a side stream)" if overlap else "single",
+            "isolated_achieved": round(iso, 2), "isolated_frac": round(iso / peak, 4),
+            "isolated_avg_launch_ms": round(fam_iso[dom]["ms"] / fam_iso[dom]["launches"], 4),
+            "families_isolated": {k: {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                      "ms_per_step": round(v["ms"] / steps, 3)} for k, v in fam_iso.items()}}
+
+
+def build_workload(name, device):
+    """The models of the secondary workloads, on the same kernels as the contract's (DESIGN.md sections 9-10)."""
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
+    if name == "crnn":
+        return audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(32000, 256), text_encoder.EmbeddingAgg(5221, 256),
+                                          match.ExpNegL2(), 256)
+    if name == "cross_attention":
+        return audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                          match.CrossAttention(512, 8, 0.1), 512)
+    if name == "cross_encoder":
+        from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
+        return audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                          match.DotProduct(text_level="token"), 512, cross_encoder=CrossAttentionGating(512))
+    return audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
+                                      match.DotProduct(), 512)
+
+
+WORKLOAD_TEXT = {
+    "cross_encoder": "configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + CrossAttentionGating(512) + match.DotProduct(token), "
+                     "fwd+bwd+clip+Adam, B=64 x 10 s",
+    "cross_attention": "configs[3]: biencoder Cnn8Rnn + EmbeddingAgg(512) + match.CrossAttention(512, 8 heads, p 0.1), "
+                       "fwd+bwd+clip+Adam, B=64 x 10 s",
+    "crnn": "strong eg_config as written (cdur_w2vmean.yaml): CrnnEncoder(256) + EmbeddingAgg(256) + match.ExpNegL2, "
+            "fwd+bwd+clip+Adam, B=64 x 10 s",
+    "infer_30s_b256": "configs[4]: Cnn8Rnn + LAION-CLAP text tower (RoBERTa-base shape, random init) + audio/text proj + "
+                      "DotProduct, forward only, B=256 x 30 s @ 32 kHz, 8-token phrases",
+}
+
+
+def other_workloads(args, device, log, budget_s=5.0):
+    """BASELINE configs[3] (both heads), the strong eg_config's CrnnEncoder and configs[4]'s 30 s inference, each timed for a
+    bounded number of steps (<= ~5 s each) on the same device after the contract's legs; reported BESIDE `value`, never as it.
+    fp32 (exact MFMA) like `value`."""
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    res = {}
+    for name in ("cross_encoder", "cross_attention", "crnn"):
+        torch.manual_seed(0)
+        runner = StrongRunner(build_workload(name, device), lr=1e-3, max_grad_norm=1.0, device=str(device))
+        batch = synthetic_batch(args.batch, 320000, 1234, device)
+        for _ in range(2):
+            runner.train_step(dict(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.train_step(dict(batch))
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        k = max(3, min(args.steps, int(budget_s / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(k):
+            loss = runner.train_step(dict(batch))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = {"workload": WORKLOAD_TEXT[name], "value": round(args.batch * k / dt, 2), "unit": "clips/s",
+                     "ms_per_step": round(dt / k * 1e3, 3), "steps": k, "dtype": "f32", "loss": round(runner.loss_value(loss), 6)}
+        log(f"other workload {name}: {res[name]['value']} clips/s")
+        del runner
+        torch.cuda.empty_cache()
+    # configs[4]: inference, 30 s clips, batch 256 (models/hf_modeling_grounding.py:319-352 of the reference)
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import Cnn8RnnLaionClapGroundingModel
+    torch.manual_seed(0)
+    B, tokens = 256, 8
+    model = Cnn8RnnLaionClapGroundingModel().to(device).eval()
+    g = torch.Generator(device=device).manual_seed(1234)
+    audio = 0.1 * torch.randn(B, 960000, device=device, generator=g)
+    audio_len = torch.full((B,), 960000)
+    ids = torch.randint(3, 50265, (B, tokens), device=device, generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    text = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    model(audio, audio_len, text)
+    torch.cuda.synchronize()
+    k = 3
+    t0 = time.perf_counter()
+    for _ in range(k):
+        fs = model(audio, audio_len, text)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(k):
+        model.model.text_encoder(text)
+    torch.cuda.synchronize()
+    dtt = time.perf_counter() - t1
+    res["infer_30s_b256"] = {"workload": WORKLOAD_TEXT["infer_30s_b256"], "value": round(B * k / dt, 2), "unit": "clips/s",
+                             "ms_per_step": round(dt / k * 1e3, 2), "steps": k, "dtype": "f32", "frame_sim_shape": list(fs.shape),
+                             # forward of a 30 s clip = 3 x 33.90 GFLOP (T' = 750) -- numerically FLOP_PER_CLIP
+                             "whole_forward_mfma_frac": round(B * k / dt * 3 * 33.90e9 / 1e12 / PEAK_FP32_MFMA, 4),
+                             "text_tower_ms_per_batch": round(dtt / k * 1e3, 2)}
+    log(f"other workload infer_30s_b256: {res['infer_30s_b256']['value']} clips/s")
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks on this node
     (one process per GPU, rendezvous on 127.0.0.1); the child rank 0 prints the JSON line on the inherited stdout."""
@@ -142,10 +296,18 @@ def main():
                     help="N > 1: time ONLY the gradient buckets' all-reduces (fp32 and bf16 payload), nothing else, and print "
                          "that as the JSON line (diagnosis of a scaling run; not the contract's metric)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the `other_workloads` block (configs[3] cross-encoder / cross-attention, the strong eg_config's "
+                         "CrnnEncoder, configs[4] 30 s inference at batch 256: a few seconds each, never `value`)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE configs[2] as a mode: bf16 conv arithmetic (fp32 accumulate) + bf16 storage of the conv "
-                         "stack's activations and gradients + bf16 all-reduce payload; fp32 BatchNorm statistics / GRU / heads "
+                         "stack's activations and gradients (the all-reduce payload stays fp32 unless --grad-wire bf16); fp32 BatchNorm statistics / GRU / heads "
                          "/ loss / master weights.  The default (and the contract's `value`) is fp32")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
+                    help="payload of the gradient all-reduce.  fp32 (default, also with --dtype bf16): the 35 MB of a step hide "
+                         "under the remaining backward on xGMI, and the collective then sums in fp32.  bf16 halves the bytes but "
+                         "the collective sums in bf16 (rms error ~ sqrt(N) * 2^-9): switch only when `comm.exposed_ms_per_step` "
+                         "of a scaling run shows exposed communication")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "x3", "x9", "bf16"],
                     help="arithmetic of the 3x3 conv forward/dgrad kernels of the TIMED run: fp32 = exact fp32 MFMA "
                          "(the contract's number); x3 = opt-in 3 x bf16 split on the bf16 MFMA (conv_x3.hip)")
@@ -168,22 +330,10 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     torch.manual_seed(0)
-    if args.crnn:
-        model = audio_text_model.BiEncoder(audio_encoder.CrnnEncoder(32000, 256), text_encoder.EmbeddingAgg(5221, 256),
-                                           match.ExpNegL2(), 256)
-    elif args.cross_attention:
-        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
-                                           match.CrossAttention(512, 8, 0.1), 512)
-    elif args.cross_encoder:
-        from texttoaudiogrounding_amd.models.cross_encoder import CrossAttentionGating
-        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
-                                           match.DotProduct(text_level="token"), 512,
-                                           cross_encoder=CrossAttentionGating(512))
-    else:
-        model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000), text_encoder.EmbeddingAgg(5221, 512),
-                                           match.DotProduct(), 512)
+    model = build_workload("crnn" if args.crnn else "cross_attention" if args.cross_attention else
+                           "cross_encoder" if args.cross_encoder else "biencoder", device)
     runner = StrongRunner(model, lr=1e-3, max_grad_norm=1.0, device=str(device),
-                          grad_comm_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+                          grad_comm_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
     batch = synthetic_batch(args.batch, 320000, 1234 + rank, device)
 
     def sync():
@@ -269,15 +419,6 @@ def main():
     # the launch stream over the timed region.  The timed region runs the weight-gradient convs on a second stream
     # (they overlap the dgrad/BatchNorm chain), which stretches every overlapped kernel's own start-to-end time;
     # a second, untimed pass of the same K steps with that overlap switched off gives the isolated kernel rate.
-    def families(prof):
-        fam = {}
-        for key, evs in prof.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-            fl = sum(f for _, _, f in evs)
-            d = fam.setdefault(key[0], {"ms": 0.0, "flop": 0.0, "launches": 0})
-            d["ms"] += ms; d["flop"] += fl; d["launches"] += len(evs)
-        return fam
-
     fam = families(prof)
     overlap = ops.WGRAD_SIDE_STREAM
     fam_iso = fam
@@ -305,94 +446,70 @@ def main():
             ops.ACT_DTYPE = "bf16" if mode == "bf16" else "fp32"
             runner.train_step(dict(batch))
             sync()
+            ops.PROFILE = {} if mode == "bf16" else None          # the bf16 mode gets its own roofline (events as in the main leg)
             ta = time.perf_counter()
             for _ in range(args.steps):
                 runner.train_step(dict(batch))
             sync()
             dta = time.perf_counter() - ta
+            prof_a, ops.PROFILE = ops.PROFILE, None
             if world > 1:
                 t = torch.tensor([dta], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dta = t.item()
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
+            if mode == "bf16":
+                fam_a = fam_a_iso = families(prof_a)
+                if overlap:                                       # isolated kernel rate: the same steps, wgrad convs in line
+                    ops.WGRAD_SIDE_STREAM = False
+                    ops.PROFILE = {}
+                    for _ in range(args.steps):
+                        runner.train_step(dict(batch))
+                    sync()
+                    fam_a_iso, ops.PROFILE = families(ops.PROFILE), None
+                    ops.WGRAD_SIDE_STREAM = True
+                alt[mode]["whole_step_mfma_frac"] = round(clips / dta / world * FLOP_PER_CLIP / 1e12 / 2500.0, 4)
+                alt[mode]["roofline"] = roofline_of(fam_a, fam_a_iso, args.steps, "bf16", "bf16", args.batch, overlap)
         ops.CONV_MATH = "fp32"
         ops.ACT_DTYPE = "fp32"
-    dom = max(fam, key=lambda k: fam[k]["flop"]) if fam else None
-    roof = None
-    if dom:
-        ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
-        iso = fam_iso[dom]["flop"] / (fam_iso[dom]["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant family: PMC counters cannot be collected from inside this process, so the
-        # figure is read from the committed profile of the SAME command (tools/collect_profiles.sh: two separate --pmc passes,
-        # FETCH_SIZE x2 + WRITE_SIZE) and labelled with where and when it was collected -- it is offline data.
-        traffic, traffic_src = None, None
-        from texttoaudiogrounding_amd.lib import csrc_sha256
-        mode = "bf16" if args.dtype == "bf16" else "fp32"
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{mode}.json")), reverse=True)
-        if not cands or args.conv_math not in ("fp32", "bf16"):
-            traffic_src = {"reason": "no PMC traffic profile for this arithmetic under profiles/"}
-        else:
-            tj = json.load(open(cands[0]))
-            meta = tj.pop("_meta", {})
-            tname = os.path.basename(cands[0])
-            if meta.get("csrc_sha256") != csrc_sha256():
-                # a profile of OTHER kernel sources says nothing about this build: no number rather than a stale one
-                traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
-                               "reason": "profile was collected on different kernel sources (csrc sha256 "
-                                         f"{str(meta.get('csrc_sha256'))[:12]} != built {csrc_sha256()[:12]}); re-run "
-                                         "tools/collect_profiles.sh"}
-            else:
-                rows = [v for k, v in tj.items() if k.startswith(dom)]
-                n = sum(v["launches_in_run"] for v in rows)
-                if n:
-                    traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]
-                                        for v in rows) / n, 3)
-                    traffic_src = {"file": f"profiles/{tname}", "collected_utc": meta.get("collected_utc"),
-                                   "csrc_sha256": meta.get("csrc_sha256"), "measured_in_this_run": False,
-                                   "whole_step_GB": round(meta.get("fetch_GB_per_step", 0) + meta.get("write_GB_per_step", 0), 2),
-                                   "algorithmic_lower_bound_GB_per_step": round((0.082 if args.dtype == "bf16" else 0.164)
-                                                                                * args.batch, 2)}
-        # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
-        nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(args.conv_math, 6.0)
-        peak = PEAK_FP32_MFMA if dom != "conv3x3_x3_kernel" else round(2500.0 / nprod, 1)
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC, offline profile)",
-                "traffic_source": traffic_src,
-                "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
-                "launches_per_step": fam[dom]["launches"] // args.steps,
-                "streams": "overlapped (wgrad on a side stream)" if overlap else "single",
-                "isolated_achieved": round(iso, 2), "isolated_frac": round(iso / peak, 4),
-                "isolated_avg_launch_ms": round(fam_iso[dom]["ms"] / fam_iso[dom]["launches"], 4),
-                "families_isolated": {k: {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                          "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in fam_iso.items()}}
+    loss_value = round(runner.loss_value(loss), 6)
+    roof = roofline_of(fam, fam_iso, args.steps, "bf16" if args.dtype == "bf16" else "fp32", args.conv_math, args.batch, overlap)
+    others = None
+    main_wl = not (args.crnn or args.cross_attention or args.cross_encoder)
+    if world == 1 and main_wl and args.conv_math == "fp32" and not args.no_others:
+        del runner, model
+        torch.cuda.empty_cache()
+        others = other_workloads(args, device, log)
     comm_only_res = comm_only() if world > 1 else None        # every rank takes part; a few ms
     if rank == 0:
         out = {"metric": "clips/sec (10 s@32 kHz, 1-phrase) fwd+bwd", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
-               "dtype": ("bf16 (conv arithmetic + activation storage + all-reduce payload; f32 accumulate, statistics, GRU, "
-                         "heads, master weights)" if args.dtype == "bf16" else
+               "dtype": ("bf16 (conv arithmetic + activation storage; f32 accumulate, statistics, GRU, heads, master weights, "
+                         f"{args.grad_wire} all-reduce payload)" if args.dtype == "bf16" else
                          {"fp32": "f32", "bf16": "bf16 conv operands, f32 accumulate, f32 elsewhere"}.get(
                              args.conv_math, "f32 (conv products as 3 x bf16 split, f32 accumulate)")),
                "data": "synthetic",
                "config": {"workload": workload_name(args), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math},
-               "loss": round(runner.loss_value(loss), 6),
+               "loss": loss_value,
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /
                                              (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4),
                "roofline": roof}
         if alt:
             out["alt_conv_math"] = alt
+        if others:
+            out["other_workloads"] = others
         out["ranks_observed"] = dist.get_world_size() if world > 1 else 1
         out["backend"] = dist.get_backend() if world > 1 else None
         if world > 1:
             out["comm"] = {"collective": "all-reduce(sum) of the flat fp32 gradient in buckets, launched from inside backward",
                            "buckets_MB": [round((e - s0) * 4 / 2 ** 20, 2) for (s0, e, _, _) in runner.buckets.bounds],
                            "overlap": runner.overlap_comm,
-                           "payload": "bf16" if args.dtype == "bf16" else "fp32",
+                           "payload": args.grad_wire,
                            # rank 0's events over the timed region: each bucket's all-reduce start->end on the communication
                            # stream (includes waiting for slower ranks to arrive) and the time the compute stream spent blocked
                            # on the communication stream at the end of backward (= communication NOT hidden under compute)

@@ -25,7 +25,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("extra", [[], ["--dtype", "bf16"]], ids=["fp32", "bf16mode"])
+@pytest.mark.parametrize("extra", [[], ["--dtype", "bf16"], ["--dtype", "bf16", "--grad-wire", "bf16"]],
+                         ids=["fp32", "bf16mode", "bf16mode_bf16wire"])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` with no launcher in the environment must spawn 2 ranks and print ONE JSON line -- for the
     contract's fp32 workload and for BASELINE configs[2] as a mode (bf16 arithmetic / storage / all-reduce payload)."""
@@ -46,11 +47,37 @@ def test_bench_launches_its_own_ranks(extra):
     # RCCL path: None under gloo) and the collectives timed alone for both payload types
     comm = out["comm"]
     assert {"bucket_ms_in_step", "exposed_ms_per_step", "comm_only", "payload"} <= set(comm)
-    assert comm["payload"] == ("bf16" if extra else "fp32")
+    assert comm["payload"] == ("bf16" if "--grad-wire" in extra else "fp32")      # fp32 wire by default, also in the bf16 mode
     for kind in ("fp32", "bf16"):
         leg = comm["comm_only"][kind]
         assert leg["ms_per_step"] > 0 and len(leg["bucket_ms"]) == len(comm["buckets_MB"]) and leg["payload_MB"] > 0
     assert abs(comm["comm_only"]["fp32"]["payload_MB"] - 2 * comm["comm_only"]["bf16"]["payload_MB"]) < 0.1
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """First contact with 8 ranks, as far as one GPU allows: `python bench.py --gpus 8 --batch 4` (BASELINE configs[2]'s mode)
+    self-launches 8 processes that all bind cuda:0 (TAG_SHARE_GPU) and exchange through gloo -- launcher, rank -> device mapping,
+    parameter broadcast to 8 replicas, 8 hosts enqueueing the cooperative GRU kernels and the side-stream wgrads into one device,
+    bucketed exchange from inside backward, the comm block of the JSON line."""
+    env = dict(os.environ, TAG_DIST_BACKEND="gloo", TAG_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--no-cpu-baseline", "--no-alt", "--dtype", "bf16"], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_observed"] == 8 and out["config"]["global_batch"] == 32
+    assert out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak" and out["value"] > 0
+    comm = out["comm"]
+    assert comm["payload"] == "fp32" and comm["overlap"] is True and len(comm["buckets_MB"]) >= 3
+    for kind in ("fp32", "bf16"):
+        leg = comm["comm_only"][kind]
+        assert leg["ms_per_step"] > 0 and len(leg["bucket_ms"]) == len(comm["buckets_MB"])
+    import math
+    assert math.isfinite(out["loss"])
 
 
 def test_bench_comm_only_leg():

@@ -166,9 +166,10 @@ def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
                                                 (2, 500, 32, 128, 128, 1), (2, 250, 16, 128, 256, 0),
                                                 (2, 250, 16, 256, 256, 1), (2, 250, 8, 256, 512, 0),
                                                 (3, 250, 8, 512, 512, 1)])
-def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
-    """Opt-in arithmetic (conv_x3.hip): fp32 operands split exactly into 3 bf16 terms, 6 partial products on the bf16
-    MFMA, fp32 accumulate -- held to the SAME tolerance against fp64 as the exact-fp32 kernels."""
+@pytest.mark.parametrize("math_", ["x3", "x9"])
+def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro, math_):
+    """Opt-in arithmetic (conv_x3.hip): fp32 operands split exactly into 3 bf16 terms, 6 ("x3") or all 9 ("x9") partial
+    products on the bf16 MFMA, fp32 accumulate -- held to the SAME tolerance against fp64 as the exact-fp32 kernels."""
     g = torch.Generator().manual_seed(B * 1000 + H + W)
     x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))   # wide dynamic range
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
@@ -180,7 +181,7 @@ def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
     dy = torch.randn(y_ref.shape, generator=g)
     da_ref = torch.nn.grad.conv2d_input(a.shape, w.double(), dy.double(), 1, 1)
     old = ops.CONV_MATH
-    ops.CONV_MATH = "x3"
+    ops.CONV_MATH = math_
     try:
         wf, wdg = ops.pack_conv_weight(w.to(dev), W=W)
         assert wf.dtype == torch.uint8
@@ -201,13 +202,14 @@ def test_conv3x3_x3_forward_dgrad(ops, dev, B, H, W, Cin, Cout, pro):
     # what the exact-fp32 kernel gives on the same data
     pf, _ = ops.pack_conv_weight(w.to(dev))
     e_32 = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), pf, Cout, pro, sd, td)), y_ref)
-    print(f"x3 conv {B}x{H}x{W} {Cin}->{Cout} pro {pro}: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e})"
+    print(f"{math_} conv {B}x{H}x{W} {Cin}->{Cout} pro {pro}: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e})"
           + (f", dgrad err {e_d:.2e}" if e_d is not None else "") + (f", wgrad err {e_w:.2e}" if e_w is not None else ""))
     assert e_f < 5e-6 and (e_d is None or e_d < 5e-6) and (e_w is None or e_w < 5e-6)
 
 
-def test_conv3x3_x3_extreme_dynamic_range(ops, dev):
-    """x3 arithmetic with operands spanning 16 orders of magnitude across channels (1e-8 ... 1e+8): the exact 3-way bf16
+@pytest.mark.parametrize("math_", ["x3", "x9"])
+def test_conv3x3_x3_extreme_dynamic_range(ops, dev, math_):
+    """x3 / x9 arithmetic with operands spanning 16 orders of magnitude across channels (1e-8 ... 1e+8): the exact 3-way bf16
     split keeps fp32 accuracy wherever fp32 itself does (bf16 has fp32's exponent range)."""
     B, H, W, Cin, Cout = 2, 33, 16, 128, 128
     g = torch.Generator().manual_seed(99)
@@ -218,9 +220,10 @@ def test_conv3x3_x3_extreme_dynamic_range(ops, dev):
     y_ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1)
     old = ops.CONV_MATH
-    ops.CONV_MATH = "x3"
+    ops.CONV_MATH = math_
     try:
         wf, _ = ops.pack_conv_weight(w.to(dev), W=W)
+        assert wf.products == (6 if math_ == "x3" else 9)
         e_f = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), wf, Cout)), y_ref)
         dw = ops.conv3x3_wgrad(nhwc(x).to(dev), nhwc(dy).to(dev))
     finally:
@@ -229,7 +232,7 @@ def test_conv3x3_x3_extreme_dynamic_range(ops, dev):
     e_32 = relerr(nchw(ops.conv3x3(nhwc(x).to(dev), pf, Cout)), y_ref)
     # weight gradients span the same 16 decades: compare per input channel
     e_w = ((dw.cpu().double() - dw_ref).abs().amax(dim=(0, 2, 3)) / dw_ref.abs().amax(dim=(0, 2, 3))).max().item()
-    print(f"x3 extreme range: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e}), wgrad per-channel err {e_w:.2e}; "
+    print(f"{math_} extreme range: fwd err {e_f:.2e} (exact-fp32 kernel {e_32:.2e}), wgrad per-channel err {e_w:.2e}; "
           f"operand scales {sc.min().item():.1e} .. {sc.max().item():.1e}")
     assert e_f < 5e-6 and e_w < 5e-6
 

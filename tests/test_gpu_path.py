@@ -72,10 +72,11 @@ def assert_grad_close(name, err, floor):
         assert err <= 4.0 * max(floor, 1e-6), (name, err, floor)
 
 
-@pytest.fixture(params=["fp32", "x3"])
+@pytest.fixture(params=["fp32", "x3", "x9"])
 def conv_math(request):
-    """Both arithmetics of the 3x3 convolutions: exact fp32 MFMA (default) and the opt-in 3 x bf16 split (conv_x3.hip);
-    the assertions (tolerances) are the same for both."""
+    """The fp32-accurate arithmetics of the 3x3 convolutions: exact fp32 MFMA (default) and the opt-in 3 x bf16 split
+    (conv_x3.hip) with 6 partial products ("x3") or all 9 ("x9": every partial product exact); the assertions (tolerances)
+    are the same for all of them."""
     from texttoaudiogrounding_amd import ops
     old = ops.CONV_MATH
     ops.CONV_MATH = request.param
@@ -452,7 +453,8 @@ def test_full_length_train_step_vs_oracle(dev):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name
 
 
-def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch):
+@pytest.mark.parametrize("math_", ["fp32", "x9"])
+def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_):
     """Parity AT THE BENCHED SIZE (BASELINE configs[1]: B = 64, 10 s clips, train-mode BatchNorm, dropout ON) -- the grids
     where the XCD remap, 3-workgroup/CU residency, split-K counts and the 128-workgroup persistent GRU actually live.
     tests/golden/b64_train_step.npz holds the CPU oracle's fp64 step (truth) and its own fp32 step (the noise floor of
@@ -468,6 +470,8 @@ def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch):
     assert np.allclose(chk, gold["input_checksum"], rtol=1e-9), "seeded inputs drifted from the fixture"
     seeds = iter(int(v) for v in gold["dropout_seeds"])
     monkeypatch.setattr(ops, "new_seed", lambda: next(seeds))
+    # "x9" (round 4): the all-nine-products split arithmetic is held to the SAME bounds as the exact-fp32 MFMA kernels
+    monkeypatch.setattr(ops, "CONV_MATH", math_)
     model = build_hip_model(st, "dot", dev).train()
     runner = StrongRunner(model, device=str(dev))
     loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})

@@ -110,3 +110,27 @@ def test_conv3x3_bn_relu_pool_operator_opcheck(dev):
     assert torch.equal(rm, torch.zeros_like(rm))                 # functional: the inputs are not mutated
     out = torch.ops.tag.conv3x3_bn_relu_pool(*args)
     assert out[0].shape == (2, 3, 4, 64) and not torch.equal(out[6], rm)
+
+
+@pytest.mark.parametrize("case", ["rank1", "rank2", "rank3"])
+def test_embedding_layer_forward_standalone(dev, golden_dir, case):
+    """``EmbeddingLayer.forward`` on its own (models/text_encoder.py:39-43; round 3 raised here): tokens of any rank, padding
+    and repeated ids, output bit-equal to the imported reference's lookup and the table gradient (a deterministic gather) equal
+    to its fp64 twin -- tests/golden/embedding_layer.npz (make_golden_embedding.py)."""
+    from tests.golden import make_golden_embedding as E
+    from texttoaudiogrounding_amd.models.text_encoder import EmbeddingLayer
+    gold = np.load(f"{golden_dir}/embedding_layer.npz")
+    m = E.make_layer(EmbeddingLayer)
+    assert np.allclose(E.checksum(m.core.weight.detach()), gold["table_checksum"], rtol=1e-12), "seeded table drifted"
+    m = m.to(dev)
+    t, dout = E.tokens(case)
+    out = m({"text": t.int()})                                   # host ids, int32: cast like the reference's .long()
+    assert tuple(out.shape) == E.CASES[case] + (E.D,)
+    assert np.array_equal(out.detach().cpu().numpy(), gold[f"{case}/out"])         # a gather: bit-exact
+    out.backward(dout.to(dev))
+    err = close(m.core.weight.grad, gold[f"{case}/dtable_f64"])
+    assert err < 1e-6, err
+    with pytest.raises(IndexError):                              # nn.Embedding raises on an id outside the table
+        m({"text": torch.tensor([0, E.V])})
+    out2 = m({"text": t.to(dev)})                                # device-resident ids take the same path
+    assert torch.equal(out2, out)

@@ -119,8 +119,14 @@ size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout);
 int tag_pack_conv_weight_x3(const float* w /*(Cout,Cin,3,3)*/, void* wfwd, void* wdgrad, int Cin, int Cout,
                             int products, void* stream);
 int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout);
-/* the same for the bf16-storage entry points (*_x3_bf16, tag_conv3x3_dgrad_bnsums_bf16): their 64-cout layers use 256-pixel tiles */
-int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cout);      /* same contract as tag_conv3x3_stats_rows */
+/* the same for the bf16-storage entry points (tag_conv3x3_forward_x3_bf16 with this Cin / prologue; tag_conv3x3_dgrad_bnsums_bf16:
+ * prologue 0).  Layers with Cin <= 128 run on the row-streaming kernel (csrc/conv_rows.hip: weights stationary in registers,
+ * input rows by LDS-DMA into a ring) whose statistics accumulate over a whole strip of rows: one partial row per (strip, wave
+ * M-group); the other layers write one row per tile M-group of the tile kernel.  (ABI 2: Cin and prologue were added.) */
+int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cin, int Cout, int prologue);
+/* 0: keep every bf16-storage layer on the tile kernel (A/B timing, tools/conv_rows_bench.py); returns the previous setting.
+ * The environment variable TAG_CONV_ROWS=0 is the process-wide form. */
+int tag_conv_rows_enable(int on);
 int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                            const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
                            int products, void* stream);

@@ -278,7 +278,11 @@ def ulp_bf16(ref):
 @pytest.mark.parametrize("pro", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 32, 64, 64), (1, 17, 16, 64, 128), (2, 250, 8, 256, 512), (2, 37, 64, 64, 64),
                                             (2, 500, 32, 128, 128), (2, 250, 16, 128, 256), (1, 19, 16, 256, 256),
-                                            (1, 33, 32, 64, 256)])
+                                            (1, 33, 32, 64, 256),
+                                            # shapes of the row-streaming kernel (conv_rows.hip): strips of 8+ steps, a strip of
+                                            # 2 steps, two rows per step (dgrad 128 -> 64 at W = 32; W = 16), two n-tiles
+                                            (3, 1001, 64, 64, 64), (1, 2, 64, 64, 64), (2, 64, 32, 64, 128), (2, 40, 32, 64, 128),
+                                            (1, 4, 32, 128, 128), (3, 6, 16, 128, 256), (2, 90, 16, 128, 128)])
 def test_conv3x3_bf16_storage(ops, dev, B, H, W, Cin, Cout, pro):
     """configs[2] storage: bf16 tensors in, bf16 tensors out, fp32 accumulate.  Forward (with / without the producer's
     BN+ReLU folded into the operand load), dgrad and wgrad equal the fp64 convolution of the SAME bf16 operands up to one
@@ -569,7 +573,9 @@ def test_conv_dgrad_fused_bnrelu_backward(ops, dev, B, H, W, Cin, C):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,C", [(2, 9, 8, 64, 128), (1, 17, 16, 128, 64), (2, 21, 32, 64, 64), (2, 33, 64, 64, 64),
-                                         (3, 250, 8, 512, 512), (2, 45, 16, 256, 256)])
+                                         (3, 250, 8, 512, 512), (2, 45, 16, 256, 256),
+                                         # row-streaming kernel (conv_rows.hip), epilogue 2: sums over whole strips
+                                         (2, 1001, 64, 64, 64), (2, 500, 32, 128, 128), (1, 3, 32, 128, 128)])
 def test_conv_dgrad_fused_bnrelu_backward_bf16(ops, dev, monkeypatch, B, H, W, Cin, C):
     """BASELINE configs[2] mode: tag_conv3x3_dgrad_bnsums_bf16 (sums from the fp32 accumulators of the bf16 dgrad conv) +
     tag_bnrelu_backward_apply_bf16 against (a) the unfused bf16 kernels and (b) the fp64 chain on the same bf16 tensors."""

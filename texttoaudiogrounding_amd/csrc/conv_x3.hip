@@ -1017,6 +1017,13 @@ void launch_wgrad_x3_w(const TS* x, int pro, const float* s, const float* t, con
 
 }  // namespace
 
+// conv_rows.hip: the row-streaming kernel that takes the bf16-storage launches of the layers with Cin <= 128
+bool tag_conv_rows_takes(int H, int W, int Cin, int Cout, int prologue);
+int tag_conv_rows_partial_rows(int B, int H, int W, int Cin, int Cout);
+int tag_conv_rows_launch(const bf16_t* x, const void* wpack, int prologue, const float* in_scale, const float* in_shift,
+                         bf16_t* y, float* stats, int epi_kind, const bf16_t* yref, const float* bn_scale, const float* bn_shift,
+                         const float* bn_mean, const float* bn_invstd, int B, int H, int W, int Cin, int Cout, hipStream_t st);
+
 extern "C" size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * 3 * 2; }
 
 extern "C" int tag_pack_conv_weight_x3(const float* w, void* wfwd, void* wdgrad, int Cin, int Cout, int products,
@@ -1036,9 +1043,11 @@ extern "C" int tag_conv3x3_x3_stats_rows(int B, int H, int W, int Cout) {
     return B * ((H + th - 1) / th) * (Cout % 128 == 0 ? 1 : 2);
 }
 
-// rows of the statistics / BatchNorm-backward partials written by the bf16-STORAGE launches (256-pixel tiles on the 64-cout layers)
-extern "C" int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cout) {
+// rows of the statistics / BatchNorm-backward partials written by the bf16-STORAGE launch of this shape: one per (strip, wave
+// M-group) where the row-streaming kernel of conv_rows.hip takes the layer, one per tile M-group of the tile kernel otherwise
+extern "C" int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cin, int Cout, int prologue) {
     if (!(W == 8 || W == 16 || W == 32 || W == 64)) return 0;
+    if (tag_conv_rows_takes(H, W, Cin, Cout, prologue)) return tag_conv_rows_partial_rows(B, H, W, Cin, Cout);
     const int th = (Cout % 128 == 0 ? 128 : 64 * TAG_X3_BF16_MB64) / W;
     return B * ((H + th - 1) / th) * (Cout % 128 == 0 ? 1 : 2);
 }
@@ -1079,6 +1088,13 @@ extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int
     const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
     const bf16_t* xi = static_cast<const bf16_t*>(x);
     bf16_t* yo = static_cast<bf16_t*>(y);
+    if (tag_conv_rows_takes(H, W, Cin, Cout, prologue)) {
+        const int rc = tag_conv_rows_launch(xi, wpack, prologue, in_scale, in_shift, yo, stats, stats ? 1 : 0, nullptr, nullptr,
+                                            nullptr, nullptr, nullptr, B, H, W, Cin, Cout, st);
+        if (rc != 0) return rc;
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
     else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, prologue, in_scale, in_shift, yo, stats, B, H, W, Cin, Cout, st);
     TAG_LAUNCH_CHECK();
@@ -1099,6 +1115,13 @@ extern "C" int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, 
     const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
     const bf16_t* xi = static_cast<const bf16_t*>(dy);
     bf16_t* yo = static_cast<bf16_t*>(da);
+    if (tag_conv_rows_takes(H, W, Cin, Cout, 0)) {
+        const int rc = tag_conv_rows_launch(xi, wpack, 0, nullptr, nullptr, yo, bnpart, 2, static_cast<const bf16_t*>(yref), bn_scale,
+                                            bn_shift, bn_mean, bn_invstd, B, H, W, Cin, Cout, st);
+        if (rc != 0) return rc;
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd};
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
     else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);

@@ -14,7 +14,8 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint64, c_void_
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtag_hip.so")
+# TAG_HIP_LIB: a privately built library (profiling / ablation builds of tools/*.sh); the product is the in-tree one
+LIB_PATH = os.environ.get("TAG_HIP_LIB") or os.path.join(_HERE, "libtag_hip.so")
 
 # = TAG_ABI_VERSION of include/tag_hip.h: bumped whenever an EXISTING entry point changes its argument list, so that a stale
 # libtag_hip.so (git-ignored, shipped separately) is refused instead of being called with shifted arguments
@@ -34,7 +35,8 @@ _SIGS = {
     "tag_pack_conv_weight": (c_int, [P, P, P, c_int, c_int, P]),
     "tag_conv3x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
-    "tag_conv3x3_x3_bf16_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "tag_conv3x3_x3_bf16_stats_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "tag_conv_rows_enable": (c_int, [c_int]),
     "tag_bn_stats_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
     "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -344,8 +344,10 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     x3 = wpack.dtype == torch.uint8
     part = None
     if want_stats and FUSE_BN_STATS:
-        P = query(("tag_conv3x3_x3_bf16_stats_rows" if x.dtype == BF16 else "tag_conv3x3_x3_stats_rows") if x3
-                  else "tag_conv3x3_stats_rows", B, H, W, Cout)
+        if x3 and x.dtype == BF16:
+            P = query("tag_conv3x3_x3_bf16_stats_rows", B, H, W, Cin, Cout, prologue)
+        else:
+            P = query("tag_conv3x3_x3_stats_rows" if x3 else "tag_conv3x3_stats_rows", B, H, W, Cout)
         if P > 0:
             part = (P, _empty(P * (3 * Cout + 1), like=x))
     sp = ptr(part[1]) if part else None
@@ -388,7 +390,7 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     if (FUSE_BN_BWD_SUMS and dy_in.dtype == BF16 and wpack.dtype == torch.uint8 and wpack.products == 1 and st.train
             and yref.dtype == BF16 and W in (8, 16, 32, 64)):
         # BASELINE configs[2] mode: the same fusion on the one-product bf16 kernels (sums from the fp32 accumulators)
-        P = query("tag_conv3x3_x3_bf16_stats_rows", B, H, W, C)
+        P = query("tag_conv3x3_x3_bf16_stats_rows", B, H, W, Cin, C, 0)
         da = _empty(B, H, W, C, like=dy_in, dtype=BF16)
         part = _empty(P * 2 * C, like=dy_in)
         with _timed(("conv3x3_x3_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):

@@ -286,6 +286,9 @@ int tag_gru_forward(const float* gi, const float* w_hh, const float* b_hh, float
 int tag_gru_backward(const float* dy, const float* y, const float* gates, const float* w_hh,
                      float* dgi, float* dgh, float* hprev, void* scratch /* tag_gru_ws_bytes */, int B, int T,
                      int H, void* stream);
+/* A HIP stream restricted to the compute units set in mask (bit i = CU i; `words` 32-bit words) -- hipExtStreamCreateWithCUMask.
+ * The host side keeps the weight-gradient side stream off a share of the CUs with it (ops.py, TAG_WGRAD_CU_SKIP). */
+int tag_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out);
 int tag_gru_timed_out(const void* host_copy_of_err_word);
 /* After a timeout: make every later persistent GRU launch of this process publish its exchange granules write-through
  * (agent scope) instead of L2-resident on one XCD -- the fast form depends on gfx950 cache behaviour (SPX partition mode,

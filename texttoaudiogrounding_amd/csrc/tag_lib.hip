@@ -19,3 +19,19 @@ extern "C" int tag_device_cu_count(void) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     return n;
 }
+
+// A stream whose kernels may only run on the compute units set in mask (bit i = CU i of the device; `words` 32-bit words).
+// ops.py: the weight-gradient side stream can be kept off a share of the CUs so that the short kernels of the main stream
+// always find a free one (TAG_WGRAD_CU_SKIP).
+extern "C" int tag_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out) {
+    TAG_CHECK_ARG(mask && words > 0 && stream_out);
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    if (e != hipSuccess) {
+        tag_set_error("hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return (int)e;
+    }
+    *stream_out = reinterpret_cast<void*>(st);
+    return 0;
+}

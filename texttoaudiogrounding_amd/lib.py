@@ -26,6 +26,7 @@ _SIGS = {
     "tag_abi_version": (c_int, []),
     "tag_last_error": (c_char_p, []),
     "tag_device_cu_count": (c_int, []),
+    "tag_stream_create_cu_mask": (c_int, [P, c_int, P]),
     "tag_logmel_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "tag_bn_stats_ws_bytes": (c_size_t, [c_long, c_int]),
     "tag_bn_stats": (c_int, [P, c_long, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),

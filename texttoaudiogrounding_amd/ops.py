@@ -834,10 +834,31 @@ WGRAD_SIDE_STREAM = _os.environ.get("TAG_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 
 
+#: TAG_WGRAD_CU_SKIP=k (k >= 2): the side stream may not use every k-th compute unit (hipExtStreamCreateWithCUMask), so that the
+#: short kernels of the main stream (BatchNorm finalizes, reductions) never queue behind a full residency round of
+#: weight-gradient workgroups.  0 = an ordinary stream.
+WGRAD_CU_SKIP = int(_os.environ.get("TAG_WGRAD_CU_SKIP", "0"))
+
+
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        st = None
+        if WGRAD_CU_SKIP >= 2:
+            import ctypes
+            ncu = query("tag_device_cu_count")
+            words = (ncu + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for i in range(ncu):
+                if i % WGRAD_CU_SKIP != WGRAD_CU_SKIP - 1:
+                    mask[i // 32] |= 1 << (i % 32)
+            out = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                rc = lib.load().tag_stream_create_cu_mask(mask, words, ctypes.byref(out))
+            if rc != 0:
+                raise RuntimeError(f"tag_stream_create_cu_mask failed: {lib.load().tag_last_error().decode()}")
+            st = torch.cuda.ExternalStream(out.value, device=device)
+        _side_streams[key] = st if st is not None else torch.cuda.Stream(device=device)
     return _side_streams[key]
 
 

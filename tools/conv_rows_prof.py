@@ -9,7 +9,7 @@ ops.CONV_MATH, ops.ACT_DTYPE = "bf16", "bf16"
 dev = torch.device("cuda:0")
 L = ctypes.CDLL(lib.LIB_PATH)
 B = 64
-names = ["prologue", "barrier", "DMA issue", "MFMA phase", "pack+staging+stats", "output stores", "wait DMA", "transform"]
+names = ["barriers", "MFMA phase", "wait DMA", "transform", "pack+window+stats", "output stores", "DMA issue", "-"]
 for (H, W, Cin, Cout, pro) in [(1001, 64, 64, 64, 1), (1001, 64, 64, 64, 0), (500, 32, 64, 128, 0)]:
     x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
@@ -23,5 +23,5 @@ for (H, W, Cin, Cout, pro) in [(1001, 64, 64, 64, 1), (1001, 64, 64, 64, 0), (50
     v = list(buf)[:8]
     tot, T = sum(v), max(1, int(buf[8]))
     print(f"{H}x{W} {Cin}->{Cout} pro={pro}: workgroup {buf[9]} clk = {buf[10] / 100.0:.1f} us ({buf[9] / max(1, buf[10]) / 10.0:.2f} GHz); "
-          f"{T} steps, {tot / T:.0f} clk/step  " +
+          f"{T} rows of wave 0 (its group: every other row), {tot / T:.0f} clk per row pair  " +
           "  ".join(f"{n} {x_ / T:.0f} ({100 * x_ / tot:.0f}%)" for n, x_ in zip(names, v)))

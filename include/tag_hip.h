@@ -127,6 +127,10 @@ int tag_conv3x3_x3_bf16_stats_rows(int B, int H, int W, int Cin, int Cout, int p
 /* 0: keep every bf16-storage layer on the tile kernel (A/B timing, tools/conv_rows_bench.py); returns the previous setting.
  * The environment variable TAG_CONV_ROWS=0 is the process-wide form. */
 int tag_conv_rows_enable(int on);
+/* the same switch for the bf16-storage weight gradient: 1 (default) = the layers without a producer prologue run on
+ * csrc/conv_wgrad_dma.hip (operands by LDS-DMA), 2 = the prologue-1 layers too, 0 = every layer on the register-staged kernel
+ * of conv_x3.hip; returns the previous setting.  Environment TAG_WGRAD_DMA is the process-wide form. */
+int tag_wgrad_dma_enable(int on);
 int tag_conv3x3_forward_x3(const float* x, const void* wpack, int prologue, const float* in_scale,
                            const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
                            int products, void* stream);

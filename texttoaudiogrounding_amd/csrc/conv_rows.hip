@@ -301,8 +301,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
         constexpr int TF0 = 6;                              // first product with a piece of the transform behind it
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
+#ifndef TAG_ROWS_ABL    // energy ablations (WRONG results): 1 = every second A fragment is not read (reuses its neighbour), 2 = only NA - 1 reads per row
             if (f + NA - 1 < NF) af[(f + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(f + NA - 1));
             acc[f % NACC] = mfma_bf16(af[f % NA], bq[f], acc[f % NACC]);
+#elif TAG_ROWS_ABL == 1
+            if (f + NA - 1 < NF && (f & 1) == 0) af[(f + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(f + NA - 1));
+            acc[f % NACC] = mfma_bf16(af[(f | 1) % NA], bq[f], acc[f % NACC]);
+#else
+            acc[f % NACC] = mfma_bf16(af[f % (NA - 1)], bq[f], acc[f % NACC]);
+#endif
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // pin: 1 MFMA, 1 LDS read, (one dword pair of the transform)
             if (f + NA - 1 < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (PRO != 0 && f >= TF0 && f < TF0 + 4 * KX) {         // one packed dword (two channels) of one plane per product

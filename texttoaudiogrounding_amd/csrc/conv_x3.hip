@@ -1024,6 +1024,11 @@ int tag_conv_rows_launch(const bf16_t* x, const void* wpack, int prologue, const
                          bf16_t* y, float* stats, int epi_kind, const bf16_t* yref, const float* bn_scale, const float* bn_shift,
                          const float* bn_mean, const float* bn_invstd, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 
+// conv_wgrad_dma.hip: the bf16-storage weight gradient with both operands brought in by LDS-DMA
+bool tag_wgrad_dma_takes(int prologue);
+int tag_wgrad_dma_launch(const bf16_t* x, int prologue, const float* in_scale, const float* in_shift, const bf16_t* dy,
+                         float* partial, int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st);
+
 extern "C" size_t tag_conv3x3_x3_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * 3 * 2; }
 
 extern "C" int tag_pack_conv_weight_x3(const float* w, void* wfwd, void* wdgrad, int Cin, int Cout, int products,
@@ -1169,6 +1174,13 @@ extern "C" int tag_conv3x3_wgrad_x3_bf16(const void* x, int prologue, const floa
     hipStream_t st = as_stream(stream);
     int cps;
     const int sp = tag_wgrad_alltaps_splits(B, H, W, Cin, Cout, &cps, 16 * TAG_WX3_KS16);
+    if (TAG_WX3_KS16 == 4 && tag_wgrad_dma_takes(prologue)) {
+        const int rc = tag_wgrad_dma_launch(static_cast<const bf16_t*>(x), prologue, in_scale, in_shift, static_cast<const bf16_t*>(dy),
+                                            partial, B, H, W, Cin, Cout, sp, cps, st);
+        if (rc != 0) return rc;
+        TAG_LAUNCH_CHECK();
+        return tag_launch_wgrad_reduce(partial, sp, Cin, Cout, dw, st);
+    }
     launch_wgrad_x3_w<1, bf16_t>(static_cast<const bf16_t*>(x), prologue, in_scale, in_shift, static_cast<const bf16_t*>(dy),
                                  partial, B, H, W, Cin, Cout, sp, cps, st);
     TAG_LAUNCH_CHECK();

@@ -38,6 +38,7 @@ _SIGS = {
     "tag_conv3x3_x3_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "tag_conv3x3_x3_bf16_stats_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "tag_conv_rows_enable": (c_int, [c_int]),
+    "tag_wgrad_dma_enable": (c_int, [c_int]),
     "tag_bn_stats_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),
     "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

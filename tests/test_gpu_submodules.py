@@ -134,3 +134,53 @@ def test_embedding_layer_forward_standalone(dev, golden_dir, case):
         m({"text": torch.tensor([0, E.V])})
     out2 = m({"text": t.to(dev)})                                # device-resident ids take the same path
     assert torch.equal(out2, out)
+
+
+def test_encoders_run_through_the_operator_registry(dev, monkeypatch):
+    """north_star: "exposed to Python through PyTorch-ROCm custom ops" -- round 4: Cnn8Rnn.forward / CrnnEncoder.forward call
+    ``torch.ops.tag.cnn8rnn_encoder`` / ``tag.crnn_encoder`` (torch.library operators with fake kernels and a registered
+    autograd formula around the fused engine).  The operator's result and gradients are bit-equal to the engine applied as a
+    plain autograd.Function (the same kernels in the same order), and opcheck accepts schema / fake kernel / autograd registration."""
+    import texttoaudiogrounding_amd.torch_ops as T
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.models import audio_encoder
+    calls = []
+    monkeypatch.setattr(T, "run_encoder", lambda op, *a, _r=T.run_encoder: (calls.append(op), _r(op, *a))[1])
+    for cls, engine, opname in ((audio_encoder.Cnn8Rnn, ops.Cnn8RnnFunction, "cnn8rnn_encoder"),
+                                (audio_encoder.CrnnEncoder, ops.CrnnFunction, "crnn_encoder")):
+        calls.clear()
+        torch.manual_seed(3)
+        m = (cls(32000) if cls is audio_encoder.Cnn8Rnn else cls(32000, 256)).to(dev).train()
+        if cls is audio_encoder.Cnn8Rnn:
+            m.dropout_p = (0.0, 0.0)
+        else:
+            m.dropout_p = 0.0
+        wave = (0.1 * torch.randn(3, 16000, generator=torch.Generator().manual_seed(5))).to(dev)
+        real = getattr(torch.ops.tag, opname)
+        out = m({"waveform": wave, "waveform_len": [16000] * 3, "specaug": False})["embedding"]
+        assert calls == [real], "the module's forward must go through torch.ops.tag." + opname
+        dy = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+        out.backward(dy)
+        g_op = [p.grad.clone() for p in m.parameters()]
+        buf_op = [b.clone() for b in m.buffers()]
+        # the same step through the engine as a plain autograd node, from the same starting state
+        torch.manual_seed(3)
+        m2 = (cls(32000) if cls is audio_encoder.Cnn8Rnn else cls(32000, 256)).to(dev).train()
+        m2.dropout_p = m.dropout_p
+        out2 = engine.apply(wave, m2, *m2._flat_params())
+        out2.backward(dy)
+        assert torch.equal(out, out2)
+        assert all(torch.equal(a, p.grad) for a, p in zip(g_op, m2.parameters()))
+        # running statistics were updated by the operator exactly as by the node (num_batches_tracked is bumped by the module)
+        for (n, b), b2 in zip(m.named_buffers(), m2.buffers()):
+            if not n.endswith("num_batches_tracked"):
+                assert torch.equal(b, b2), n
+        # eval / no_grad: no saved state is kept
+        with torch.no_grad():
+            m.eval()
+            m({"waveform": wave, "waveform_len": [16000] * 3, "specaug": False})
+        assert T._ENC_HANDOVER[0] is None
+        torch.library.opcheck(real, (wave, list(m._flat_params()), T.encoder_token(m), False),
+                              test_utils=("test_schema", "test_faketensor"))
+        torch.library.opcheck(real, (wave, list(m.train()._flat_params()), T.encoder_token(m), True),
+                              test_utils=("test_autograd_registration",))

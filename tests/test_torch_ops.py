@@ -29,6 +29,14 @@ def test_ops_registered_with_schemas_and_fake_kernels():
         rnn = [torch.empty(768, 512), torch.empty(768, 256), torch.empty(768), torch.empty(768)] * 2
         yy, gates = torch.ops.tag.gru_bidir(torch.empty(4, 250, 512), *rnn)
         assert yy.shape == (4, 250, 512) and gates.shape == (4, 250, 2, 1024)
+    # the fused encoders (round 4): shape inference needs the module (hop, downsample ratio, width) named by the token
+    from texttoaudiogrounding_amd.models import audio_encoder
+    cnn8, crnn = audio_encoder.Cnn8Rnn(32000), audio_encoder.CrnnEncoder(32000, 256)
+    t8, tc = T.encoder_token(cnn8), T.encoder_token(crnn)
+    with FakeTensorMode():
+        emb = torch.ops.tag.cnn8rnn_encoder(torch.empty(4, 320000), [], t8, False)
+        assert emb.shape == (4, 250, 512)
+        assert torch.ops.tag.crnn_encoder(torch.empty(3, 64000), [], tc, False).shape == (3, 25, 256)      # hop 640, downsample 4
 
 
 def test_ops_raise_on_cpu_tensors():

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import torch_ops  # noqa: F401  (registers torch.ops.tag.*)
 from .panns import ConvBlock, init_bn, init_layer
 
 
@@ -116,7 +117,7 @@ class CrnnEncoder(nn.Module):
     def forward(self, input_dict: Dict):
         if self.training:
             ops.bump_bn_counters(self, self._bn_modules())
-        x = ops.CrnnFunction.apply(input_dict["waveform"], self, *self._flat_params())
+        x = torch_ops.run_encoder(torch.ops.tag.crnn_encoder, self, input_dict["waveform"], self._flat_params())
         length = torch.div(torch.as_tensor(input_dict["waveform_len"]), self.hop_length, rounding_mode="floor") + 1
         length = torch.div(length, self.downsample_ratio, rounding_mode="floor")
         return {"embedding": x, "length": length}
@@ -204,7 +205,7 @@ class Cnn8Rnn(nn.Module):
         if self.training and not self.freeze_bn:
             ops.bump_bn_counters(self, [self.bn0, *(getattr(self, f"conv_block{i}").bn1 for i in range(1, 5)),
                                         *(getattr(self, f"conv_block{i}").bn2 for i in range(1, 5))])
-        x = ops.Cnn8RnnFunction.apply(waveform, self, *self._flat_params())
+        x = torch_ops.run_encoder(torch.ops.tag.cnn8rnn_encoder, self, waveform, self._flat_params())
         length = torch.div(torch.as_tensor(input_dict["waveform_len"]), self.hop_length, rounding_mode="floor") + 1
         length = torch.div(length, self.downsample_ratio, rounding_mode="floor")
         return {"embedding": x, "length": length}

@@ -5,9 +5,10 @@ of the SAME C ABI (libtag_hip.so through ctypes, texttoaudiogrounding_amd.lib): 
 ``frame_match``, models/align.py -> ``align_dot``, losses.py -> ``frame_bce``, models/text_encoder.py -> ``embed_mean``,
 models/panns.py ConvBlock.forward -> ``conv3x3_bn_relu_pool``, utils/eval_util.py -> ``segments``).  Every formula exists
 once: an operator's forward / backward body is a plain function of ``ops.py`` (``ops.match_forward`` / ``ops.match_backward``
-...), shared with the two composite autograd nodes that stay there because they own per-step state an operator cannot
-(``ops.Cnn8RnnFunction`` / ``ops.CrnnFunction``: the fused encoders, which never materialise the intermediate activations and
-write parameter gradients straight into the flat buffer; ``ops.EmbedMeanFunction``: the direct-gradient scatter).
+...).  The fused encoders are operators too (``tag::cnn8rnn_encoder`` / ``tag::crnn_encoder``, round 4): they wrap the engine
+of ``ops.py`` (``ops.Cnn8RnnFunction`` / ``ops.CrnnFunction`` never materialise the intermediate activations and write
+parameter gradients straight into the flat buffer -- per-step state that travels beside the operator, see below);
+``ops.EmbedMeanFunction`` (the direct-gradient scatter) is the one autograd node the modules still apply directly.
 
     import texttoaudiogrounding_amd.torch_ops          # registers torch.ops.tag.*
 
@@ -357,6 +358,104 @@ def _bce_backward(ctx, dloss):
 register_autograd("tag::frame_bce", _bce_backward, setup_context=_bce_setup)
 
 
+# ------------------------------------------------------------------------------------------------ the fused audio encoders
+# ``tag::cnn8rnn_encoder`` / ``tag::crnn_encoder``: log-mel -> conv stack -> (fc1) -> BiGRU as ONE operator each (rows F1-F3,
+# A1-A4), what models/audio_encoder.py Cnn8Rnn.forward / CrnnEncoder.forward call -- the hot 97 % of the step goes through the
+# operator registry like the heads do.  The operator wraps the engine of ops.py (ops.Cnn8RnnFunction / ops.CrnnFunction: the
+# same forward / backward bodies, called with a plain context object): that engine keeps per-step state no functional
+# operator could return cheaply (GBs of raw conv outputs saved for backward, dropout seeds, the direct-gradient sinks of the
+# flat buffer, the weight-gradient side stream), so the saved state travels from the forward kernel to ``setup_context`` through
+# a one-slot hand-over and the module (eps / momentum / dropout probabilities / frozen flags) is named by a token.
+import weakref
+
+_ENC_MODULES = weakref.WeakValueDictionary()          # token -> nn.Module
+_ENC_HANDOVER = [None]                                # saved state of the forward that just ran -> its setup_context
+
+
+def encoder_token(mod) -> int:
+    """Registers ``mod`` (Cnn8Rnn / CrnnEncoder) for the encoder operators and returns its token."""
+    tok = id(mod)
+    _ENC_MODULES[tok] = mod
+    return tok
+
+
+class _EncCtx:
+    """What ops.Cnn8RnnFunction.forward / .backward expect of their ctx."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved = None
+
+
+def _enc_forward(engine, waveform, params, module_token, need_grad):
+    mod = _ENC_MODULES[module_token]
+    ctx = _EncCtx((False, False) + tuple(bool(need_grad and p.requires_grad) for p in params))
+    y = engine.forward(ctx, waveform, mod, *params)
+    _ENC_HANDOVER[0] = (engine, ctx) if need_grad else None
+    return y
+
+
+def _enc_setup(ctx, inputs, output):
+    ctx.enc, _ENC_HANDOVER[0] = _ENC_HANDOVER[0], None
+
+
+def _enc_backward(ctx, dy):
+    if ctx.enc is None:
+        raise RuntimeError("tag encoder operator: backward without saved state (call it with need_grad=True under autograd)")
+    engine, ectx = ctx.enc
+    ctx.enc = None
+    grads = engine.backward(ectx, dy.contiguous())            # (None, None, *parameter gradients)
+    return None, list(grads[2:]), None, None
+
+
+def _enc_fake_frames(mod, waveform):
+    return (waveform.shape[1] // mod.hop_length + 1) // mod.downsample_ratio
+
+
+@custom_op("tag::cnn8rnn_encoder", mutates_args=())
+def cnn8rnn_encoder(waveform: Tensor, params: List[Tensor], module_token: int, need_grad: bool) -> Tensor:
+    """Cnn8Rnn.forward of models/audio_encoder.py:88-227: waveform (B,S) -> embedding (B, T', 512).  params in
+    Cnn8Rnn._flat_params() order.  In train mode the BatchNorm running statistics of the MODULE named by the token are updated
+    as nn.BatchNorm2d updates its buffers: module state, not operator arguments (torch.library refuses an autograd formula on an
+    operator that declares mutated arguments)."""
+    return _enc_forward(ops.Cnn8RnnFunction, waveform, params, module_token, need_grad)
+
+
+@cnn8rnn_encoder.register_fake
+def _(waveform, params, module_token, need_grad):
+    mod = _ENC_MODULES[module_token]
+    return waveform.new_empty(waveform.shape[0], _enc_fake_frames(mod, waveform), mod.embed_dim)
+
+
+register_autograd("tag::cnn8rnn_encoder", _enc_backward, setup_context=_enc_setup)
+
+
+@custom_op("tag::crnn_encoder", mutates_args=())
+def crnn_encoder(waveform: Tensor, params: List[Tensor], module_token: int, need_grad: bool) -> Tensor:
+    """CrnnEncoder.forward of models/audio_encoder.py:16-86: waveform (B,S) -> embedding (B, T', embed_dim)."""
+    return _enc_forward(ops.CrnnFunction, waveform, params, module_token, need_grad)
+
+
+@crnn_encoder.register_fake
+def _(waveform, params, module_token, need_grad):
+    mod = _ENC_MODULES[module_token]
+    return waveform.new_empty(waveform.shape[0], _enc_fake_frames(mod, waveform), 2 * mod.gru.hidden_size)
+
+
+register_autograd("tag::crnn_encoder", _enc_backward, setup_context=_enc_setup)
+
+
+def run_encoder(op, mod, waveform, params):
+    """Front door of the two encoder modules: calls ``op`` with the caller's grad mode made visible to the engine (inside an
+    operator grad mode is always off) and the module's token."""
+    need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    prev, ops._RECORDING = ops._RECORDING, torch.is_grad_enabled()
+    try:
+        return op(waveform, list(params), encoder_token(mod), need)
+    finally:
+        ops._RECORDING = prev
+
+
 # ------------------------------------------------------------------------------------------------ P1 segments
 @custom_op("tag::segments", mutates_args=())
 def segments(frame_sim: Tensor, thresholds: Tensor, window_size: int, n_connect: int) -> Tuple[Tensor, Tensor]:
@@ -375,4 +474,4 @@ def _(frame_sim, thresholds, window_size, n_connect):
 
 OP_NAMES = ["logmel", "conv3x3", "conv3x3_dgrad", "conv3x3_wgrad", "conv3x3_bn_relu_pool", "conv3x3_bn_relu_pool_backward",
             "gru_bidir", "gru_bidir_backward", "embed_mean", "embed_mean_backward", "frame_match", "frame_match_backward",
-            "align_dot", "align_dot_backward", "frame_bce", "frame_bce_backward", "segments"]
+            "align_dot", "align_dot_backward", "frame_bce", "frame_bce_backward", "segments", "cnn8rnn_encoder", "crnn_encoder"]

@@ -131,7 +131,10 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
                                      f"{str(meta.get('csrc_sha256'))[:12]} != built {csrc_sha256()[:12]}); re-run "
                                      "tools/collect_profiles.sh"}
         else:
-            rows = [v for k, v in tj.items() if k.startswith(dom)]
+            # the bf16 conv family is two kernels since round 4: the tile kernel and the row-streaming kernel of conv_rows.hip
+            names = {"conv3x3_x3_kernel": ("conv3x3_x3_kernel", "conv3x3_rows_kernel"),
+                     "conv3x3_wgrad_x3_kernel": ("conv3x3_wgrad_x3_kernel", "conv3x3_wgrad_dma_kernel")}.get(dom, (dom,))
+            rows = [v for k, v in tj.items() if k.startswith(names)]
             n = sum(v["launches_in_run"] for v in rows)
             if n:
                 traffic = round(sum((v["fetch_GB_per_launch"] + v["write_GB_per_launch"]) * v["launches_in_run"]

@@ -372,6 +372,58 @@ def cnn8rnn_forward_bf16_mode(st, waveform, waveform_len, training=False, prefix
     return {"embedding": x, "length": output_length(waveform_len, FRONTEND["cnn8rnn"]["hop_length"])}
 
 
+# ---- the bf16 mode's BACKWARD rounding points, stage by stage (round 4; the backward twin of cnn8rnn_forward_bf16_mode).  Every
+# function takes the tensors a device stage reads AS STORED (bf16 values widened to float64, NCHW) plus the fp32 per-channel
+# constants, computes in float64 and rounds exactly where the kernels round.  (models/panns.py:46-62 backward.)
+
+def bf16_bnrelu_pool_backward(y, scale, shift, mean, invstd, gamma, dout, ps):
+    """Backward of  out = avg_pool(a) + max_pool(a),  a = relu(y * scale + shift)  (ConvBlock pool_type 'avg+max') and of the
+    train-mode BatchNorm in front of it, as tag_bnrelu_pool_backward_bf16 does it (csrc/bn_pool.hip PoolBwdCtx::compute,
+    pool_bwd_reduce_kernel, pool_bwd_apply_kernel): the max gradient goes to the FIRST maximum in scan order (ATen's rule),
+    sums over the batch in high precision, ONE rounding -- of dy to bf16 on store.  -> (dy (bf16-rounded), dgamma, dbeta)."""
+    v = lambda t: t.view(1, -1, 1, 1)
+    a = (y * v(scale) + v(shift)).detach().requires_grad_(True)
+    r = F.relu(a)
+    (F.avg_pool2d(r, kernel_size=ps) + F.max_pool2d(r, kernel_size=ps)).backward(dout)
+    g = a.grad                                                      # dz: pool routing and the ReLU mask
+    xh = (y - v(mean)) * v(invstd)
+    n = y.shape[0] * y.shape[2] * y.shape[3]
+    dbeta, dgamma = g.sum(dim=(0, 2, 3)), (g * xh).sum(dim=(0, 2, 3))
+    dy = v(gamma * invstd) * (g - v(dbeta) / n - xh * v(dgamma) / n)
+    return _q_bf16(dy), dgamma, dbeta
+
+
+def bf16_conv_dgrad(dy, w, in_shape):
+    """Input gradient of the 3x3 convolution on the bf16 MFMA: bf16 operands (dy as stored, the weights rounded), wide
+    accumulation; UNROUNDED (the epilogue sums of tag_conv3x3_dgrad_bnsums_bf16 use the accumulators, the store rounds)."""
+    return torch.nn.grad.conv2d_input(in_shape, _q_bf16(w), dy, 1, 1)
+
+
+def bf16_dgrad_bnrelu_backward(da_f, yref, scale, shift, mean, invstd, gamma):
+    """What follows the dgrad conv whose result flows into relu(bn(yref)) (tag_conv3x3_dgrad_bnsums_bf16 +
+    tag_bn_grad_from_partials + tag_bnrelu_backward_apply_bf16; csrc/conv_x3.hip EPI == 1, csrc/conv_rows.hip EPI == 2,
+    csrc/bn_pool.hip bnrelu_bwd_apply_kernel): dgamma / dbeta sum g = da * [bn(yref) > 0] from the UNROUNDED accumulators, the
+    apply pass re-reads the STORED (bf16) da.  -> (dy (bf16-rounded), dgamma, dbeta, da (bf16-rounded, what the conv stored))."""
+    v = lambda t: t.view(1, -1, 1, 1)
+    mask = (yref * v(scale) + v(shift)) > 0
+    xh = (yref - v(mean)) * v(invstd)
+    gf = torch.where(mask, da_f, torch.zeros_like(da_f))
+    n = yref.shape[0] * yref.shape[2] * yref.shape[3]
+    dbeta, dgamma = gf.sum(dim=(0, 2, 3)), (gf * xh).sum(dim=(0, 2, 3))
+    da_q = _q_bf16(da_f)
+    gq = torch.where(mask, da_q, torch.zeros_like(da_q))
+    dy = v(gamma * invstd) * (gq - v(dbeta) / n - xh * v(dgamma) / n)
+    return _q_bf16(dy), dgamma, dbeta, da_q
+
+
+def bf16_conv_wgrad(x, dy, wshape, scale=None, shift=None):
+    """Weight gradient on the bf16 MFMA: operands as stored; with a producer prologue the activation relu(x * scale + shift)
+    is formed in fp32 and ROUNDED to bf16 before it multiplies (the same operand the forward conv used); fp32 result."""
+    if scale is not None:
+        x = _q_bf16(F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)))
+    return torch.nn.grad.conv2d_weight(x, wshape, dy, 1, 1)
+
+
 def gru_bidir(x, st, prefix):
     """nn.GRU(512, 256, bidirectional=True, batch_first=True), h0 = 0, all T' steps (row A4)."""
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]

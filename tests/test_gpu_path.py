@@ -643,6 +643,83 @@ def test_bf16_mode_stages_match_rounding_point_emulation(dev, monkeypatch):
     assert m_emu < m_ref and m_emu < 2e-3
 
 
+def test_bf16_mode_backward_stages_match_rounding_point_emulation(dev, monkeypatch):
+    """The backward twin of the test above (round-3 review: "the bf16 BACKWARD -- dgrad / wgrad / bf16 gradient storage -- is
+    only budget-checked").  One training-mode forward of the encoder on the device (bf16 mode, dropout off) leaves the saved
+    activations of every block; then the backward of the conv stack is driven STAGE BY STAGE with the engine's own calls, from a
+    seeded gradient at the top, and every stage is compared with the oracle's restatement of its rounding points
+    (O.bf16_bnrelu_pool_backward / bf16_conv_dgrad / bf16_dgrad_bnrelu_backward / bf16_conv_wgrad) evaluated in float64 ON THE
+    DEVICE'S OWN INPUTS of that stage.  bf16-stored results: mean error <= 1e-6 of the range and <= 5e-4 of the elements off
+    by more than one bf16 ulp; fp32 results (weight gradients, dgamma / dbeta): <= 2e-5 of their maximum.  Blocks 4..2 in full,
+    block 1 down to dL/dy1 (its Cin = 1 backward has its own kernel tests)."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd import torch_ops as T
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    monkeypatch.setattr(ops, "ACT_DTYPE", "bf16")
+    st = O.init_state(seed=17, logit_gain=30.0)
+    batch = O.synthetic_batch(4, 64000, seed=23, ragged=False)
+    model = build_hip_model(st, "dot", dev).train()
+    mod = model.audio_encoder
+    mod.dropout_p = (0.0, 0.0)
+    ctx = T._EncCtx((False, False) + (True,) * len(mod._flat_params()))
+    ops.Cnn8RnnFunction.forward(ctx, batch["waveform"].to(dev), mod, *mod._flat_params())
+    sv = ctx.saved
+    p = sv["p"]
+    worst = {"mean": 0.0, "frac": 0.0, "f32": 0.0}
+    nchw = lambda t: t.double().cpu().permute(0, 3, 1, 2).contiguous()
+    vec = lambda t: t.double().cpu()
+
+    def check16(name, dev_t, ref):
+        d, r = nchw(dev_t), ref
+        e = (d - r).abs()
+        rng = r.abs().max().item()
+        mean, frac = e.mean().item() / rng, (e > r.abs() * 2.0 ** -7 + 1e-6 * rng).double().mean().item()
+        print(f"  {name:34s} mean err / range {mean:.1e}   elements off by > 1 bf16 ulp {frac:.1e}")
+        worst["mean"], worst["frac"] = max(worst["mean"], mean), max(worst["frac"], frac)
+        assert mean <= 1e-6 and frac <= 5e-4, (name, mean, frac)
+
+    def check32(name, dev_t, ref):
+        e = (dev_t.double().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-300)
+        print(f"  {name:34s} max err / max {e:.1e}")
+        worst["f32"] = max(worst["f32"], e)
+        assert e <= 2e-5, (name, e)
+
+    g = torch.Generator().manual_seed(5)
+    dx = (0.05 * torch.randn(sv["x_last"].shape, generator=g)).to(dev).bfloat16()
+    for i in range(3, -1, -1):
+        x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
+        c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]
+        ph, pw = ops.CNN8_POOLS[i]
+        # (1) pool + ReLU + BatchNorm backward of the block's second half
+        dy2, dg2, db2 = ops.bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, 0.0, 0)
+        r_dy2, r_dg2, r_db2 = O.bf16_bnrelu_pool_backward(nchw(y2), vec(s2.scale), vec(s2.shift), vec(s2.mean), vec(s2.invstd),
+                                                          vec(g2), nchw(dx), (ph, pw))
+        check16(f"block{i + 1}: pool/ReLU/bn2 backward", dy2, r_dy2)
+        check32(f"block{i + 1}: dgamma2", dg2, r_dg2)
+        check32(f"block{i + 1}: dbeta2", db2, r_db2)
+        # (2) weight gradient of conv2 (operand = relu(bn1(y1)) rounded to bf16, as in the forward)
+        dw2 = ops.conv3x3_wgrad(y1, dy2, prologue=1, scale=s1.scale, shift=s1.shift)
+        check32(f"block{i + 1}: conv2 weight gradient", dw2,
+                O.bf16_conv_wgrad(nchw(y1), nchw(dy2), tuple(c2w.shape), vec(s1.scale), vec(s1.shift)))
+        # (3) dgrad of conv2 + BatchNorm-backward sums in its epilogue + the apply pass
+        dy1, dg1, db1 = ops.conv3x3_dgrad_bnrelu_backward(dy2, wd2, y1, s1, g1)
+        da_f = O.bf16_conv_dgrad(nchw(dy2), vec(c2w), tuple(nchw(y1).shape))
+        r_dy1, r_dg1, r_db1, _ = O.bf16_dgrad_bnrelu_backward(da_f, nchw(y1), vec(s1.scale), vec(s1.shift), vec(s1.mean),
+                                                              vec(s1.invstd), vec(g1))
+        check16(f"block{i + 1}: conv2 dgrad + bn1 backward", dy1, r_dy1)
+        check32(f"block{i + 1}: dgamma1", dg1, r_dg1)
+        check32(f"block{i + 1}: dbeta1", db1, r_db1)
+        if i == 0:
+            break
+        # (4) conv1: weight gradient (operand = the stored pooled activation) and input gradient (stored bf16)
+        dw1 = ops.conv3x3_wgrad(x_in, dy1)
+        check32(f"block{i + 1}: conv1 weight gradient", dw1, O.bf16_conv_wgrad(nchw(x_in), nchw(dy1), tuple(c1w.shape)))
+        dx = ops.conv3x3(dy1, wd1, x_in.shape[3])
+        check16(f"block{i + 1}: conv1 dgrad", dx, O._q_bf16(O.bf16_conv_dgrad(nchw(dy1), vec(c1w), tuple(nchw(x_in).shape))))
+    print(f"bf16 mode backward, per stage: worst mean err / range {worst['mean']:.1e}, worst > 1 ulp fraction {worst['frac']:.1e}, "
+          f"worst fp32 result {worst['f32']:.1e}")
+
+
 @pytest.mark.parametrize("B,S", [(1, 4000), (3, 9999), (2, 32000)])
 def test_edge_shapes_train_step(dev, B, S):
     """Edge cases of the path: a single clip, clips of a few frames (T' = 3), odd sample counts, one-token phrases:

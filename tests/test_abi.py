@@ -128,10 +128,11 @@ def test_host_resident_token_ids_out_of_range_raise_at_once():
 
 
 def test_pass_size_limit_is_reported_before_any_launch():
-    """A training batch beyond the conv kernels' 32-bit activation offsets raises a RuntimeError that names the limit (round-2
-    review: it used to surface as TAG_EINVAL from the first conv): 10 s clips -> 261 per pass in fp32, 30 s clips -> 87."""
+    """A batch beyond the kernels' index range raises a RuntimeError that names the limit (round-2 review: it used to surface as
+    TAG_EINVAL from the first conv).  Round 4: the conv kernels take a 64-bit image base, so the limit is the 31-bit pixel
+    index of the BatchNorm / pool passes (33 520 clips of 10 s), no longer 261 clips of 10 s."""
     from texttoaudiogrounding_amd import ops
-    assert ops.max_clips_per_pass(1001) == 261 and ops.max_clips_per_pass(3001) == 87
-    ops.check_pass_size(64, 3001)
-    with pytest.raises(RuntimeError, match="at most 261 clips"):
-        ops.check_pass_size(262, 1001)
+    assert ops.max_clips_per_pass(1001) == 33520 and ops.max_clips_per_pass(3001) == 11181
+    ops.check_pass_size(300, 1001)
+    with pytest.raises(RuntimeError, match="at most 33520 clips"):
+        ops.check_pass_size(33521, 1001)

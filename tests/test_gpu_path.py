@@ -720,6 +720,47 @@ def test_bf16_mode_backward_stages_match_rounding_point_emulation(dev, monkeypat
           f"worst fp32 result {worst['f32']:.1e}")
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_batch_of_300_clips_in_one_pass(dev, monkeypatch, mode):
+    """Round-3 review, missing #4: `ops.py` raised at B >= 262 x 10 s because the conv kernels indexed activations with 32-bit
+    byte offsets over the whole batch; the reference takes any batch that fits memory (run_strong.py:123-152).  The kernels now
+    add a 64-bit per-image base to 32-bit in-image offsets.  B = 300 x 10 s (first conv output 4.9 GB in fp32: beyond 2^32 bytes) in
+    ONE eval pass: rows 0..63 / 236..299 equal the same clips run as passes of 64 to 2e-6 (every stage up to the GRU is
+    batch-invariant bit for bit; 300 sequences take the per-step GRU kernels instead of the persistent 4-row ones, a different
+    summation order), and one TRAINING step at B = 300 runs (loss finite, every gradient finite and non-zero)."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    if mode == "bf16":
+        monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+        monkeypatch.setattr(ops, "ACT_DTYPE", "bf16")
+    B, S = 300, 320000
+    st = O.init_state(seed=9, logit_gain=40.0)
+    g = torch.Generator().manual_seed(77)
+    wave = (0.1 * torch.randn(B, S, generator=g)).to(dev)
+    text = torch.randint(2, 5221, (B, 3), generator=g)
+    batch = {"waveform": wave, "waveform_len": np.full((B,), S), "text": text.to(dev), "text_len": torch.full((B,), 3).to(dev),
+             "specaug": False}
+    model = build_hip_model(st, "dot", dev).eval()
+    with torch.no_grad():
+        full = model(dict(batch))["frame_sim"]
+        for lo in (0, 236):
+            part = model({k: (v[lo:lo + 64] if hasattr(v, "__len__") and not isinstance(v, bool) else v) for k, v in batch.items()})
+            d = (full[lo:lo + 64] - part["frame_sim"]).abs().max().item()
+            print(f"B = 300 in one pass vs a pass of 64 (clips {lo}..{lo + 63}): max |d frame_sim| = {d:.1e}")
+            assert d <= 2e-6, (lo, d)
+    assert torch.isfinite(full).all()
+    if mode == "fp32":
+        return                                                  # the fp32 training step at B = 300 needs ~25 GB more; bf16 covers it
+    model.train()
+    runner = StrongRunner(model, device=str(dev))
+    tb = dict(batch)
+    tb["label"] = (torch.rand(B, 250, generator=g) < 0.5).float().to(dev)
+    loss = runner.forward_backward(tb)
+    assert np.isfinite(runner.loss_value(loss))
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+
+
 @pytest.mark.parametrize("B,S", [(1, 4000), (3, 9999), (2, 32000)])
 def test_edge_shapes_train_step(dev, B, S):
     """Edge cases of the path: a single clip, clips of a few frames (T' = 3), odd sample counts, one-token phrases:

@@ -327,9 +327,10 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
         const bool ok = ex && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
         pexist |= (unsigned)ex << i;
         pvalid |= (unsigned)ok << i;
-        const long pix = ok ? ((long)img * H + h) * W + w : (long)img * H * W;
-        poff[i] = (unsigned)((pix * Cin + q * 4) * 4);
+        const int pix = ok ? h * W + w : 0;                // inside the image: 32-bit byte offsets hold any batch (round 4)
+        poff[i] = (unsigned)(((long)pix * Cin + q * 4) * 4);
     }
+    const char* ximg = reinterpret_cast<const char*>(x) + (size_t)img * H * W * Cin * 4;      // wave-uniform 64-bit image base
     unsigned boffb[B_LOADS];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
         const unsigned coff = (unsigned)(cc * BK * 4);
 #pragma unroll
         for (int i = 0; i < G::ITEMS; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x) + (poff[i] + coff));
+            ra[i] = *reinterpret_cast<const f32x4*>(ximg + (poff[i] + coff));
     };
     auto store_patch = [&](int cc) {
         f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1606,11 +1607,13 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
                                    int Cout, void* stream) {
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0 && W > 0);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
-    TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside the kernel
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
     const bool halo = conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64);
+    // 32-bit byte offsets: inside ONE image for the halo-tile kernel (64-bit image base), over the whole batch for the fallback
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
+    TAG_CHECK_ARG(halo || (long)B * H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(stats == nullptr || halo);
 #define EPI_PTR nullptr
 #define HALO_BY_W(BN_)                                                                                          \
@@ -1639,7 +1642,7 @@ extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, flo
                                         void* stream) {
     TAG_CHECK_ARG(dy && wpack && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart);
     TAG_CHECK_ARG(B > 0 && H > 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
-    TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
     hipStream_t st = as_stream(stream);
     const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd};
@@ -1753,7 +1756,9 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     TAG_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
-    TAG_CHECK_ARG(M < (1L << 31) && M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32) && W <= 64);
+    // the all-taps kernel indexes pixels with 64-bit products; the per-tap fallback keeps 32-bit byte offsets over the batch
+    TAG_CHECK_ARG(M < (1L << 31) && W <= 64);
+    TAG_CHECK_ARG(wgrad_alltaps_ok(W) || (M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32)));
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);
     const long nred = (long)9 * Cin * Cout;

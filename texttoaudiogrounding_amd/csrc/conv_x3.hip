@@ -196,9 +196,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
         const bool ok = ex & ((unsigned)h < (unsigned)H) & ((unsigned)w < (unsigned)W);
         pexist |= (unsigned)ex << i;
         pvalid |= (unsigned)ok << i;
-        const long pix = ok ? ((long)img * H + h) * W + w : (long)img * H * W;
+        const long pix = ok ? (long)h * W + w : 0;        // inside the image: 32-bit byte offsets hold any batch (round 4)
         poff[i] = HS16 ? (unsigned)((pix * Cin + q * 8) * 2) : (unsigned)((pix * Cin + q * 4) * 4);
     }
+    const char* ximg = reinterpret_cast<const char*>(x) + (size_t)img * H * W * Cin * sizeof(TS);   // wave-uniform 64-bit image base
     // per-lane LDS byte offset of tap (ky=0,kx=0) for each MFMA block, channel octet kl
     unsigned abase[MB];
 #pragma unroll
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
         const unsigned coff = (unsigned)(cc * KC * (HS16 ? 2 : 4));
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
-            ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + (poff[i] + coff));
+            ra[i] = *reinterpret_cast<const u32x4*>(ximg + (poff[i] + coff));
     };
     auto store_patch = [&](int cc) {
 #pragma unroll
@@ -1063,7 +1064,7 @@ extern "C" int tag_conv3x3_forward_x3(const float* x, const void* wpack, int pro
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
-    TAG_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside the kernel
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));      // 32-bit byte offsets inside one image
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
@@ -1086,7 +1087,7 @@ extern "C" int tag_conv3x3_forward_x3_bf16(const void* x, const void* wpack, int
     TAG_CHECK_ARG(x && wpack && y && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
-    TAG_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32));
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 2 < (1L << 32));
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
@@ -1115,7 +1116,7 @@ extern "C" int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, 
     TAG_CHECK_ARG(dy && wpack && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && B > 0 && H > 0);
     TAG_CHECK_ARG(W == 8 || W == 16 || W == 32 || W == 64);
     TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 64 == 0 && Cin <= 512);
-    TAG_CHECK_ARG((long)B * H * W * Cin * 2 < (1L << 32));
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 2 < (1L << 32));
     hipStream_t st = as_stream(stream);
     const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
     const bf16_t* xi = static_cast<const bf16_t*>(dy);
@@ -1148,7 +1149,7 @@ extern "C" int tag_conv3x3_wgrad_x3(const float* x, int prologue, const float* i
     TAG_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
-    TAG_CHECK_ARG(M < (1L << 31) && M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32));
+    TAG_CHECK_ARG(M < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32) && (long)H * W * Cout * 4 < (1L << 32));   // offsets inside one image
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);
     int cps;

@@ -189,8 +189,8 @@ class Cnn8RnnLaionClapGroundingModel(nn.Module):
         ids, mask = text["input_ids"], text["attention_mask"]
         audio_len = torch.as_tensor(audio_len)
         outs = []
-        # batches are processed in passes: the conv kernels index activations with 32-bit byte offsets
-        # (B * F * 64 * 64 * 4 B < 4 GiB) and the persistent GRU holds <= 128 sequences per launch
+        # batches are processed in passes of max_clips_per_pass (64): the first conv output of 64 x 30 s clips is 3.15 GB, and the
+        # persistent GRU holds <= 128 sequences per launch (the kernels themselves take any batch since round 4)
         frames = audio.shape[1] // self.model.audio_encoder.hop_length + 1
         per_pass = max(1, min(self.max_clips_per_pass, ops.max_clips_per_pass(frames)))
         for b0 in range(0, B, per_pass):

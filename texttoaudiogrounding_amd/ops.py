@@ -736,22 +736,23 @@ def bump_bn_counters(owner, bns):
 
 
 def max_clips_per_pass(frames: int) -> int:
-    """Largest batch the conv kernels take in one launch: activations are indexed with 32-bit BYTE offsets, and the largest
-    tensor is the first block's (B, frames, 64 mel, 64 channels) -- fp32, or bf16 in the bf16-storage mode."""
-    esz = 2 if act_bf16() else 4
-    return max(1, (2 ** 32 - 1) // (int(frames) * 64 * 64 * esz))
+    """Largest batch the kernels take in one launch.  Round 4: the conv kernels add a 64-bit per-image base to 32-bit offsets
+    INSIDE the image, so what is left is the 31-bit PIXEL index of the BatchNorm / pool passes over the largest tensor, the
+    first block's (B, frames, 64 mel) pixels -- 33 520 clips of 10 s (rounds 1-3: 32-bit byte offsets over the whole batch, 261
+    clips of 10 s in fp32).  Memory is the practical limit: ~75 MB of saved activations per 10 s clip in fp32."""
+    return max(1, (2 ** 31 - 1) // (int(frames) * 64))
 
 
 def check_pass_size(B: int, frames: int):
-    """Loud and early instead of TAG_EINVAL from the first conv: a training batch beyond the 32-bit offset range must be split by
-    the CALLER (train-mode BatchNorm statistics are per forward pass, so the split is not invisible; the inference wrapper
-    models/hf_modeling_grounding.py does split -- eval-mode BatchNorm makes its passes independent)."""
+    """Loud and early instead of TAG_EINVAL from the first kernel: a batch beyond the 31-bit pixel index must be split by the
+    CALLER (train-mode BatchNorm statistics are per forward pass, so the split is not invisible; the inference wrapper
+    models/hf_modeling_grounding.py splits into passes of 64 for memory -- eval-mode BatchNorm makes its passes independent)."""
     lim = max_clips_per_pass(frames)
     if B > lim:
-        raise RuntimeError(f"batch of {B} clips x {frames} frames exceeds the conv kernels' 32-bit activation offsets: at most {lim} "
-                           f"clips of this length per forward pass ({'bf16' if act_bf16() else 'fp32'} storage). Split the batch "
-                           "(gradient accumulation over sub-batches; note that train-mode BatchNorm statistics are then per "
-                           "sub-batch, as they would be with a smaller batch in the reference)")
+        raise RuntimeError(f"batch of {B} clips x {frames} frames exceeds the kernels' 31-bit pixel index: at most {lim} clips of "
+                           "this length per forward pass. Split the batch (gradient accumulation over sub-batches; note that "
+                           "train-mode BatchNorm statistics are then per sub-batch, as they would be with a smaller batch in the "
+                           "reference)")
 
 
 def gru_bidir_forward(x2d, rnn, B, T, need_grad):

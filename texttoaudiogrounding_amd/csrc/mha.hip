@@ -11,6 +11,7 @@
 //   * resln_head_{fwd,bwd}: z = audio + dropout(attn_out); LayerNorm(z) * gamma + beta; Linear(E,1); sigmoid -- one wave
 //     per frame, E spread over the lanes.  Backward writes dz (shared by the two residual branches up to the dropout mask)
 //     and the per-row terms of dW_linear / dgamma / dbeta, which the caller folds with tag_colsum (fixed order).
+#include <stdlib.h>
 #include "tag_common.h"
 
 namespace {
@@ -321,6 +322,213 @@ __global__ __launch_bounds__(256) void resln_head_bwd_kernel(const float* __rest
         }                                                                                               \
     }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The attention core on the matrix pipe (round 4; BASELINE configs[3] names "audio-text cross-attention as MFMA kernel").
+// One wave per (clip, head, tile of 32 frames), exact-fp32 v_mfma_f32_32x32x2_f32 (an fmaf chain per output, like every
+// fp32 kernel of the library).  The scores are formed TRANSPOSED, S^T[token][frame] = K_h Q_h^T, so that in the MFMA result
+// layout (column = lane & 31, rows over the 16 registers and the two half-waves) a lane owns ONE frame and 16 of its 32
+// tokens: the softmax over the tokens is a reduction over registers plus one lane ^ 32 exchange, and the probabilities
+// P^T[token][frame] sit exactly where the B operand of the next product wants them -- step j of  ctx^T = V_h^T P^T  takes
+// register j (k-slot = half-wave <-> token (j&3) + 8 (j>>2) + 4 half) with no data movement at all.  The same holds for
+// dQ^T = K_h^T dS^T in the backward pass; the two token-side products (dV = Pd^T-as-(tokens x frames) dctx, dK = dS Q), whose
+// contraction runs over the FRAMES (= lanes here), take their A operand through a wave-private 32 x 33 LDS transpose.
+// Operand rows are read as contiguous half-rows (k-slot s of step j <-> column s * DH/2 + j: any bijection of the
+// contraction index serves both operands alike).  32 + 32 MFMAs per wave forward, 128 backward.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int d_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }     // MFMA result row of register r
+
+template <int HD>
+__device__ __forceinline__ void load_half_row(float (&dst)[HD], const float* p, bool ok) {
+#pragma unroll
+    for (int j = 0; j < HD; j += 4) {
+        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(p + j) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        dst[j] = v.x; dst[j + 1] = v.y; dst[j + 2] = v.z; dst[j + 3] = v.w;
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_cross_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const long* __restrict__ klen,
+                                                                 float* __restrict__ attn, float* __restrict__ ctx, int B, int T,
+                                                                 int L, int E, int H, float scale, float drop_p, uint64_t seed) {
+    constexpr int HD = DH / 2;
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const int NT = (T + 31) / 32;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)B * H * NT) return;
+    const int tile = (int)(item % NT), h = (int)((item / NT) % H), b = (int)(item / ((long)NT * H));
+    const int f = tile * 32 + n;                                   // this lane's frame (result column)
+    const bool fok = f < T;
+    const long row = (long)b * T + (fok ? f : T - 1);
+    const int kl = (int)klen[b];
+    // S^T = K_h Q_h^T: A = K (row = token n), B = Q^T (column = frame n); k-slot `half` of step j = column half * HD + j
+    float ka[HD], qb[HD];
+    load_half_row<HD>(ka, k + ((long)b * L + (n < L ? n : 0)) * E + h * DH + half * HD, n < L);
+    load_half_row<HD>(qb, q + row * E + h * DH + half * HD, fok);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HD; ++j) s = mfma_f32(ka[j], qb[j], s);
+    // softmax over the tokens of this lane's frame: 16 registers here, 16 in lane ^ 32
+    float p[16], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = d_row(r, half) < kl ? s[r] * scale : -INFINITY;     // key_padding_mask
+        mx = fmaxf(mx, p[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mx); den += p[r]; }     // kl == 0: exp(-inf + inf) = NaN, as nn.MultiheadAttention
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.0f / den, keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = d_row(r, half);
+        p[r] *= inv;
+        const long ai = (row * H + h) * L + t;
+        if (fok && t < L) attn[ai] = p[r];                         // the weights BEFORE dropout (what backward needs)
+        if (drop_p > 0.0f) p[r] = (t < L && tag_keep(seed, (uint64_t)ai, drop_p)) ? p[r] * keep_scale : 0.0f;
+    }
+    // ctx^T = V_h^T Pd^T, 32 channels at a time: A = V^T (row = channel, k-slot <-> token d_row(j, half)), B = register j of Pd^T
+#pragma unroll
+    for (int db = 0; db < DH / 32; ++db) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int t = d_row(j, half);
+            const float a = t < L ? v[((long)b * L + t) * E + h * DH + db * 32 + n] : 0.0f;
+            c = mfma_f32(a, p[j], c);
+        }
+        if (fok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)                             // rows 8 g + 4 half .. + 3 = four consecutive channels of the frame
+                *reinterpret_cast<f32x4*>(ctx + row * E + h * DH + db * 32 + 8 * g + 4 * half) =
+                    (f32x4){c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+        }
+    }
+}
+
+// dq (B,T,E) final; dk_p / dv_p (B,NT,L,E) per-tile partials (NT = tiles of 32 frames), folded by mha_fold_tiles_kernel.
+template <int DH>
+__global__ __launch_bounds__(256) void mha_cross_bwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ attn,
+                                                                 const float* __restrict__ dctx, const long* __restrict__ klen,
+                                                                 float* __restrict__ dq, float* __restrict__ dk_p,
+                                                                 float* __restrict__ dv_p, int B, int T, int L, int E, int H,
+                                                                 float scale, float drop_p, uint64_t seed) {
+    constexpr int HD = DH / 2;
+    __shared__ float xs[4][32 * 33];                               // wave-private transpose tile [token][frame]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
+    const int NT = (T + 31) / 32;
+    const long item = (long)blockIdx.x * 4 + wv;
+    if (item >= (long)B * H * NT) return;
+    const int tile = (int)(item % NT), h = (int)((item / NT) % H), b = (int)(item / ((long)NT * H));
+    const int f0 = tile * 32, f = f0 + n;
+    const bool fok = f < T;
+    const long row = (long)b * T + (fok ? f : T - 1);
+    const int kl = (int)klen[b];
+    const float keep_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float* X = xs[wv];
+    // d(dropped weights)^T[token][frame] = V_h dctx_h^T: same operand shapes as the forward scores
+    f32x16 s;
+    {
+        float va[HD], gb[HD];
+        load_half_row<HD>(va, v + ((long)b * L + (n < L ? n : 0)) * E + h * DH + half * HD, n < L);
+        load_half_row<HD>(gb, dctx + row * E + h * DH + half * HD, fok);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < HD; ++j) s = mfma_f32(va[j], gb[j], s);
+    }
+    // softmax backward per frame (= per lane pair): ds = a (g - sum_t a g) scale; ad = the dropped weights the forward multiplied V with
+    float ds[16], ad[16], dot = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = d_row(r, half);
+        const long ai = (row * H + h) * L + t;
+        const float a = (fok && t < L) ? attn[ai] : 0.0f;
+        float g = s[r];
+        ad[r] = a;
+        if (drop_p > 0.0f) {
+            const bool keep = t < L && tag_keep(seed, (uint64_t)ai, drop_p);
+            g = keep ? g * keep_scale : 0.0f;
+            ad[r] = keep ? a * keep_scale : 0.0f;
+        }
+        ds[r] = g;
+        dot = fmaf(a, g, dot);
+        s[r] = a;                                                   // keep a for the second half of the formula
+    }
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = d_row(r, half) < kl ? s[r] * (ds[r] - dot) * scale : 0.0f;
+    // dQ^T = K_h^T dS^T: A = K^T (row = channel, k-slot <-> token d_row(j, half)), B = register j of dS^T
+#pragma unroll
+    for (int db = 0; db < DH / 32; ++db) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int t = d_row(j, half);
+            const float a = t < L ? k[((long)b * L + t) * E + h * DH + db * 32 + n] : 0.0f;
+            c = mfma_f32(a, ds[j], c);
+        }
+        if (fok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(dq + row * E + h * DH + db * 32 + 8 * g + 4 * half) =
+                    (f32x4){c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+        }
+    }
+    // token-side products: contraction over the FRAMES.  A = M[token][frame] (through the transpose tile: k-slot `half` of step j
+    // = frame half * 16 + j), B = rows of dctx / q (column = channel n)
+    auto token_side = [&](const float (&m)[16], const float* __restrict__ rhs, float* __restrict__ out) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // earlier reads of X are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[d_row(r, half) * 33 + n] = fok ? m[r] : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float am[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) am[j] = X[n * 33 + half * 16 + j];
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int fr = f0 + half * 16 + j;
+                const float bv = fr < T ? rhs[((long)b * T + fr) * E + h * DH + db * 32 + n] : 0.0f;
+                c = mfma_f32(am[j], bv, c);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                          // result row = token, column = channel n
+                const int t = d_row(r, half);
+                if (t < L) out[(((long)b * NT + tile) * L + t) * E + h * DH + db * 32 + n] = c[r];
+            }
+        }
+    };
+    token_side(ad, dctx, dv_p);
+    token_side(ds, q, dk_p);
+}
+
+static bool mha_mfma_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TAG_MHA_MFMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+static bool mha_mfma_ok(int E, int H) {
+    const int dh = E / H;
+    return mha_mfma_enabled() && (dh == 32 || dh == 64 || dh == 128) && E % 4 == 0;
+}
+
 static bool mha_shape_ok(int E, int H, int L) {
     if (E <= 0 || H <= 0 || E % H != 0 || L <= 0 || L > MAXL || E > 64 * MAXE) return false;
     const int dh = E / H;
@@ -335,6 +543,15 @@ extern "C" int tag_mha_cross_forward(const float* q, const float* k, const float
     TAG_CHECK_ARG(mha_shape_ok(E, H, L) && drop_p >= 0.0f && drop_p < 1.0f);
     const int dh = E / H;
     const float scale = 1.0f / sqrtf((float)dh);
+    if (mha_mfma_ok(E, H)) {                                       // the attention core on the matrix pipe (exact fp32 MFMA)
+        const int g4 = cdiv((long)B * H * cdiv(T, 32), 4);
+#define MFMA_FWD(DH_) hipLaunchKernelGGL((mha_cross_fwd_mfma_kernel<DH_>), dim3(g4), dim3(256), 0, as_stream(stream), q, k, v, klen, \
+                                         attn, ctx, B, T, L, E, H, scale, drop_p, seed)
+        if (dh == 32) MFMA_FWD(32); else if (dh == 64) MFMA_FWD(64); else MFMA_FWD(128);
+#undef MFMA_FWD
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     const int grid = cdiv((long)B * T, 4);
     MHA_DISPATCH(E, dh, hipLaunchKernelGGL((mha_cross_fwd_kernel<NE, HL>), dim3(grid), dim3(256), 0, as_stream(stream), q, k,
                                            v, klen, attn, ctx, B, T, L, E, H, scale, drop_p, seed))
@@ -351,10 +568,18 @@ extern "C" int tag_mha_cross_backward(const float* q, const float* k, const floa
                                       float drop_p, uint64_t seed, void* ws, void* stream) {
     TAG_CHECK_ARG(q && k && v && attn && dctx && klen && dq && dk && dv && ws && B > 0 && T > 0);
     TAG_CHECK_ARG(mha_shape_ok(E, H, L) && drop_p >= 0.0f && drop_p < 1.0f);
-    const int dh = E / H, NT = cdiv(T, QT);
+    const bool mfma = mha_mfma_ok(E, H);
+    const int dh = E / H, NT = mfma ? cdiv(T, 32) : cdiv(T, QT);
     const float scale = 1.0f / sqrtf((float)dh);
     float* dk_p = static_cast<float*>(ws);
     float* dv_p = dk_p + (size_t)B * NT * L * E;
+    if (mfma) {
+        const int g4 = cdiv((long)B * H * NT, 4);
+#define MFMA_BWD(DH_) hipLaunchKernelGGL((mha_cross_bwd_mfma_kernel<DH_>), dim3(g4), dim3(256), 0, as_stream(stream), q, k, v, attn, \
+                                         dctx, klen, dq, dk_p, dv_p, B, T, L, E, H, scale, drop_p, seed)
+        if (dh == 32) MFMA_BWD(32); else if (dh == 64) MFMA_BWD(64); else MFMA_BWD(128);
+#undef MFMA_BWD
+    } else
     MHA_DISPATCH(E, dh, hipLaunchKernelGGL((mha_cross_bwd_kernel<NE, HL>), dim3(B * NT), dim3(64), 0, as_stream(stream), q, k, v,
                                            attn, dctx, klen, dq, dk_p, dv_p, B, T, L, E, H, scale, drop_p, seed, NT))
     TAG_LAUNCH_CHECK();

@@ -45,6 +45,11 @@
 #ifndef TAG_ROWS_NACC
 #define TAG_ROWS_NACC 2        // accumulator sets the k loop alternates between (dependent-MFMA latency)
 #endif
+#ifndef TAG_ROWS_M16
+#define TAG_ROWS_M16 0         // 1: v_mfma_f32_16x16x32_bf16 (2 x 2 blocks per wave tile), 0: v_mfma_f32_32x32x16_bf16.  Same FLOP rate, same
+#endif                         // operand traffic per FLOP here (an A fragment feeds two products); tools/mfma_peak.hip: the 16x16x32
+                               // shape sustains 2.01-2.05 PFLOP/s on random operands against 1.81-1.85 for 32x32x16 (fewer
+                               // accumulator reads and writes per FLOP) -- in a power-limited kernel that is clock
 #ifndef TAG_ROWS_NA
 #define TAG_ROWS_NA 6          // A fragments in flight: the fragment of product f + NA - 1 is read while product f multiplies
 #endif
@@ -65,6 +70,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // MFMA row i (0..31) -> pixel of the 32-pixel block such that the ds_read_b128 lane groups {0-3,12-15,20-27} and
@@ -163,8 +171,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
     {
         const int NBK = Cout / 32;
         const u32x4* wl = wp + (size_t)(n0 / 32 + wn) * 192 + lane;      // + ((tap*KS + ks) * NBK) * 192
+#if TAG_ROWS_M16
+        // 16x16x32 B fragment (tap, k32, ni): lane (column n15 = lane & 15, k octet kq = lane >> 4) holds k = 32 k32 + 8 kq .. + 7 of cout
+        // ni * 16 + n15 = the 16 bytes the 32x32x16 pack keeps at fragment (tap, kk16 = 2 k32 + (kq >> 1)), lane (kq & 1) * 32 + ni * 16 + n15
+        const int kq = lane >> 4, n15 = lane & 15;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {                          // f = (tap * KS/2 + k32) * 2 + ni
+            const int ni = f & 1, k32 = (f >> 1) % (KS / 2), tap = (f >> 1) / (KS / 2);
+            bq[f] = wp[((size_t)(tap * KS + 2 * k32 + (kq >> 1)) * NBK + n0 / 32 + wn) * 192 + (kq & 1) * 32 + ni * 16 + n15];
+        }
+        (void)wl;
+#else
 #pragma unroll
         for (int f = 0; f < NF; ++f) bq[f] = wl[(size_t)f * NBK * 192];
+#endif
     }
 
     // ---- zeros everywhere (plane heads, the zero slot), the prologue table ----
@@ -229,14 +249,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
     };
 
     // ---- A-fragment lane base: plane kl, pixel slot = column (the slot in front of column 0 is the plane's zero head) ----
+#if TAG_ROWS_M16
+    // 16x16x32: lane = (pixel lane & 15 of a 16-pixel block, k octet lane >> 4 of a 32-channel group); block mi at + mi * 256 bytes
+    const unsigned abase = (unsigned)((lane >> 4) * G::PLB + (wm * 32 + (lane & 15)) * 16);   // + slot + (k32 * 4 * PLB + mi * 256 + kx * 16)
+    constexpr int NCH = 2;                                  // couts per lane: ni * 16 + (lane & 15)
+    // result element e = (mi * 2 + ni) * 4 + r: pixel mi * 16 + 4 (lane >> 4) + r of the wave's 32, cout ni * 16 + (lane & 15) of its 32
+    auto PIX = [&](int e) { return (e >> 3) * 16 + 4 * (lane >> 4) + (e & 3); };
+    auto CHL = [&](int e) { return ((e >> 2) & 1) * 16 + (lane & 15); };
+    auto CHI = [](int e) { return (e >> 2) & 1; };
+#else
     const int col = wm * 32 + row_to_pix(ml);
     const unsigned abase = (unsigned)(kl * G::PLB + col * 16);   // + slot base + (ks * 2 * PLB + kx * 16) as an immediate
+    constexpr int NCH = 1;
+    // result element e = register e of the 32x32 tile: D col = lane & 31 (cout), D row = (e&3) + 8 (e>>2) + 4 kl -> pixel via row_to_pix
+    auto PIX = [&](int e) { return row_to_pix((e & 3) + 8 * (e >> 2) + 4 * kl); };
+    auto CHL = [&](int e) { return ml; };
+    auto CHI = [](int e) { return 0; };
+#endif
 
-    // ---- epilogue constants ----
-    const int n = n0 + wn * 32 + ml;
-    float e_sc = 0.0f, e_sh = 0.0f, e_mu = 0.0f, e_is = 0.0f;
-    if (EPI == 2) { e_sc = epi.scale[n]; e_sh = epi.shift[n]; e_mu = epi.mean[n]; e_is = epi.invstd[n]; }
-    float st_mu = 0.0f, st_a = 0.0f, st_b = 0.0f;           // EPI 1: pivot, sum(y - pivot), sum (y - pivot)^2; EPI 2: sum g, sum g*xhat
+    // ---- epilogue constants (per cout of this lane) ----
+    float e_sc[NCH], e_sh[NCH], e_mu[NCH], e_is[NCH], st_mu[NCH], st_a[NCH], st_b[NCH];   // EPI 1: pivot, sum(y - pivot), sum (y - pivot)^2
+#pragma unroll                                                                            // EPI 2: sum g, sum g * xhat
+    for (int c = 0; c < NCH; ++c) {
+        const int n = n0 + wn * 32 + CHL(c * 4);
+        e_sc[c] = e_sh[c] = e_mu[c] = e_is[c] = st_mu[c] = st_a[c] = st_b[c] = 0.0f;
+        if (EPI == 2) { e_sc[c] = epi.scale[n]; e_sh[c] = epi.shift[n]; e_mu[c] = epi.mean[n]; e_is[c] = epi.invstd[n]; }
+    }
 
     // Ring index u = input row r0 - 1 + u.  The matrix phase of output row rho (phase rho) reads u = rho, rho + 1, rho + 2 and,
     // in the issue shadow of its MFMAs, applies the producer BatchNorm + ReLU to row rho + 3 (first read in phase rho + 1); the
@@ -271,15 +309,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
             const int ri = r0 - 1 + rho + ky;
             va[ky] = abase + (unsigned)(((unsigned)ri < (unsigned)H ? (rho + ky) % D : D) * G::SLOT);
         }
-        f32x16 acc[NACC];
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-        auto a_ptr = [&](int f) {
-            const int tap = f / KS, ks = f % KS, ky = tap / 3, kx = tap % 3;
-            return smem + va[ky] + (ks * 2 * G::PLB + kx * 16);
-        };
         // ring row rho + 3 (issued PF tails ago by this wave) has landed: its planes are transformed between the MFMAs below
         wait_vmcnt<G::NWAIT_X>();
         RP_MARK(2)
@@ -292,27 +321,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
                 traw[k] = *reinterpret_cast<const u32x4*>(tpp[k]);
             }
         }
-        // NA - 1 reads stay in flight: LDS latency under 8 waves per CU is several MFMA issue times
-        constexpr int NA = TAG_ROWS_NA;
-        u32x4 af[NA];
-#pragma unroll
-        for (int f = 0; f < NA - 1; ++f) af[f] = *reinterpret_cast<const u32x4*>(a_ptr(f));
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int TF0 = 6;                              // first product with a piece of the transform behind it
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-#ifndef TAG_ROWS_ABL    // energy ablations (WRONG results): 1 = every second A fragment is not read (reuses its neighbour), 2 = only NA - 1 reads per row
-            if (f + NA - 1 < NF) af[(f + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(f + NA - 1));
-            acc[f % NACC] = mfma_bf16(af[f % NA], bq[f], acc[f % NACC]);
-#elif TAG_ROWS_ABL == 1
-            if (f + NA - 1 < NF && (f & 1) == 0) af[(f + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(f + NA - 1));
-            acc[f % NACC] = mfma_bf16(af[(f | 1) % NA], bq[f], acc[f % NACC]);
-#else
-            acc[f % NACC] = mfma_bf16(af[f % (NA - 1)], bq[f], acc[f % NACC]);
-#endif
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // pin: 1 MFMA, 1 LDS read, (one dword pair of the transform)
-            if (f + NA - 1 < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (PRO != 0 && f >= TF0 && f < TF0 + 4 * KX) {         // one packed dword (two channels) of one plane per product
+        // one packed dword (two channels) of one plane of the producer transform, placed behind product f
+        constexpr int TF0 = 6;
+        auto transform_step = [&](int f) {
+            if (PRO != 0 && f >= TF0 && f < TF0 + 4 * KX) {
                 const int k = (f - TF0) / 4, d = (f - TF0) % 4;
                 const unsigned w = traw[k][d];
                 tout[k][d] = tag_pack_bf16(fmaxf(fmaf(tag_bf16_lo(w), tsc[k][2 * d], tsh[k][2 * d]), 0.0f),
@@ -323,10 +335,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
             }
+        };
+        float val[16];                                      // the wave's 32 px x 32 co results, element e <-> (PIX(e), CHL(e))
+        constexpr int NA = TAG_ROWS_NA;
+#if TAG_ROWS_M16
+        // 9 taps x KS/2 k32 steps x (2 A fragments, 4 MFMAs on 4 independent accumulators): NA - 1 A reads stay in flight
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        constexpr int NAF = 9 * (KS / 2) * 2;               // A fragments per row: index a = (tap * KS/2 + k32) * 2 + mi
+        auto a_ptr = [&](int a) {
+            const int mi = a & 1, k32 = (a >> 1) % (KS / 2), tap = (a >> 1) / (KS / 2), ky = tap / 3, kx = tap % 3;
+            return smem + va[ky] + (k32 * 4 * G::PLB + mi * 256 + kx * 16);
+        };
+        u32x4 af[NA];
+#pragma unroll
+        for (int a = 0; a < NA - 1; ++a) af[a] = *reinterpret_cast<const u32x4*>(a_ptr(a));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < NAF; ++a) {
+            if (a + NA - 1 < NAF) af[(a + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(a + NA - 1));
+            const int mi = a & 1, fb = (a >> 1) * 2;        // B fragments fb (ni = 0), fb + 1 (ni = 1)
+            acc[mi][0] = mfma16_bf16(af[a % NA], bq[fb], acc[mi][0]);
+            acc[mi][1] = mfma16_bf16(af[a % NA], bq[fb + 1], acc[mi][1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // pin: 2 MFMAs, 1 LDS read
+            if (a + NA - 1 < NAF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            transform_step(a);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) val[e] = acc[e >> 3][(e >> 2) & 1][e & 3];
+#else
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+        auto a_ptr = [&](int f) {
+            const int tap = f / KS, ks = f % KS, ky = tap / 3, kx = tap % 3;
+            return smem + va[ky] + (ks * 2 * G::PLB + kx * 16);
+        };
+        // NA - 1 reads stay in flight: LDS latency under 8 waves per CU is several MFMA issue times
+        u32x4 af[NA];
+#pragma unroll
+        for (int f = 0; f < NA - 1; ++f) af[f] = *reinterpret_cast<const u32x4*>(a_ptr(f));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (f + NA - 1 < NF) af[(f + NA - 1) % NA] = *reinterpret_cast<const u32x4*>(a_ptr(f + NA - 1));
+            acc[f % NACC] = mfma_bf16(af[f % NA], bq[f], acc[f % NACC]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // pin: 1 MFMA, 1 LDS read, (one dword pair of the transform)
+            if (f + NA - 1 < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            transform_step(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) val[e] = acc[0][e] + (NACC == 2 ? acc[NACC - 1][e] : 0.0f);
+#endif
 #ifdef TAG_ROWS_PROF
-        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[NACC - 1][0]));     // the last products have retired
+        asm volatile("s_nop 0" :: "v"(val[0]), "v"(val[15]));     // the last products have retired
 #endif
         RP_MARK(1)
         lds_fence_barrier();                                // end of phase rho
@@ -336,48 +405,45 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
         // the yref tile of row rho was issued PF tails ago by this wave
         if (EPI == 2) wait_vmcnt<G::NWAIT_Y>();
         RP_MARK(2)
-        if (NACC == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
-        }
         RP_MARK(3)
-        // D col = lane & 31 (cout), D row = (r&3) + 8 (r>>2) + 4 kl -> pixel via row_to_pix.  Window = [32 pixels][32 couts] bf16:
-        // EPI 2 reads the yref values first, then the packed outputs overwrite them (no other wave touches the window)
+        // Window = [32 pixels][32 couts] bf16: EPI 2 reads the yref values first, then the packed outputs overwrite them (no other
+        // wave touches the window)
         unsigned char* win = win0 + (EPI == 2 ? (j % PF) * G::WINB : 0);
         float yv[EPI == 2 ? 16 : 1];
         if (EPI == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pm = row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl);
-                yv[r] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(win + pm * 64 + ml * 2) << 16);
-            }
+            for (int e = 0; e < 16; ++e)
+                yv[e] = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(win + PIX(e) * 64 + CHL(e) * 2) << 16);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pm = row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl);
-            *reinterpret_cast<unsigned short*>(win + pm * 64 + ml * 2) = (unsigned short)tag_pack_bf16(acc[0][r], 0.0f);
-        }
+        for (int e = 0; e < 16; ++e)
+            *reinterpret_cast<unsigned short*>(win + PIX(e) * 64 + CHL(e) * 2) = (unsigned short)tag_pack_bf16(val[e], 0.0f);
         if (EPI == 1) {
-            if (j == 0) {                                   // pivot = mean of the wave's first tile
-                float s = 0.0f;
+            if (j == 0) {                                   // pivot per cout = mean of the wave's first tile
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[0][r];
-                s += __shfl_xor(s, 32, 64);
-                st_mu = s * (1.0f / 32.0f);
+                for (int c = 0; c < NCH; ++c) {
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sm += CHI(e) == c ? val[e] : 0.0f;
+                    if (NCH == 2) sm += __shfl_xor(sm, 16, 64);
+                    sm += __shfl_xor(sm, 32, 64);
+                    st_mu[c] = sm * (1.0f / 32.0f);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc[0][r] - st_mu;
-                st_a += d;
-                st_b = fmaf(d, d, st_b);
+            for (int e = 0; e < 16; ++e) {
+                const float d = val[e] - st_mu[CHI(e)];
+                st_a[CHI(e)] += d;
+                st_b[CHI(e)] = fmaf(d, d, st_b[CHI(e)]);
             }
         }
         if (EPI == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float g = fmaf(yv[r], e_sc, e_sh) > 0.0f ? acc[0][r] : 0.0f;
-                st_a += g;
-                st_b = fmaf(g, (yv[r] - e_mu) * e_is, st_b);
+            for (int e = 0; e < 16; ++e) {
+                const int c = CHI(e);
+                const float g = fmaf(yv[e], e_sc[c], e_sh[c]) > 0.0f ? val[e] : 0.0f;
+                st_a[c] += g;
+                st_b[c] = fmaf(g, (yv[e] - e_mu[c]) * e_is[c], st_b[c]);
             }
         }
         RP_MARK(4)
@@ -413,16 +479,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
     if (EPI != 0) {
         const int prow = ((img * NS + strip) * 2 + grp) * WM + wm;
         const int P = B * NS * 2 * WM;
-        st_a += __shfl_xor(st_a, 32, 64);
-        st_b += __shfl_xor(st_b, 32, 64);
-        if (EPI == 1) {
-            float* ps = stats + (size_t)prow * 3 * Cout;
-            if (kl == 0) { ps[n] = st_mu; ps[Cout + n] = st_a; ps[2 * Cout + n] = st_b; }
-            if (nt == 0 && wn == 0 && lane == 0) stats[(size_t)P * 3 * Cout + prow] = (float)(j * 32);
-        } else {
-            float* ps = stats + (size_t)prow * 2 * Cout;
-            if (kl == 0) { ps[n] = st_a; ps[Cout + n] = st_b; }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (NCH == 2) { st_a[c] += __shfl_xor(st_a[c], 16, 64); st_b[c] += __shfl_xor(st_b[c], 16, 64); }
+            st_a[c] += __shfl_xor(st_a[c], 32, 64);
+            st_b[c] += __shfl_xor(st_b[c], 32, 64);
+            const int n = n0 + wn * 32 + CHL(c * 4);
+            const bool writer = NCH == 2 ? lane < 16 : kl == 0;
+            if (EPI == 1) {
+                float* ps = stats + (size_t)prow * 3 * Cout;
+                if (writer) { ps[n] = st_mu[c]; ps[Cout + n] = st_a[c]; ps[2 * Cout + n] = st_b[c]; }
+            } else {
+                float* ps = stats + (size_t)prow * 2 * Cout;
+                if (writer) { ps[n] = st_a[c]; ps[Cout + n] = st_b[c]; }
+            }
         }
+        if (EPI == 1 && nt == 0 && wn == 0 && lane == 0) stats[(size_t)P * 3 * Cout + prow] = (float)(j * 32);
     }
 }
 

@@ -246,20 +246,26 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 // ------------------------------------------------------------------------------------------
 // Halo-tile forward / dgrad kernel (images whose width is 8, 16, 32 or 64 -- every Cnn8Rnn / CrnnEncoder layer).
 // The 128 output pixels of a workgroup form a TH x TW rectangle of ONE image; for each 32-channel chunk the
-// (TH+2) x (TW+2) input patch is staged ONCE in LDS (k-major, BN+ReLU prologue and zero padding applied there)
-// and all 9 taps read it at a shifted base -- 4-7x fewer global loads and LDS stores than the tap-by-tap kernel
-// above, no per-tap masks.  The 32 x BN_ weight chunk of each (chunk, tap) step is double buffered in LDS.
+// (TH+2) x (TW+2) input patch is staged ONCE in LDS (BN+ReLU prologue and zero padding applied there) and all 9 taps
+// read it at a shifted base -- 4-7x fewer global loads and LDS stores than the tap-by-tap kernel above, no per-tap masks.
+//
+// Round 4 form (tools/coissue_probe.hip, tools/run_halo_prof.sh):
+//  * beside another wave's fp32 MFMA stream on the same SIMD a ds_write_b32 issues once per ~1250-5000 clocks (12-26 on an idle
+//    SIMD) while ds_write_b64 / b128, every LDS read, VALU work and global loads are unaffected.  The patch used to be stored
+//    k-major with 24 ds_write_b32 per thread and chunk (5800 clocks per chunk in the phase clocks): it is now PIXEL-major,
+//    36 floats per patch pixel (row stride = 4 banks mod 32: the 16-byte pieces of 8 consecutive pixels cover the 32 banks),
+//    written with 6 ds_write_b128 per thread.
+//  * an A fragment is one ds_read_b128 per lane = 4 consecutive channels, i.e. the A operands of FOUR k-steps: k-step j of
+//    channel group g (8 channels) multiplies channel 8g + 4 kl + j (kl = lane / 32), the B rows follow the same order.
+//    MFMA row -> pixel goes through halo_row_to_pix so that the ds_read_b128 lane groups read 16 consecutive pixels.
+//  * the 32 x BN_ weight chunk of a (chunk, tap) step is staged per HALF tap (16 channels) in two LDS buffers of half the size:
+//    the half after the next one is requested from L2 at the start of a half, the next half is written to the other buffer in
+//    the middle of the current half's MFMA stream, one barrier ends each half.  Same LDS and barrier count as the single
+//    buffer (free / full) it replaces, but no store phase between two barriers in which the wave issues no MFMA
+//    (127.7 -> 131.1 TFLOP/s forward, 131.2 -> 133.8 dgrad over the layer shapes at B = 64).
+//  * measured and dropped on the way: weight operands straight from L2 into registers (no LDS buffer, no per-tap barrier):
+//    121 TFLOP/s; a second full-tap buffer for the 64-cout tiles: 2.59 -> 2.61 ms.
 // ------------------------------------------------------------------------------------------
-#ifndef TAG_HALO_NB
-#define TAG_HALO_NB 1
-#endif
-// weight-chunk buffers of the 64-cout tiles (their own knob: a second 8 KB buffer still leaves 3 workgroups per CU, and a
-// 64-cout tap is only 32 MFMAs per wave between the barriers).  Measured with 2: 64 -> 64 at W = 64 2.59 -> 2.61 ms,
-// 128 -> 64 at W = 32 1.17 -> 1.23 ms -- the second barrier per tap is not what holds these tiles at 0.77 MFMA busy.
-#ifndef TAG_HALO_NB64
-#define TAG_HALO_NB64 1
-#endif
-template <int BN_> constexpr int halo_nb() { return BN_ == 64 ? TAG_HALO_NB64 : TAG_HALO_NB; }
 // -DTAG_HALO_PROF (tools/run_halo_prof.sh, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
 #ifdef TAG_HALO_PROF
 __device__ unsigned long long tag_halo_prof[8];
@@ -271,9 +277,15 @@ __device__ unsigned long long tag_halo_sub[4];        // (written by every workg
 template <int TW>
 struct HaloGeom {
     static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
-    static constexpr int LDP = ((PP + 6) / 8) * 8 + 1;            // = 1 (mod 8): conflict-free transposing stores
+    static constexpr int AROW = 36;                               // floats per patch pixel in LDS (32 channels + 4 pad)
+    static constexpr int ASZ = PP * AROW;
     static constexpr int ITEMS = (PP * 8 + 255) / 256;            // float4 per thread per patch chunk
 };
+// MFMA row i (0..31) -> pixel inside the 32-pixel block: the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
+// read pixels 0..15 / 16..31 (quad map [0,4,5,1,6,2,3,7], the same as the bf16 kernels of conv_x3.hip)
+__device__ __forceinline__ int halo_row_to_pix(int i) {
+    return (int)((0xED6360u >> (3 * (i >> 2))) & 7u) * 4 + (i & 3);
+}
 
 // Epilogue operands of the dgrad launches (EPI == 1): the tensor whose BatchNorm+ReLU the gradient flows into next.
 struct BnBwdEpi {
@@ -285,18 +297,17 @@ struct BnBwdEpi {
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
-__global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
                                                               int Cin, int Cout) {
     using G = HaloGeom<TW>;
-    constexpr int TN = BN_ / 64, B_LOADS = BN_ / 32, NB = halo_nb<BN_>();
+    constexpr int TN = BN_ / 64, BH_LOADS = BN_ / 64;            // float4 per thread per half tap (16 x BN_ floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ASZ = ((BK * G::LDP + 3) / 4) * 4;
-    float* As = smem;                          // [BK][LDP] patch, k-major
-    float* Bs = smem + ASZ;                    // [NB][BK][BN_]
-    float* Ss = Bs + NB * BK * BN_;            // [2][Cin] producer BN scale / shift
+    float* As = smem;                          // [PP][AROW] patch, pixel-major
+    float* Bs = smem + G::ASZ;                 // [2][16][BN_] weight half taps
+    float* Ss = Bs + 2 * 16 * BN_;             // [2][Cin] producer BN scale / shift
 
     const int n_tiles = (Cout + BN_ - 1) / BN_;
     const int row_tiles = (H + G::TH - 1) / G::TH;               // W == TW: one tile column
@@ -331,26 +342,19 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
         poff[i] = (unsigned)(((long)pix * Cin + q * 4) * 4);
     }
     const char* ximg = reinterpret_cast<const char*>(x) + (size_t)img * H * W * Cin * 4;      // wave-uniform 64-bit image base
-    unsigned boffb[B_LOADS];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-        const int idx = tid + 256 * i;
-        const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-        int n = n0 + n4 * 4;
-        n = n < Cout ? n : 0;
-        boffb[i] = (unsigned)((k * Cout + n) * 4);
-    }
+    // pixel of the tile behind result register r of row tile i (C/D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 kl)
+    auto tile_m = [&](int i, int r) { return wm0 + i * 32 + halo_row_to_pix((r & 3) + 8 * (r >> 2) + 4 * kl); };
     // per-lane patch position of the two 32-pixel MFMA row tiles (tap (0,0) = +1,+1 inside the patch)
     int pbase[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = wm0 + i * 32 + ml;
+        const int m = wm0 + i * 32 + halo_row_to_pix(ml);
         pbase[i] = (m / TW + 1) * G::PW + (m % TW) + 1;
     }
 
     const int cchunks = Cin / BK;
     const int total = cchunks * 9;
-    f32x4 ra[G::ITEMS], rb[B_LOADS];
+    f32x4 ra[G::ITEMS];
     auto issue_patch = [&](int cc) {
         const unsigned coff = (unsigned)(cc * BK * 4);
 #pragma unroll
@@ -369,26 +373,34 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
             const int pp = (tid + 256 * i) >> 3;
             f32x4 v = apply_prologue(ra[i], PRO, rs, rt);
             if (!((pvalid >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            As[(q * 4 + 0) * G::LDP + pp] = v.x;
-            As[(q * 4 + 1) * G::LDP + pp] = v.y;
-            As[(q * 4 + 2) * G::LDP + pp] = v.z;
-            As[(q * 4 + 3) * G::LDP + pp] = v.w;
+            *reinterpret_cast<f32x4*>(As + pp * G::AROW + q * 4) = v;
         }
     };
-    auto issue_b = [&](int it) {
-        const int cc = it / 9, tap = it - cc * 9;
-        const float* wchunk = wp + ((size_t)tap * Cin + cc * BK) * Cout;
+    // ---- half-tap weight staging (16 k rows x BN_ couts) ----
+    unsigned bhoff[BH_LOADS];
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i)
-            rb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wchunk) + boffb[i]);
+    for (int i = 0; i < BH_LOADS; ++i) {
+        const int idx = tid + 256 * i;
+        const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
+        int n = n0 + n4 * 4;
+        n = n < Cout ? n : 0;
+        bhoff[i] = (unsigned)((k * Cout + n) * 4);
+    }
+    f32x4 rh[2][BH_LOADS];
+    auto issue_bh = [&](int it, int half, f32x4 (&r)[BH_LOADS]) {
+        const int itc = it < total ? it : total - 1;           // past the end: re-read the last tap (stored, never used)
+        const int cc = itc / 9, tap = itc - cc * 9;
+        const char* wchunk = reinterpret_cast<const char*>(wp + ((size_t)tap * Cin + cc * BK + half * 16) * Cout);
+#pragma unroll
+        for (int i = 0; i < BH_LOADS; ++i) r[i] = *reinterpret_cast<const f32x4*>(wchunk + bhoff[i]);
     };
-    auto store_b = [&](int buf) {
-        float* b = Bs + buf * BK * BN_;
+    auto store_bh = [&](int buf, const f32x4 (&r)[BH_LOADS]) {
+        float* b = Bs + buf * 16 * BN_;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
+        for (int i = 0; i < BH_LOADS; ++i) {
             const int idx = tid + 256 * i;
             const int k = idx / (BN_ / 4), n4 = idx % (BN_ / 4);
-            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + k * BN_ + n4 * 4) = r[i];
         }
     };
 
@@ -400,42 +412,50 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    auto mma_tap = [&](int buf, int tap) {
+    // 8 k-steps (channels 16 half .. 16 half + 15 of the chunk) of one tap from weight buffer buf; mid() runs after k-step 3.
+    // k-step ks = 4 g + j multiplies channel 8 g + 4 kl + j of the half: A = element j of the lane's float4 of group g, B = that row.
+    auto mma_half = [&](int buf, int tap, int half, auto&& mid) {
         const int shift = (tap / 3 - 1) * G::PW + (tap % 3 - 1);
-        const float* a0 = As + kl * G::LDP + pbase[0] + shift;
-        const float* a1 = As + kl * G::LDP + pbase[1] + shift;
-        const float* b = Bs + buf * BK * BN_ + kl * BN_ + wn0 + ml;
-        constexpr int PF = 2, NS = BK / 2;
-        float af[PF + 1][2], bf[PF + 1][TN];
+        const float* a0 = As + (pbase[0] + shift) * G::AROW + half * 16 + kl * 4;
+        const float* a1 = As + (pbase[1] + shift) * G::AROW + half * 16 + kl * 4;
+        const float* b = Bs + buf * 16 * BN_ + (kl * 4) * BN_ + wn0 + ml;
+        f32x4 af[2][2];                                         // [channel group][row tile]
+        af[0][0] = *reinterpret_cast<const f32x4*>(a0);
+        af[0][1] = *reinterpret_cast<const f32x4*>(a1);
+        constexpr int PF = 2, NS = 8;
+        float bf[PF + 1][TN];
 #pragma unroll
-        for (int s0 = 0; s0 < PF; ++s0) {
-            af[s0][0] = a0[(2 * s0) * G::LDP];
-            af[s0][1] = a1[(2 * s0) * G::LDP];
+        for (int s0 = 0; s0 < PF; ++s0)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[s0][j] = b[(2 * s0) * BN_ + j * 32];
-        }
+            for (int j = 0; j < TN; ++j) bf[s0][j] = b[((s0 >> 2) * 8 + (s0 & 3)) * BN_ + j * 32];
+        af[1][0] = *reinterpret_cast<const f32x4*>(a0 + 8);
+        af[1][1] = *reinterpret_cast<const f32x4*>(a1 + 8);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
             const int cur = ks % (PF + 1), nxt = (ks + PF) % (PF + 1);
             if (ks + PF < NS) {
-                af[nxt][0] = a0[(2 * (ks + PF)) * G::LDP];
-                af[nxt][1] = a1[(2 * (ks + PF)) * G::LDP];
+                const int kn = ks + PF;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[(2 * (ks + PF)) * BN_ + j * 32];
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = b[((kn >> 2) * 8 + (kn & 3)) * BN_ + j * 32];
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks >> 2][i][ks & 3], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                  // keeps the operand reads of k-step ks + 2 ahead of their use
+            if (ks == 3) { mid(); __builtin_amdgcn_sched_barrier(0); }
         }
     };
 
-#ifdef TAG_HALO_PROF   // 0 prologue, 1 MFMA taps, 2 barrier, 3 operand stores, 4 barrier, 5 output stores, 6 statistics epilogue
+#ifdef TAG_HALO_PROF   // 0 prologue, 1 MFMA taps, 2 barrier, 3 patch stores, 4 barrier (+ wait for the patch loads), 5 output stores, 6 statistics
+    const unsigned long long hrt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: shader clock = sum(hpc) / realtime
     unsigned long long hpc[7] = {0, 0, 0, 0, 0, 0, 0}, hp0 = __builtin_amdgcn_s_memtime();
 #endif
     issue_patch(0);
-    issue_b(0);
+    issue_bh(0, 0, rh[0]);
+    issue_bh(0, 1, rh[1]);
 #ifdef TAG_HALO_PROF
     { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[0] = p1_ - hp0; }
 #endif
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
     { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[1] = p1_ - hp0; }
 #endif
     store_patch(0);
-    store_b(0);
+    store_bh(0, rh[0]);
 #ifdef TAG_HALO_PROF
     { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[2] = p1_ - hp0; }
 #endif
@@ -453,25 +473,33 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
     HP_MARK(0)
     for (int it = 0; it < total; ++it) {
         const int cc = it / 9, tap = it - cc * 9;
-        const int buf = NB == 2 ? (it & 1) : 0;
-        const bool more = it + 1 < total;
         const bool newpatch = tap == 8 && cc + 1 < cchunks;
-        if (more) issue_b(it + 1);
         if (newpatch) issue_patch(cc + 1);
+        issue_bh(it + 1, 0, rh[0]);                            // rh[0] went to LDS during the previous half
         __builtin_amdgcn_sched_barrier(0);
-        mma_tap(buf, tap);
-        __builtin_amdgcn_sched_barrier(0);
+        mma_half(0, tap, 0, [&] { store_bh(1, rh[1]); });      // (it, 1) -> buffer 1, read after the next barrier
         HP_MARK(1)
-        if (NB == 1 || newpatch) __syncthreads();          // all waves are done reading what is overwritten next
-        HP_MARK(2)
-        if (more) store_b(NB == 2 ? (buf ^ 1) : 0);
-        if (newpatch) store_patch(cc + 1);
-        HP_MARK(3)
         __syncthreads();
-        HP_MARK(4)
+        HP_MARK(2)
+        issue_bh(it + 1, 1, rh[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(1, tap, 1, [&] { store_bh(0, rh[0]); });      // (it + 1, 0) -> buffer 0
+        HP_MARK(1)
+        __syncthreads();
+        HP_MARK(2)
+        if (newpatch) {                                        // every wave has read the last tap of the old patch
+#ifdef TAG_HALO_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HP_MARK(4)
+#endif
+            store_patch(cc + 1);
+            HP_MARK(3)
+            __syncthreads();
+            HP_MARK(4)
+        }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel tile_m(i, r) ----
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
             const int n = n0 + wn0 + j * 32 + ml;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;     // pixel inside the tile
+                const int m = tile_m(i, r);                                       // pixel inside the tile
                 const int h = h0 + m / TW, w = m % TW;
                 if (h < H && n < Cout) y[(((size_t)img * H + h) * W + w) * Cout + n] = acc[i][j][r];
             }
@@ -509,15 +537,14 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
                 float yv[16];                                // 16 loads in flight, then their arithmetic
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    const int m = tile_m(i, r);
                     const int h = h0 + m / TW, w = m % TW;
                     const int hc = h < H ? h : H - 1;
                     yv[r] = epi.yref[(((size_t)img * H + hc) * W + w) * Cout + nc];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                    const bool ok = (h0 + m / TW) < H;
+                    const bool ok = (h0 + tile_m(i, r) / TW) < H;
                     const float g = (ok && fmaf(yv[r], sc, sh) > 0.0f) ? acc[i][j][r] : 0.0f;
                     s1 += g;
                     s2 = fmaf(g, (yv[r] - mu) * is, s2);
@@ -535,8 +562,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                cnt += (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H ? 1.0f : 0.0f;
+            for (int r = 0; r < 16; ++r) cnt += (h0 + tile_m(i, r) / TW) < H ? 1.0f : 0.0f;
         cnt += __shfl_xor(cnt, 32, 64);
         const float rc = 1.0f / fmaxf(cnt, 1.0f);
 #pragma unroll
@@ -546,7 +572,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool ok = (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H;
+                    const bool ok = (h0 + tile_m(i, r) / TW) < H;
                     s1 += ok ? acc[i][j][r] : 0.0f;
                 }
             s1 += __shfl_xor(s1, 32, 64);
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool ok = (h0 + (wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) / TW) < H;
+                    const bool ok = (h0 + tile_m(i, r) / TW) < H;
                     const float d = ok ? acc[i][j][r] - mu : 0.0f;
                     r1 += d;
                     q = fmaf(d, d, q);
@@ -570,7 +596,10 @@ __global__ __launch_bounds__(256, (halo_nb<BN_>() == 2 && BN_ != 64) ? 2 : 3) vo
     }
 #ifdef TAG_HALO_PROF
     HP_MARK(6)
-    if (blockIdx.x == 1500 && tid == 0) for (int i = 0; i < 7; ++i) tag_halo_prof[i] = hpc[i];
+    if (blockIdx.x == 1500 && tid == 0) {
+        for (int i = 0; i < 7; ++i) tag_halo_prof[i] = hpc[i];
+        tag_halo_sub[3] = __builtin_amdgcn_s_memrealtime() - hrt0;
+    }
 #endif
 }
 
@@ -1560,7 +1589,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
     // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
     // third workgroup of a CU fits only without the unused part of a 512-channel table)
-    const size_t lds = (size_t)(((BK * G::LDP + 3) / 4) * 4 + halo_nb<BN_>() * BK * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
+    const size_t lds = (size_t)(G::ASZ + 2 * 16 * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
     if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
         static bool attr_set = false;
         if (!attr_set) {
@@ -1965,6 +1994,6 @@ extern "C" int tag_conv3x3_c1_backward_bnrelu_bf16(const float* x, const float* 
 #ifdef TAG_HALO_PROF
 extern "C" int tag_debug_get_halo_prof(unsigned long long* out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_prof), 56) != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out + 7, HIP_SYMBOL(tag_halo_sub), 24) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out + 7, HIP_SYMBOL(tag_halo_sub), 32) == hipSuccess ? 0 : -1;
 }
 #endif

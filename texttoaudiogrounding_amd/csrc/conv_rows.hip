@@ -42,6 +42,9 @@
 #ifndef TAG_ROWS_PF
 #define TAG_ROWS_PF 2          // tails of its group a DMA is issued ahead of the tail that consumes it (>= 2)
 #endif
+#ifndef TAG_ROWS_DMA_SADDR
+#define TAG_ROWS_DMA_SADDR 0   // 1: SGPR-base form of the DMA (glds16s).  Measured: plane DMA 370-374 vs 374 us (nothing), the yref gather
+#endif                         // of the dgrad launches 484 vs 405 us (worse): the partner group's real MFMA stream has gaps, the probe's has none
 #ifndef TAG_ROWS_NACC
 #define TAG_ROWS_NACC 2        // accumulator sets the k loop alternates between (dependent-MFMA latency)
 #endif
@@ -86,6 +89,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// The same with a wave-uniform base in an SGPR pair and a 32-bit per-lane offset.  tools/coissue_probe.hip: beside another wave's
+// bf16 MFMA stream on the same SIMD the 64-bit-VGPR-address form above issues once per ~2500 clocks, this form once per ~95
+// (an idle SIMD: 84-97 either way) -- and the ping-pong groups of this kernel issue their DMA exactly while the partner group
+// streams MFMAs.
+__device__ __forceinline__ void glds16s(const void* ubase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ubase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void gstore16(void* gdst, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(gdst), "v"(v) : "memory");
@@ -204,8 +216,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
         if (TW == 64 || lane < TW)
             glds16(ximg + (size_t)ri * TW * G::PIXB + lane * 16 + o * TW * 16, __builtin_amdgcn_readfirstlane(dst));
 #else
-        if (TW == 64 || lane < TW)
+        if (TW == 64 || lane < TW) {
+#if TAG_ROWS_DMA_SADDR
+            glds16s(ximg + (size_t)ri * TW * G::PIXB + o * 16, (unsigned)(lane * G::PIXB), __builtin_amdgcn_readfirstlane(dst));
+#else
             glds16(ximg + (size_t)ri * TW * G::PIXB + lane * G::PIXB + o * 16, __builtin_amdgcn_readfirstlane(dst));
+#endif
+        }
 #endif
     };
     // BatchNorm + ReLU of the producer, in place: the 8 channels of the plane are wave-uniform
@@ -240,10 +257,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(
             row = row >= H ? H - 1 : row;
 #pragma unroll
             for (int k = 0; k < G::KY; ++k) {
-                const int px = wm * 32 + k * 16 + (lane >> 2);
+                [[maybe_unused]] const int px = wm * 32 + k * 16 + (lane >> 2);
                 const unsigned dst = lds0 + (unsigned)(G::OFF_WIN + (wid * G::NWIN + window) * G::WINB + k * 1024);
+#if TAG_ROWS_DMA_SADDR
+                glds16s(yimg + ((size_t)row * TW + wm * 32 + k * 16) * Cout * 2 + (n0 + wn * 32) * 2,
+                        (unsigned)((lane >> 2) * Cout * 2 + (lane & 3) * 16), __builtin_amdgcn_readfirstlane(dst));
+#else
                 glds16(yimg + ((size_t)row * TW + px) * Cout * 2 + (n0 + wn * 32) * 2 + (lane & 3) * 16,
                        __builtin_amdgcn_readfirstlane(dst));
+#endif
             }
         }
     };

@@ -22,4 +22,6 @@ for (H, W, Cin, Cout) in [(1001, 64, 64, 64), (500, 32, 128, 128), (250, 16, 256
     v = list(buf)[:7]
     tot = sum(v)
     print(f"   prologue of a sampled workgroup: loads issued at {buf[7]}, barrier + loads landed at {buf[8]}, operands stored at {buf[9]} clk")
+    if buf[10]:
+        print(f"   shader clock over that workgroup's life: {tot / (buf[10] / 100e6) / 1e9:.2f} GHz ({tot} clk in {buf[10] / 100:.1f} us)")
     print(f"{H}x{W} {Cin}->{Cout}: total {tot} clk  " + "  ".join(f"{n} {x_} ({100 * x_ / tot:.0f}%)" for n, x_ in zip(names, v)))

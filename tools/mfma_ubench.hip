@@ -82,5 +82,7 @@ int main() {
     run<1, 4>("MFMA + LDS frag reads (PF2), 2 WG/CU", 512);
     run<2, 4>("MFMA + LDS reads + barrier/chunk, 2 WG/CU", 512);
     run<2, 4>("MFMA + LDS reads + barrier/chunk, 1 WG/CU", 256);
+    run<1, 4>("MFMA + LDS frag reads (PF2), 3 WG/CU", 768);
+    run<2, 4>("MFMA + LDS reads + barrier/chunk, 3 WG/CU", 768);
     return 0;
 }

@@ -2,7 +2,7 @@
 # Builds a private library with -DTAG_HALO_PROF, runs tools/conv_halo_prof.py on it and restores the product library.
 set -e
 cd texttoaudiogrounding_amd/csrc
-L="tag_lib.o logmel.o bn_pool.o conv_x3.o gemm.o gru.o heads.o text_tower.o cross.o mha.o"
+L="tag_lib.o logmel.o bn_pool.o conv_x3.o conv_rows.o conv_wgrad_dma.o gemm.o gru.o heads.o text_tower.o cross.o mha.o"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off"
 [ -f ../libtag_hprof.so ] || { /opt/rocm/bin/hipcc $F -DTAG_HALO_PROF -c conv.hip -o /tmp/conv_hprof.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libtag_hprof.so $L /tmp/conv_hprof.o; }
 cd ..

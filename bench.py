@@ -426,7 +426,8 @@ def main():
     # (they overlap the dgrad/BatchNorm chain), which stretches every overlapped kernel's own start-to-end time;
     # a second, untimed pass of the same K steps with that overlap switched off gives the isolated kernel rate.
     fam = families(prof)
-    overlap = ops.WGRAD_SIDE_STREAM
+    overlap = ops.side_stream_enabled()         # auto: off for the fp32-accurate arithmetics, on in the bf16 mode (ops.py)
+    side_setting = ops.WGRAD_SIDE_STREAM
     fam_iso = fam
     if overlap:
         ops.WGRAD_SIDE_STREAM = False
@@ -435,7 +436,7 @@ def main():
             runner.train_step(dict(batch))
         sync()
         fam_iso, ops.PROFILE = families(ops.PROFILE), None
-        ops.WGRAD_SIDE_STREAM = True
+        ops.WGRAD_SIDE_STREAM = side_setting
     # ---- the same K steps with the opt-in conv arithmetic (reported beside the contract's number, never as `value`)
     alt = None
     if args.conv_math == "fp32" and not args.no_alt:
@@ -467,16 +468,17 @@ def main():
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
             if mode == "bf16":
                 fam_a = fam_a_iso = families(prof_a)
-                if overlap:                                       # isolated kernel rate: the same steps, wgrad convs in line
+                overlap_a = ops.side_stream_enabled()
+                if overlap_a:                                     # isolated kernel rate: the same steps, wgrad convs in line
                     ops.WGRAD_SIDE_STREAM = False
                     ops.PROFILE = {}
                     for _ in range(args.steps):
                         runner.train_step(dict(batch))
                     sync()
                     fam_a_iso, ops.PROFILE = families(ops.PROFILE), None
-                    ops.WGRAD_SIDE_STREAM = True
+                    ops.WGRAD_SIDE_STREAM = side_setting
                 alt[mode]["whole_step_mfma_frac"] = round(clips / dta / world * FLOP_PER_CLIP / 1e12 / 2500.0, 4)
-                alt[mode]["roofline"] = roofline_of(fam_a, fam_a_iso, args.steps, "bf16", "bf16", args.batch, overlap)
+                alt[mode]["roofline"] = roofline_of(fam_a, fam_a_iso, args.steps, "bf16", "bf16", args.batch, overlap_a)
         ops.CONV_MATH = "fp32"
         ops.ACT_DTYPE = "fp32"
     loss_value = round(runner.loss_value(loss), 6)

@@ -788,8 +788,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
                                                                        int Cin, int Cout, int splits, int chunks_per_split) {
     using G = WgGeom<TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [PP][64]  input patch, pixel-major
-    float* Bs = smem + G::PP * 64;             // [32][64]  dy chunk
+    // two operand buffers: buffer b = [PP][64] input patch (pixel-major) followed by [32][64] dy chunk.  The next chunk is written
+    // to the other buffer IN THE MIDDLE of the current chunk's MFMA stream (its loads were issued one chunk earlier) and one
+    // barrier ends each chunk: no store phase between two barriers in which the wave issues no MFMA (round 4, as in the halo conv)
+    constexpr int BUFSZ = G::PP * 64 + 32 * 64;
 
     const int ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 63) / 64;
     int L = xcd_remap(blockIdx.x, ci_tiles * co_tiles * splits);
@@ -849,7 +851,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
             rd[i] = ldg4(dy + pix * Cout + cb);
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int buf) {
+        float* As = smem + buf * BUFSZ;
+        float* Bs = As + G::PP * 64;
 #pragma unroll
         for (int i = 0; i < G::XITEMS; ++i) {
             if (!((xex >> i) & 1u)) continue;
@@ -875,16 +879,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
 
     if (cbeg < cend) {
         issue_chunk(cbeg);
-        store_chunk();
+        store_chunk(0);
+        if (cbeg + 1 < cend) issue_chunk(cbeg + 1);
     }
     __syncthreads();
     for (int c = cbeg; c < cend; ++c) {
-        if (c + 1 < cend) issue_chunk(c + 1);
+        const int buf = (c - cbeg) & 1;
         __builtin_amdgcn_sched_barrier(0);
-        const float* a = As + kl * 64 + wci + ml;
-        const float* b = Bs + kl * 64 + wco + ml;
+        const float* a = smem + buf * BUFSZ + kl * 64 + wci + ml;
+        const float* b = smem + buf * BUFSZ + G::PP * 64 + kl * 64 + wco + ml;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
+            if (ks == 8) {                                 // chunk c + 1 (loaded during chunk c - 1 .. c) -> the other buffer
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < cend) store_chunk(buf ^ 1);
+                if (c + 2 < cend) issue_chunk(c + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // pixel pair (2ks, 2ks+1) of the chunk rectangle -> patch position of tap (0,0)
             constexpr int dummy = 0; (void)dummy;
             const int pr = (2 * ks) / G::CW, pc = (2 * ks) % G::CW;
@@ -898,9 +909,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                   // every wave is done reading the chunk
-        if (c + 1 < cend) store_chunk();
-        __syncthreads();
+        __syncthreads();                                   // chunk c + 1 is complete in LDS; every wave is done reading chunk c
     }
     // partial[split][tap][ci][co]
 #pragma unroll
@@ -1732,7 +1741,7 @@ static void launch_wgrad_alltaps(const float* x, int pro, const float* s, const 
                                  int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
     using G = WgGeom<TW>;
     const int grid = ((Cin + 63) / 64) * ((Cout + 63) / 64) * splits;
-    const size_t lds = (size_t)(G::PP * 64 + 32 * 64) * sizeof(float);
+    const size_t lds = (size_t)2 * (G::PP * 64 + 32 * 64) * sizeof(float);
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \

@@ -10,8 +10,10 @@ export TMPDIR=/tmp
 BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt --no-others"
 for mode in fp32 bf16; do
   extra=""; [ $mode = bf16 ] && extra="--dtype bf16"
+  # steps in the traced process: 2 warm-up + 5 timed (+ 5 of bench.py's isolated pass where the wgrad side stream is on = bf16 mode)
+  KS=7; [ $mode = bf16 ] && KS=12
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$mode -o k -- $BENCH $extra > $OUT/kt_$mode.log 2>&1
-  python tools/kstats.py $OUT/kt_$mode/k_kernel_stats.csv 12 80 > $OUT/${R}_bench_b64_${mode}_kernel_summary.txt
+  python tools/kstats.py $OUT/kt_$mode/k_kernel_stats.csv $KS 80 > $OUT/${R}_bench_b64_${mode}_kernel_summary.txt
   cp $OUT/kt_$mode/k_kernel_stats.csv $OUT/${R}_bench_b64_${mode}_kernel_stats.csv
   grep '^{"metric"' $OUT/kt_$mode.log > $OUT/${R}_bench_b64_${mode}_under_rocprof.json
   TAG_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iso_$mode -o k -- $BENCH $extra > $OUT/iso_$mode.log 2>&1

@@ -274,6 +274,14 @@ __device__ unsigned long long tag_halo_sub[4];        // (written by every workg
 #else
 #define HP_MARK(i)
 #endif
+// channels of a weight stage (one barrier per stage): 16 = half a tap (3 workgroups per CU), 32 = a whole tap in two 16 KB buffers
+// (128 couts: 62 KB of LDS, 2 workgroups per CU, half the barriers).  The synthetic loop of tools/mfma_ubench.hip gains 2.5 % from
+// the rarer barrier (147.8 vs 144.2 TFLOP/s); the kernel does not: 128.6 / 132.1 (32) vs 130.3 / 132.4 TFLOP/s (16), forward / dgrad
+// over the seven layer shapes -- the third workgroup per CU is worth more.
+#ifndef TAG_HALO_STAGE128
+#define TAG_HALO_STAGE128 16
+#endif
+template <int BN_> constexpr int halo_stage() { return BN_ == 128 ? TAG_HALO_STAGE128 : 16; }
 template <int TW>
 struct HaloGeom {
     static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
@@ -297,17 +305,18 @@ struct BnBwdEpi {
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
-__global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
                                                               int Cin, int Cout) {
     using G = HaloGeom<TW>;
-    constexpr int TN = BN_ / 64, BH_LOADS = BN_ / 64;            // float4 per thread per half tap (16 x BN_ floats)
+    constexpr int ST = halo_stage<BN_>(), NSTG = 32 / ST;       // channels per weight stage, stages per tap
+    constexpr int TN = BN_ / 64, BH_LOADS = ST * BN_ / 1024;     // float4 per thread per stage (ST x BN_ floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [PP][AROW] patch, pixel-major
-    float* Bs = smem + G::ASZ;                 // [2][16][BN_] weight half taps
-    float* Ss = Bs + 2 * 16 * BN_;             // [2][Cin] producer BN scale / shift
+    float* Bs = smem + G::ASZ;                 // [2][ST][BN_] weight stages
+    float* Ss = Bs + 2 * ST * BN_;             // [2][Cin] producer BN scale / shift
 
     const int n_tiles = (Cout + BN_ - 1) / BN_;
     const int row_tiles = (H + G::TH - 1) / G::TH;               // W == TW: one tile column
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
             *reinterpret_cast<f32x4*>(As + pp * G::AROW + q * 4) = v;
         }
     };
-    // ---- half-tap weight staging (16 k rows x BN_ couts) ----
+    // ---- weight staging per stage (ST k rows x BN_ couts) ----
     unsigned bhoff[BH_LOADS];
 #pragma unroll
     for (int i = 0; i < BH_LOADS; ++i) {
@@ -387,15 +396,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
         bhoff[i] = (unsigned)((k * Cout + n) * 4);
     }
     f32x4 rh[2][BH_LOADS];
-    auto issue_bh = [&](int it, int half, f32x4 (&r)[BH_LOADS]) {
-        const int itc = it < total ? it : total - 1;           // past the end: re-read the last tap (stored, never used)
-        const int cc = itc / 9, tap = itc - cc * 9;
-        const char* wchunk = reinterpret_cast<const char*>(wp + ((size_t)tap * Cin + cc * BK + half * 16) * Cout);
+    auto issue_bh = [&](int sg, f32x4 (&r)[BH_LOADS]) {        // weights of stage sg = tap step sg / NSTG, channels ST (sg % NSTG) ..
+        const int sgc = sg < total * NSTG ? sg : total * NSTG - 1;         // past the end: re-read the last stage (stored, never used)
+        const int it = sgc / NSTG, h = sgc - it * NSTG;
+        const int cc = it / 9, tap = it - cc * 9;
+        const char* wchunk = reinterpret_cast<const char*>(wp + ((size_t)tap * Cin + cc * BK + h * ST) * Cout);
 #pragma unroll
         for (int i = 0; i < BH_LOADS; ++i) r[i] = *reinterpret_cast<const f32x4*>(wchunk + bhoff[i]);
     };
     auto store_bh = [&](int buf, const f32x4 (&r)[BH_LOADS]) {
-        float* b = Bs + buf * 16 * BN_;
+        float* b = Bs + buf * ST * BN_;
 #pragma unroll
         for (int i = 0; i < BH_LOADS; ++i) {
             const int idx = tid + 256 * i;
@@ -412,17 +422,18 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // 8 k-steps (channels 16 half .. 16 half + 15 of the chunk) of one tap from weight buffer buf; mid() runs after k-step 3.
-    // k-step ks = 4 g + j multiplies channel 8 g + 4 kl + j of the half: A = element j of the lane's float4 of group g, B = that row.
-    auto mma_half = [&](int buf, int tap, int half, auto&& mid) {
+    // The ST / 2 k-steps of one stage (channels ST h .. ST h + ST - 1 of the chunk, one tap) from weight buffer buf; mid() runs in the
+    // middle.  k-step ks = 4 g + j multiplies channel 8 g + 4 kl + j of the stage: A = element j of the lane's float4 of channel
+    // group g, B = that row of the buffer.
+    auto mma_stage = [&](int buf, int tap, int h, auto&& mid) {
         const int shift = (tap / 3 - 1) * G::PW + (tap % 3 - 1);
-        const float* a0 = As + (pbase[0] + shift) * G::AROW + half * 16 + kl * 4;
-        const float* a1 = As + (pbase[1] + shift) * G::AROW + half * 16 + kl * 4;
-        const float* b = Bs + buf * 16 * BN_ + (kl * 4) * BN_ + wn0 + ml;
-        f32x4 af[2][2];                                         // [channel group][row tile]
+        const float* a0 = As + (pbase[0] + shift) * G::AROW + h * ST + kl * 4;
+        const float* a1 = As + (pbase[1] + shift) * G::AROW + h * ST + kl * 4;
+        const float* b = Bs + buf * ST * BN_ + (kl * 4) * BN_ + wn0 + ml;
+        constexpr int PF = 2, NS = ST / 2, NG = NS / 4;
+        f32x4 af[NG][2];                                        // [channel group][row tile]
         af[0][0] = *reinterpret_cast<const f32x4*>(a0);
         af[0][1] = *reinterpret_cast<const f32x4*>(a1);
-        constexpr int PF = 2, NS = 8;
         float bf[PF + 1][TN];
 #pragma unroll
         for (int s0 = 0; s0 < PF; ++s0)
@@ -439,13 +450,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = b[((kn >> 2) * 8 + (kn & 3)) * BN_ + j * 32];
             }
+            if ((ks & 3) == 1 && (ks >> 2) + 2 < NG) {          // channel group g + 2 while group g is being multiplied
+                af[(ks >> 2) + 2][0] = *reinterpret_cast<const f32x4*>(a0 + ((ks >> 2) + 2) * 8);
+                af[(ks >> 2) + 2][1] = *reinterpret_cast<const f32x4*>(a1 + ((ks >> 2) + 2) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks >> 2][i][ks & 3], bf[cur][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);                  // keeps the operand reads of k-step ks + 2 ahead of their use
-            if (ks == 3) { mid(); __builtin_amdgcn_sched_barrier(0); }
+            if (ks == NS / 2 - 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
         }
     };
 
@@ -454,8 +469,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
     unsigned long long hpc[7] = {0, 0, 0, 0, 0, 0, 0}, hp0 = __builtin_amdgcn_s_memtime();
 #endif
     issue_patch(0);
-    issue_bh(0, 0, rh[0]);
-    issue_bh(0, 1, rh[1]);
+    issue_bh(0, rh[0]);
+    issue_bh(1, rh[1]);
 #ifdef TAG_HALO_PROF
     { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[0] = p1_ - hp0; }
 #endif
@@ -471,23 +486,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
 #endif
     __syncthreads();
     HP_MARK(0)
-    for (int it = 0; it < total; ++it) {
+    // Stage sg (weight buffer sg & 1): the weights of stage sg + 2 are requested into the register set stage sg's weights left; in
+    // mid-stream the weights of stage sg + 1 (requested one stage ago) go to the other buffer; one barrier ends the stage.  Two
+    // stages per loop pass so that the register sets alternate statically.
+    auto stage = [&](int sg, f32x4 (&rnext)[BH_LOADS], f32x4 (&rnew)[BH_LOADS]) {
+        const int it = sg / NSTG, h = sg - it * NSTG;
         const int cc = it / 9, tap = it - cc * 9;
         const bool newpatch = tap == 8 && cc + 1 < cchunks;
-        if (newpatch) issue_patch(cc + 1);
-        issue_bh(it + 1, 0, rh[0]);                            // rh[0] went to LDS during the previous half
+        if (newpatch && h == 0) issue_patch(cc + 1);
+        issue_bh(sg + 2, rnew);
         __builtin_amdgcn_sched_barrier(0);
-        mma_half(0, tap, 0, [&] { store_bh(1, rh[1]); });      // (it, 1) -> buffer 1, read after the next barrier
+        mma_stage(sg & 1, tap, h, [&] { store_bh((sg + 1) & 1, rnext); });
         HP_MARK(1)
         __syncthreads();
         HP_MARK(2)
-        issue_bh(it + 1, 1, rh[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(1, tap, 1, [&] { store_bh(0, rh[0]); });      // (it + 1, 0) -> buffer 0
-        HP_MARK(1)
-        __syncthreads();
-        HP_MARK(2)
-        if (newpatch) {                                        // every wave has read the last tap of the old patch
+        if (newpatch && h == NSTG - 1) {                       // every wave has read the last tap of the old patch
 #ifdef TAG_HALO_PROF
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             HP_MARK(4)
@@ -497,7 +510,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const float* __res
             __syncthreads();
             HP_MARK(4)
         }
+    };
+    const int nstages = total * NSTG;
+    int sg = 0;
+    for (; sg + 1 < nstages; sg += 2) {
+        stage(sg, rh[1], rh[0]);
+        stage(sg + 1, rh[0], rh[1]);
     }
+    if (sg < nstages) stage(sg, rh[1], rh[0]);                 // odd count: whole-tap stages with Cin = 32 (2k + 1)
 
     // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel tile_m(i, r) ----
 #pragma unroll
@@ -1598,7 +1618,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
     // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
     // third workgroup of a CU fits only without the unused part of a 512-channel table)
-    const size_t lds = (size_t)(G::ASZ + 2 * 16 * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
+    const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
     if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
         static bool attr_set = false;
         if (!attr_set) {

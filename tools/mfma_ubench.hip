@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 3) void k2(const float* __restrict__ g, float*
                 glds16(gp + ((long)(it * 2 + half) % 64) * gstride, __builtin_amdgcn_readfirstlane(d));
                 glds16(gp + ((long)(it * 2 + half) % 64) * gstride + 1024, __builtin_amdgcn_readfirstlane(d + 4096));
             }
-            if (MODE == 3) {
+            if (MODE == 3 || MODE == 7) {
                 rh[half][0] = *reinterpret_cast<const f32x4*>(gp + ((long)(it * 2 + half) % 64) * gstride);
                 rh[half][1] = *reinterpret_cast<const f32x4*>(gp + ((long)(it * 2 + half) % 64) * gstride + 1024);
             }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 3) void k2(const float* __restrict__ g, float*
                 }
             }
             if (MODE == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (MODE != 7 || half == 1) __syncthreads();          // MODE 7: one barrier per 64 MFMAs (full-tap weight buffers)
         }
     }
     float s = 0;
@@ -183,6 +183,9 @@ int main() {
     run2<4>("half-tap pipeline + LDS stores, 3 WG/CU", 768);
     run2<3>("half-tap pipeline + global loads + stores, 3 WG/CU", 768);
     run2<3>("half-tap pipeline + global loads + stores, 16 rounds", 768 * 16);
+    run2<7>("loads + stores, barrier per 64 MFMAs, 3 WG/CU x16", 768 * 16);
+    run2<7>("loads + stores, barrier per 64 MFMAs, 2 WG/CU x16", 512 * 16);
+    run2<3>("loads + stores, barrier per 32 MFMAs, 2 WG/CU x16", 512 * 16);
     run2<6>("half-tap pipeline + LDS-DMA weights, 3 WG/CU", 768);
     run2<6>("half-tap pipeline + LDS-DMA weights, 16 rounds", 768 * 16);
     run2<6>("... DMA from an L2-resident 1 MB, 16 rounds", 768 * 16, 1);

@@ -616,7 +616,10 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     }
 #ifdef TAG_HALO_PROF
     HP_MARK(6)
-    if (blockIdx.x == 1500 && tid == 0) {
+#ifndef TAG_HALO_PROF_BLOCK
+#define TAG_HALO_PROF_BLOCK 1500                                  // the sampled workgroup (a late one + TAG_PROF_REPS launches: steady clocks)
+#endif
+    if (blockIdx.x == TAG_HALO_PROF_BLOCK && tid == 0) {
         for (int i = 0; i < 7; ++i) tag_halo_prof[i] = hpc[i];
         tag_halo_sub[3] = __builtin_amdgcn_s_memrealtime() - hrt0;
     }

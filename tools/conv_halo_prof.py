@@ -13,7 +13,7 @@ for (H, W, Cin, Cout) in [(1001, 64, 64, 64), (500, 32, 128, 128), (250, 16, 256
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
     s, t = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
     wf, wd = ops.pack_conv_weight(w, W=W)
-    for _ in range(2):
+    for _ in range(int(os.environ.get("TAG_PROF_REPS", "2"))):
         ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=True)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 12)()

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 #ifdef TAG_HALO_PROF
 __device__ unsigned long long tag_halo_prof[8];
 __device__ unsigned long long tag_halo_sub[4];        // (written by every workgroup: the last writer wins -- a sample)
+__device__ unsigned long long tag_halo_wg[4 * 65536];   // [start of the pipeline | end | XCC/SE/CU id | first instruction] of every workgroup (s_memrealtime, 100 MHz)
 #define HP_MARK(i) { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); hpc[i] += p1_ - hp0; hp0 = p1_; }
 #else
 #define HP_MARK(i)
@@ -281,7 +282,7 @@ __device__ unsigned long long tag_halo_sub[4];        // (written by every workg
 #ifndef TAG_HALO_STAGE128
 #define TAG_HALO_STAGE128 16
 #endif
-template <int BN_> constexpr int halo_stage() { return BN_ == 128 ? TAG_HALO_STAGE128 : 16; }
+template <int BN_> constexpr int halo_stage() { return 16; }
 template <int TW>
 struct HaloGeom {
     static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
@@ -310,6 +311,9 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
                                                               int Cin, int Cout) {
+#ifdef TAG_HALO_PROF
+    const unsigned long long hrt_first = __builtin_amdgcn_s_memrealtime();
+#endif
     using G = HaloGeom<TW>;
     constexpr int ST = halo_stage<BN_>(), NSTG = 32 / ST;       // channels per weight stage, stages per tap
     constexpr int TN = BN_ / 64, BH_LOADS = ST * BN_ / 1024;     // float4 per thread per stage (ST x BN_ floats)
@@ -329,8 +333,13 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
     const int kl = lane >> 5, ml = lane & 31;
+    // 128-bit LDS writes: beside the fp32 MFMA streams of the two resident workgroups a ds_write_b32 waits 1250-5000 clocks for a gap
+    // (tools/coissue_probe.hip); the one-float-per-thread form of this table fill held every new workgroup for ~8.7 us (halo_wg_timeline)
     if (PRO != 0)
-        for (int c = tid; c < Cin; c += 256) { Ss[c] = in_scale[c]; Ss[Cin + c] = in_shift[c]; }
+        for (int c4 = tid; c4 < Cin / 4; c4 += 256) {
+            *reinterpret_cast<f32x4*>(Ss + 4 * c4) = ldg4(in_scale + 4 * c4);
+            *reinterpret_cast<f32x4*>(Ss + Cin + 4 * c4) = ldg4(in_shift + 4 * c4);
+        }
 
     // ---- patch staging geometry (loop invariant): item = (patch pixel, channel quad) ----
     const int q = tid & 7;
@@ -396,11 +405,7 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
         bhoff[i] = (unsigned)((k * Cout + n) * 4);
     }
     f32x4 rh[2][BH_LOADS];
-    auto issue_bh = [&](int sg, f32x4 (&r)[BH_LOADS]) {        // weights of stage sg = tap step sg / NSTG, channels ST (sg % NSTG) ..
-        const int sgc = sg < total * NSTG ? sg : total * NSTG - 1;         // past the end: re-read the last stage (stored, never used)
-        const int it = sgc / NSTG, h = sgc - it * NSTG;
-        const int cc = it / 9, tap = it - cc * 9;
-        const char* wchunk = reinterpret_cast<const char*>(wp + ((size_t)tap * Cin + cc * BK + h * ST) * Cout);
+    auto issue_bh = [&](const char* wchunk, f32x4 (&r)[BH_LOADS]) {        // ST weight rows x BN_ couts from wchunk (wave-uniform)
 #pragma unroll
         for (int i = 0; i < BH_LOADS; ++i) r[i] = *reinterpret_cast<const f32x4*>(wchunk + bhoff[i]);
     };
@@ -425,8 +430,7 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     // The ST / 2 k-steps of one stage (channels ST h .. ST h + ST - 1 of the chunk, one tap) from weight buffer buf; mid() runs in the
     // middle.  k-step ks = 4 g + j multiplies channel 8 g + 4 kl + j of the stage: A = element j of the lane's float4 of channel
     // group g, B = that row of the buffer.
-    auto mma_stage = [&](int buf, int tap, int h, auto&& mid) {
-        const int shift = (tap / 3 - 1) * G::PW + (tap % 3 - 1);
+    auto mma_stage = [&](int buf, int shift, int h, auto&& mid) {      // shift = (ky - 1) * PW + (kx - 1) of the tap
         const float* a0 = As + (pbase[0] + shift) * G::AROW + h * ST + kl * 4;
         const float* a1 = As + (pbase[1] + shift) * G::AROW + h * ST + kl * 4;
         const float* b = Bs + buf * ST * BN_ + (kl * 4) * BN_ + wn0 + ml;
@@ -468,9 +472,16 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     const unsigned long long hrt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: shader clock = sum(hpc) / realtime
     unsigned long long hpc[7] = {0, 0, 0, 0, 0, 0, 0}, hp0 = __builtin_amdgcn_s_memtime();
 #endif
+    // Loop state is carried incrementally (tap / chunk counters, the tap's patch shift, the weight pointer one tap ahead): SALU
+    // instructions wait for gaps in the co-resident waves' MFMA streams (tools/coissue_probe.hip: ~300 clocks each beside a dense
+    // fp32 stream, 4.6 alone), and the divisions and 64-bit multiplies of the per-stage index form were ~90 of them per tap.
+    static_assert(NSTG == 2, "two 16-channel stages per tap");
+    const char* const wbase = reinterpret_cast<const char*>(wp);
+    const size_t tap_stride = (size_t)Cin * Cout * 4;           // bytes from tap to tap in the (9, Cin, Cout) pack
+    const unsigned half_stride = (unsigned)(ST * Cout * 4);     // from the first to the second 16 channels of a chunk
     issue_patch(0);
-    issue_bh(0, rh[0]);
-    issue_bh(1, rh[1]);
+    issue_bh(wbase, rh[0]);
+    issue_bh(wbase + half_stride, rh[1]);
 #ifdef TAG_HALO_PROF
     { const unsigned long long p1_ = __builtin_amdgcn_s_memtime(); tag_halo_sub[0] = p1_ - hp0; }
 #endif
@@ -486,21 +497,29 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
 #endif
     __syncthreads();
     HP_MARK(0)
-    // Stage sg (weight buffer sg & 1): the weights of stage sg + 2 are requested into the register set stage sg's weights left; in
-    // mid-stream the weights of stage sg + 1 (requested one stage ago) go to the other buffer; one barrier ends the stage.  Two
-    // stages per loop pass so that the register sets alternate statically.
-    auto stage = [&](int sg, f32x4 (&rnext)[BH_LOADS], f32x4 (&rnew)[BH_LOADS]) {
-        const int it = sg / NSTG, h = sg - it * NSTG;
-        const int cc = it / 9, tap = it - cc * 9;
+    // Per tap two stages (weight buffers 0 / 1): at the start of a stage the weights of the stage after the next one are requested
+    // into the register set this stage's weights left; in mid-stream the next stage's weights (requested one stage ago) go to the
+    // other buffer; one barrier ends the stage.
+    int tap = 0, cc = 0, kx = 0, shift = -G::PW - 1;            // current tap: (chunk cc, tap), its patch shift
+    int p_tap = 1, p_cc = 0;                                    // the tap whose weights are requested during this one (= the next)
+    const char* pw = wbase + tap_stride;
+    if (total == 1) pw = wbase;
+    for (int it = 0; it < total; ++it) {
         const bool newpatch = tap == 8 && cc + 1 < cchunks;
-        if (newpatch && h == 0) issue_patch(cc + 1);
-        issue_bh(sg + 2, rnew);
+        if (newpatch) issue_patch(cc + 1);
+        issue_bh(pw, rh[0]);                                   // (next tap, channels 0..15)
         __builtin_amdgcn_sched_barrier(0);
-        mma_stage(sg & 1, tap, h, [&] { store_bh((sg + 1) & 1, rnext); });
+        mma_stage(0, shift, 0, [&] { store_bh(1, rh[1]); });   // (this tap, channels 16..31) -> buffer 1, read after the barrier
         HP_MARK(1)
         __syncthreads();
         HP_MARK(2)
-        if (newpatch && h == NSTG - 1) {                       // every wave has read the last tap of the old patch
+        issue_bh(pw + half_stride, rh[1]);                     // (next tap, channels 16..31)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_stage(1, shift, 1, [&] { store_bh(0, rh[0]); });   // (next tap, channels 0..15) -> buffer 0
+        HP_MARK(1)
+        __syncthreads();
+        HP_MARK(2)
+        if (newpatch) {                                        // every wave has read the last tap of the old patch
 #ifdef TAG_HALO_PROF
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             HP_MARK(4)
@@ -510,28 +529,51 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
             __syncthreads();
             HP_MARK(4)
         }
-    };
-    const int nstages = total * NSTG;
-    int sg = 0;
-    for (; sg + 1 < nstages; sg += 2) {
-        stage(sg, rh[1], rh[0]);
-        stage(sg + 1, rh[0], rh[1]);
+        // advance (tap, cc, shift) and the prefetch position by one tap
+        if (tap == 8) { tap = 0; ++cc; kx = 0; shift = -G::PW - 1; }
+        else { ++tap; if (kx == 2) { kx = 0; shift += G::PW - 2; } else { ++kx; ++shift; } }
+        if (p_tap == 8) {
+            p_tap = 0; ++p_cc;
+            pw += (size_t)BK * Cout * 4;
+            pw -= 8 * tap_stride;
+            if (p_cc == cchunks) { p_cc = 0; pw = wbase; }      // past the end: the first tap again (stored, never used)
+        } else { ++p_tap; pw += tap_stride; }
     }
-    if (sg < nstages) stage(sg, rh[1], rh[0]);                 // odd count: whole-tap stages with Cin = 32 (2k + 1)
 
-    // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel tile_m(i, r) ----
+    // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel tile_m(i, r).  Registers 4 rq .. 4 rq + 3
+    // of a lane quad (4 consecutive couts) are 4 consecutive pixels x 4 couts: transposed inside the quad (two DPP exchange rounds,
+    // 16 VALU per block) each lane owns ONE pixel's 4 couts = one 16-byte store.  A global_store_dword is one of the instruction
+    // forms that wait for the co-resident waves' MFMA streams to pause (tools/coissue_probe.hip; 32-64 of them held a finished tile
+    // for 3-7 us), a dwordx4 store is not. ----
+    {
+        const int c4 = lane & 3;                                // position inside the lane quad = cout offset before, pixel offset after
+        const bool odd = c4 & 1, hi = c4 & 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + ml;
+            for (int j = 0; j < TN; ++j) {
+                const int nq = n0 + wn0 + j * 32 + (ml & ~3);   // first of the quad's 4 couts
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tile_m(i, r);                                       // pixel inside the tile
-                const int h = h0 + m / TW, w = m % TW;
-                if (h < H && n < Cout) y[(((size_t)img * H + h) * W + w) * Cout + n] = acc[i][j][r];
+                for (int rq = 0; rq < 4; ++rq) {
+                    float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
+                    // round 1: exchange with lane c4 ^ 1 (quad_perm [1,0,3,2]): even lanes send x1 / x3, odd lanes x0 / x2
+                    const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
+                    const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                    const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                    if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
+                    // round 2: exchange with lane c4 ^ 2 (quad_perm [2,3,0,1]): low lanes send x2 / x3, high lanes x0 / x1
+                    const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
+                    const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                    const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                    if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
+                    // now x_t = cout nq + t of the pixel behind register 4 rq + c4
+                    const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
+                    const int h = h0 + m / TW, w = m % TW;
+                    if (h < H && nq < Cout)
+                        *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
+                }
             }
-        }
+    }
     HP_MARK(5)
     // ---- fused BatchNorm statistics of the output (training): per (64-pixel wave tile, channel) a pivot mu (the tile
     // mean as rounded in fp32), r = sum(y - mu) and q = sum((y - mu)^2): the tile's sum is n*mu + r EXACTLY up to the
@@ -619,6 +661,14 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
 #ifndef TAG_HALO_PROF_BLOCK
 #define TAG_HALO_PROF_BLOCK 1500                                  // the sampled workgroup (a late one + TAG_PROF_REPS launches: steady clocks)
 #endif
+    if (tid == 0 && blockIdx.x < 65536) {
+        const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);            // HW_ID bits 0..15
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+        tag_halo_wg[blockIdx.x] = hrt0;
+        tag_halo_wg[65536 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        tag_halo_wg[2 * 65536 + blockIdx.x] = (xcc << 16) | (hw & 0xffffu);
+        tag_halo_wg[3 * 65536 + blockIdx.x] = hrt_first;
+    }
     if (blockIdx.x == TAG_HALO_PROF_BLOCK && tid == 0) {
         for (int i = 0; i < 7; ++i) tag_halo_prof[i] = hpc[i];
         tag_halo_sub[3] = __builtin_amdgcn_s_memrealtime() - hrt0;
@@ -2027,5 +2077,8 @@ extern "C" int tag_conv3x3_c1_backward_bnrelu_bf16(const float* x, const float* 
 extern "C" int tag_debug_get_halo_prof(unsigned long long* out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_prof), 56) != hipSuccess) return -1;
     return hipMemcpyFromSymbol(out + 7, HIP_SYMBOL(tag_halo_sub), 32) == hipSuccess ? 0 : -1;
+}
+extern "C" int tag_debug_get_halo_wg(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tag_halo_wg), sizeof(unsigned long long) * 4 * 65536) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -18,7 +18,7 @@ __device__ __forceinline__ void glds16_s(const void* gbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
 // MF: 0 idle partner, 1 fp32 32x32x2 stream, 2 bf16 32x32x16 stream.  WORK: 0 independent v_fma, 1 ds_write_b32, 2 ds_read_b32
-template <int MF, int WORK>
+template <int MF, int WORK, int PRIO = 0>
 __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sink, int mf_iters, int work_iters) {
     __shared__ float lds[8192];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,10 +50,13 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
         if (s == 12345.678f) sink[0] = s;
         return;
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);                // does a higher issue priority get the starved instruction forms through?
     // let the MFMA stream get going
     for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(1);
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = lane * 0.001f + i;
+    int su = __builtin_amdgcn_readfirstlane(work_iters);      // wave-uniform chain for the SALU / SMEM probes
+    const float* __restrict__ csink = sink;
     float* p = lds + (wid - 4) * 2048 + lane;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < work_iters; ++it) {
@@ -71,6 +74,9 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
             if (WORK == 11 && i < 4) *reinterpret_cast<f32x4*>(sink + 64 + 4096 + ((wid * 4 + i) * 64 + lane) * 4) = (f32x4){v[i], v[i + 1], v[i + 2], v[i + 3]};
             if (WORK == 12 && i < 4) glds16_s(sink + 64, (unsigned)((i * 64 + lane) * 16), __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds + (wid - 4) * 2048 + i * 256) & 0xffffu));
             if (WORK == 13 && i < 4) asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)(lds + (wid - 4) * 2048 + i * 64 + lane) & 0xffffu), "v"(v[i]) : "memory");
+            if (WORK == 14) { su = su * 3 + 7 + i; su ^= su >> 3; }
+            if (WORK == 15 && i < 4) { su += reinterpret_cast<const int*>(csink)[64 + ((su + i) & 1023)]; }
+            if (WORK == 16) { unsigned u_ = __float_as_uint(v[i]); u_ = u_ * 2654435761u + 12345u; v[i] = __uint_as_float((u_ & 0x007fffffu) | 0x3f800000u); }
             if (WORK == 7 && i < 4) *reinterpret_cast<float2*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 2) = make_float2(v[i], v[i + 1]);
             if (WORK == 8 && i < 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 4); v[i] += t.x; }
         }
@@ -80,16 +86,16 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
     for (int i = 0; i < 16; ++i) s += v[i];
-    if (s == 12345.678f) sink[1] = s + lds[lane];
+    if (s == 12345.678f || su == 123457) sink[1] = s + lds[lane] + su;
     if (lane == 0 && wid == 4 && blockIdx.x == 0) out[0] = t1 - t0;
 }
 
-template <int MF, int WORK>
+template <int MF, int WORK, int PRIO = 0>
 static void run(const char* name) {
     unsigned long long* out; float* sink;
     hipMalloc(&out, 8); hipMalloc(&sink, 65536); hipMemset(sink, 0, 65536);
     const int work_iters = 200;
-    hipLaunchKernelGGL((probe<MF, WORK>), dim3(256), dim3(512), 0, 0, out, sink, 4000, work_iters);
+    hipLaunchKernelGGL((probe<MF, WORK, PRIO>), dim3(256), dim3(512), 0, 0, out, sink, 4000, work_iters);
     hipDeviceSynchronize();
     unsigned long long h = 0;
     hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
@@ -130,6 +136,16 @@ int main() {
     run<0, 13>("single ds_write_b32, partner idle");
     run<1, 13>("single ds_write_b32 beside fp32 MFMA");
     run<2, 13>("single ds_write_b32 beside bf16 MFMA");
+    run<0, 14>("5 dependent SALU ops, partner idle");
+    run<1, 14>("5 dependent SALU ops beside fp32 MFMA");
+    run<1, 14, 3>("5 dependent SALU ops beside fp32 MFMA, s_setprio 3");
+    run<1, 13, 3>("single ds_write_b32 beside fp32 MFMA, s_setprio 3");
+    run<1, 6, 3>("global_store_dword beside fp32 MFMA, s_setprio 3");
+    run<2, 4, 3>("global_load_lds_dwordx4 beside bf16 MFMA, s_setprio 3");
+    run<0, 15>("dependent s_load_dword (+2 SALU), partner idle");
+    run<1, 15>("dependent s_load_dword (+2 SALU) beside fp32 MFMA");
+    run<0, 16>("v_mul_lo_u32 + 3 int VALU, partner idle");
+    run<1, 16>("v_mul_lo_u32 + 3 int VALU beside fp32 MFMA");
     run<0, 7>("ds_write_b64, partner idle");
     run<1, 7>("ds_write_b64 beside fp32 MFMA stream");
     run<0, 8>("ds_read_b128, partner idle");

@@ -287,9 +287,12 @@ template <int TW>
 struct HaloGeom {
     static constexpr int TH = 128 / TW, PW = TW + 2, PH = TH + 2, PP = PH * PW;
     static constexpr int AROW = 36;                               // floats per patch pixel in LDS (32 channels + 4 pad)
-    static constexpr int ASZ = PP * AROW;
+    static constexpr int ASZ = (PP + 1) * AROW;                   // + one scratch pixel: the staging items past the patch land there
     static constexpr int ITEMS = (PP * 8 + 255) / 256;            // float4 per thread per patch chunk
 };
+// n / d by the host's magic pair (mul, shift) of d (n < 2^31): three scalar instructions instead of a runtime division's ~25 --
+// scalar instructions wait for gaps in the co-resident waves' MFMA streams, and a new workgroup's ~190 of them took ~9 us
+__device__ __forceinline__ unsigned halo_fdiv(unsigned n, unsigned mul, unsigned shr) { return (__umulhi(n, mul) + n) >> shr; }
 // MFMA row i (0..31) -> pixel inside the 32-pixel block: the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
 // read pixels 0..15 / 16..31 (quad map [0,4,5,1,6,2,3,7], the same as the bf16 kernels of conv_x3.hip)
 __device__ __forceinline__ int halo_row_to_pix(int i) {
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
-                                                              int Cin, int Cout) {
+                                                              int Cin, int Cout, unsigned nt_mul, unsigned nt_shr,
+                                                              unsigned rt_mul, unsigned rt_shr) {
 #ifdef TAG_HALO_PROF
     const unsigned long long hrt_first = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -326,38 +330,38 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     const int row_tiles = (H + G::TH - 1) / G::TH;               // W == TW: one tile column
     const int m_tiles = B * row_tiles;
     const int L = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-    const int n0 = (L % n_tiles) * BN_;
-    const int mt = L / n_tiles;
-    const int img = mt / row_tiles, h0 = (mt % row_tiles) * G::TH;
+    const int mt = (int)halo_fdiv((unsigned)L, nt_mul, nt_shr);                  // L / n_tiles
+    const int n0 = (L - mt * n_tiles) * BN_;
+    const int img = (int)halo_fdiv((unsigned)mt, rt_mul, rt_shr);                // mt / row_tiles
+    const int h0 = (mt - img * row_tiles) * G::TH;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
     const int kl = lane >> 5, ml = lane & 31;
     // 128-bit LDS writes: beside the fp32 MFMA streams of the two resident workgroups a ds_write_b32 waits 1250-5000 clocks for a gap
     // (tools/coissue_probe.hip); the one-float-per-thread form of this table fill held every new workgroup for ~8.7 us (halo_wg_timeline)
-    if (PRO != 0)
-        for (int c4 = tid; c4 < Cin / 4; c4 += 256) {
-            *reinterpret_cast<f32x4*>(Ss + 4 * c4) = ldg4(in_scale + 4 * c4);
-            *reinterpret_cast<f32x4*>(Ss + Cin + 4 * c4) = ldg4(in_shift + 4 * c4);
-        }
+    if (PRO != 0 && tid < Cin / 4) {                             // Cin <= 512 (host check): one item per thread
+        *reinterpret_cast<f32x4*>(Ss + 4 * tid) = ldg4(in_scale + 4 * tid);
+        *reinterpret_cast<f32x4*>(Ss + Cin + 4 * tid) = ldg4(in_shift + 4 * tid);
+    }
 
     // ---- patch staging geometry (loop invariant): item = (patch pixel, channel quad) ----
     const int q = tid & 7;
     unsigned poff[G::ITEMS];                   // byte offset of the item in x (clamped to a valid pixel)
     unsigned pvalid = 0;                       // bit i: the pixel lies inside the image
-    unsigned pexist = 0;                       // bit i: the item exists (idx < PP*8)
+    // (sign-bit arithmetic instead of comparisons: vector compares and their && are combined in SCALAR mask registers)
 #pragma unroll
     for (int i = 0; i < G::ITEMS; ++i) {
         const int idx = tid + 256 * i;
         const int pp = idx >> 3;
         const int pr = pp / G::PW, pc = pp - pr * G::PW;
-        const int h = h0 - 1 + pr, w = pc - 1;
-        const bool ex = pp < G::PP;
-        const bool ok = ex && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        pexist |= (unsigned)ex << i;
-        pvalid |= (unsigned)ok << i;
-        const int pix = ok ? h * W + w : 0;                // inside the image: 32-bit byte offsets hold any batch (round 4)
-        poff[i] = (unsigned)(((long)pix * Cin + q * 4) * 4);
+        const unsigned uh = (unsigned)(h0 - 1 + pr), uw = (unsigned)(pc - 1);
+        const unsigned okh = ((uh - (unsigned)H) >> 31) & (~uh >> 31);          // 0 <= h < H
+        const unsigned okw = ((uw - (unsigned)W) >> 31) & (~uw >> 31);
+        const unsigned ok = okh & okw & ((unsigned)(pp - G::PP) >> 31);         // ... and the item exists (pp < PP)
+        pvalid |= ok << i;
+        const unsigned pix = (uh * (unsigned)W + uw) & (0u - ok);               // inside the image: 32-bit byte offsets hold any batch
+        poff[i] = (pix * (unsigned)Cin + (unsigned)(q * 4)) * 4u;
     }
     const char* ximg = reinterpret_cast<const char*>(x) + (size_t)img * H * W * Cin * 4;      // wave-uniform 64-bit image base
     // pixel of the tile behind result register r of row tile i (C/D layout: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 kl)
@@ -387,8 +391,8 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
         }
 #pragma unroll
         for (int i = 0; i < G::ITEMS; ++i) {
-            if (!((pexist >> i) & 1u)) continue;
-            const int pp = (tid + 256 * i) >> 3;
+            int pp = (tid + 256 * i) >> 3;
+            pp = pp < G::PP ? pp : G::PP;                      // items past the patch: the scratch pixel (no exec-mask branch)
             f32x4 v = apply_prologue(ra[i], PRO, rs, rt);
             if (!((pvalid >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             *reinterpret_cast<f32x4*>(As + pp * G::AROW + q * 4) = v;
@@ -1668,7 +1672,17 @@ template <int BN_, int TW>
 static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, float* stats,
                         const BnBwdEpi* epi, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = HaloGeom<TW>;
-    const int grid = B * ((H + G::TH - 1) / G::TH) * ((Cout + BN_ - 1) / BN_);
+    const int row_tiles = (H + G::TH - 1) / G::TH, n_tiles = (Cout + BN_ - 1) / BN_;
+    const int grid = B * row_tiles * n_tiles;
+    auto magic = [](unsigned d, unsigned* mul, unsigned* shr) {            // n / d = (mulhi(n, mul) + n) >> shr for n < 2^31
+        unsigned l = 0;
+        while ((1u << l) < d) ++l;
+        *shr = l;
+        *mul = (unsigned)((((unsigned long long)1 << 32) * ((1ull << l) - d)) / d + 1);
+    };
+    unsigned nt_mul, nt_shr, rt_mul, rt_shr;
+    magic((unsigned)n_tiles, &nt_mul, &nt_shr);
+    magic((unsigned)row_tiles, &rt_mul, &rt_shr);
     // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
     // third workgroup of a CU fits only without the unused part of a 512-channel table)
     const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
@@ -1680,7 +1694,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
             attr_set = true;
         }
         hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
-                           B, H, W, Cin, Cout);
+                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr);
         return;
     }
     const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1693,7 +1707,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
             attr_set = true;                                                                                      \
         }                                                                                                         \
         hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
-                           none, B, H, W, Cin, Cout);                                                             \
+                           none, B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr);                             \
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;

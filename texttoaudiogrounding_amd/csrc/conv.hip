@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
     // two operand buffers: buffer b = [PP][64] input patch (pixel-major) followed by [32][64] dy chunk.  The next chunk is written
     // to the other buffer IN THE MIDDLE of the current chunk's MFMA stream (its loads were issued one chunk earlier) and one
     // barrier ends each chunk: no store phase between two barriers in which the wave issues no MFMA (round 4, as in the halo conv)
-    constexpr int BUFSZ = G::PP * 64 + 32 * 64;
+    constexpr int BUFSZ = (G::PP + 1) * 64 + 32 * 64;           // + one scratch pixel for the staging items past the patch
 
     const int ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 63) / 64;
     int L = xcd_remap(blockIdx.x, ci_tiles * co_tiles * splits);
@@ -886,58 +886,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
     const int wci = (wid >> 1) * 32, wco = (wid & 1) * 32;
     const int kl = lane >> 5, ml = lane & 31;
 
-    // staging geometry (loop invariant): patch item = (patch pixel, channel quad), dy item = (pixel, channel quad)
-    int xpr[G::XITEMS], xpc[G::XITEMS];
-    unsigned xex = 0;
+    // staging geometry (loop invariant): patch item = (patch pixel, channel quad), dy item = (pixel, channel quad).  Scalar
+    // instructions wait for gaps in the co-resident workgroup's MFMA stream (tools/coissue_probe.hip), so the per-chunk part is kept
+    // free of divisions, 64-bit multiplies, vector compares and exec-mask branches: the chunk origin is carried incrementally,
+    // validity is sign-bit arithmetic, offsets are 32-bit inside the image, items past the patch go to a scratch pixel.
+    int xpr[G::XITEMS], xpc[G::XITEMS], xpp[G::XITEMS];
     const int c4 = (tid & 15) * 4;
     const int ca = ci0 + c4 < Cin ? ci0 + c4 : 0, cb = co0 + c4 < Cout ? co0 + c4 : 0;
 #pragma unroll
     for (int i = 0; i < G::XITEMS; ++i) {
         const int pp = (tid + 256 * i) >> 4;
-        xex |= (unsigned)(pp < G::PP) << i;
         xpr[i] = pp / G::PW;
         xpc[i] = pp - xpr[i] * G::PW;
+        xpp[i] = pp < G::PP ? pp : G::PP;
     }
     f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
     if (PRO != 0) { rs = ldg4(in_scale + ca); rt = ldg4(in_shift + ca); }
 
     f32x4 rx[G::XITEMS], rd[2];
     unsigned xok = 0, dok = 0;
-    auto issue_chunk = [&](int c) {
-        // wave-uniform chunk origin
-        const int cbk = c % cb_per_row; int r = c / cb_per_row;
-        const int rbk = r % rb_per_img; const int img = r / rb_per_img;
-        const int h0 = rbk * G::CH, w0 = cbk * G::CW;
-        const long ibase = (long)img * H * W;
+    // origin of the NEXT chunk to be requested (chunks are requested in increasing order, column blocks fastest)
+    int o_img, o_h0, o_w0;
+    {
+        const int cbk = cbeg % cb_per_row; const int r = cbeg / cb_per_row;
+        o_img = r / rb_per_img; o_h0 = (r - o_img * rb_per_img) * G::CH; o_w0 = cbk * G::CW;
+    }
+    const size_t img_x = (size_t)H * W * Cin * 4, img_d = (size_t)H * W * Cout * 4;       // bytes per image
+    const char* xi = reinterpret_cast<const char*>(x) + (size_t)o_img * img_x;
+    const char* di = reinterpret_cast<const char*>(dy) + (size_t)o_img * img_d;
+    auto issue_chunk = [&](int) {
+        const int h0 = o_h0, w0 = o_w0;
         xok = dok = 0;
 #pragma unroll
         for (int i = 0; i < G::XITEMS; ++i) {
-            const int h = h0 - 1 + xpr[i], w = w0 - 1 + xpc[i];
-            const unsigned ok = ((xex >> i) & 1u) & (unsigned)((unsigned)h < (unsigned)H) & (unsigned)((unsigned)w < (unsigned)W);
+            const unsigned uh = (unsigned)(h0 - 1 + xpr[i]), uw = (unsigned)(w0 - 1 + xpc[i]);
+            const unsigned ok = ((uh - (unsigned)H) >> 31) & (~uh >> 31) & ((uw - (unsigned)W) >> 31) & (~uw >> 31);
             xok |= ok << i;
-            const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rx[i] = ldg4(x + pix * Cin + ca);
+            const unsigned pix = (uh * (unsigned)W + uw) & (0u - ok);
+            rx[i] = *reinterpret_cast<const f32x4*>(xi + (pix * (unsigned)Cin + (unsigned)ca) * 4u);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = (tid + 256 * i) >> 4;                     // pixel of the chunk, row-major in the rectangle
-            const int h = h0 + k / G::CW, w = w0 + k % G::CW;
-            const unsigned ok = (unsigned)(h < H);
+            const unsigned uh = (unsigned)(h0 + k / G::CW), uw = (unsigned)(w0 + k % G::CW);
+            const unsigned ok = (uh - (unsigned)H) >> 31;
             dok |= ok << i;
-            const long pix = ok ? ibase + (long)h * W + w : ibase;
-            rd[i] = ldg4(dy + pix * Cout + cb);
+            const unsigned pix = (uh * (unsigned)W + uw) & (0u - ok);
+            rd[i] = *reinterpret_cast<const f32x4*>(di + (pix * (unsigned)Cout + (unsigned)cb) * 4u);
+        }
+        // advance the origin by one chunk
+        o_w0 += G::CW;
+        if (o_w0 >= TW) {
+            o_w0 = 0; o_h0 += G::CH;
+            if (o_h0 >= rb_per_img * G::CH) { o_h0 = 0; ++o_img; xi += img_x; di += img_d; }
         }
     };
     auto store_chunk = [&](int buf) {
         float* As = smem + buf * BUFSZ;
-        float* Bs = As + G::PP * 64;
+        float* Bs = As + (G::PP + 1) * 64;
 #pragma unroll
         for (int i = 0; i < G::XITEMS; ++i) {
-            if (!((xex >> i) & 1u)) continue;
-            const int pp = (tid + 256 * i) >> 4;
             f32x4 v = apply_prologue(rx[i], PRO, rs, rt);
             if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            *reinterpret_cast<f32x4*>(As + pp * 64 + c4) = v;
+            *reinterpret_cast<f32x4*>(As + xpp[i] * 64 + c4) = v;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -964,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
         const int buf = (c - cbeg) & 1;
         __builtin_amdgcn_sched_barrier(0);
         const float* a = smem + buf * BUFSZ + kl * 64 + wci + ml;
-        const float* b = smem + buf * BUFSZ + G::PP * 64 + kl * 64 + wco + ml;
+        const float* b = smem + buf * BUFSZ + (G::PP + 1) * 64 + kl * 64 + wco + ml;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             if (ks == 8) {                                 // chunk c + 1 (loaded during chunk c - 1 .. c) -> the other buffer
@@ -1828,7 +1839,7 @@ static void launch_wgrad_alltaps(const float* x, int pro, const float* s, const 
                                  int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
     using G = WgGeom<TW>;
     const int grid = ((Cin + 63) / 64) * ((Cout + 63) / 64) * splits;
-    const size_t lds = (size_t)2 * (G::PP * 64 + 32 * 64) * sizeof(float);
+    const size_t lds = (size_t)2 * ((G::PP + 1) * 64 + 32 * 64) * sizeof(float);
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
@@ -1881,8 +1892,10 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     TAG_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
-    // the all-taps kernel indexes pixels with 64-bit products; the per-tap fallback keeps 32-bit byte offsets over the batch
+    // the all-taps kernel keeps a 64-bit image base and 32-bit byte offsets inside ONE image; the per-tap fallback keeps 32-bit
+    // byte offsets over the batch
     TAG_CHECK_ARG(M < (1L << 31) && W <= 64);
+    TAG_CHECK_ARG((long)H * W * Cin * 4 < (1L << 32) && (long)H * W * Cout * 4 < (1L << 32));
     TAG_CHECK_ARG(wgrad_alltaps_ok(W) || (M * Cin * 4 < (1L << 32) && M * Cout * 4 < (1L << 32)));
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);

@@ -466,6 +466,7 @@ def main():
                 dta = t.item()
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3)}
+            alt[mode]["wgrad_side_stream"] = bool(ops.side_stream_enabled())
             if mode == "bf16":
                 fam_a = fam_a_iso = families(prof_a)
                 overlap_a = ops.side_stream_enabled()

@@ -309,12 +309,12 @@ struct BnBwdEpi {
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
-__global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float* __restrict__ y,
                                                               float* __restrict__ stats, BnBwdEpi epi, int B, int H, int W,
                                                               int Cin, int Cout, unsigned nt_mul, unsigned nt_shr,
-                                                              unsigned rt_mul, unsigned rt_shr) {
+                                                              unsigned rt_mul, unsigned rt_shr, int col_tiles) {
 #ifdef TAG_HALO_PROF
     const unsigned long long hrt_first = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -327,13 +327,16 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
     float* Ss = Bs + 2 * ST * BN_;             // [2][Cin] producer BN scale / shift
 
     const int n_tiles = (Cout + BN_ - 1) / BN_;
-    const int row_tiles = (H + G::TH - 1) / G::TH;               // W == TW: one tile column
+    // W == col_tiles * TW: one tile column, or two for the 64-wide images (a 4 x 32 rectangle has a 204-pixel patch where the
+    // 2 x 64 one has 264: 38 instead of 47 KB of LDS, i.e. FOUR workgroups of the 64-cout tiles per CU)
+    const int row_tiles = ((H + G::TH - 1) / G::TH) * col_tiles; // (row tile, column tile) pairs per image, column tiles fastest
     const int m_tiles = B * row_tiles;
     const int L = xcd_remap(blockIdx.x, m_tiles * n_tiles);
     const int mt = (int)halo_fdiv((unsigned)L, nt_mul, nt_shr);                  // L / n_tiles
     const int n0 = (L - mt * n_tiles) * BN_;
     const int img = (int)halo_fdiv((unsigned)mt, rt_mul, rt_shr);                // mt / row_tiles
-    const int h0 = (mt - img * row_tiles) * G::TH;
+    const int rc = mt - img * row_tiles;                         // col_tiles is 1 or 2
+    const int h0 = (col_tiles == 2 ? rc >> 1 : rc) * G::TH, w0 = (col_tiles == 2 ? rc & 1 : 0) * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * (BN_ / 2);
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
         const int idx = tid + 256 * i;
         const int pp = idx >> 3;
         const int pr = pp / G::PW, pc = pp - pr * G::PW;
-        const unsigned uh = (unsigned)(h0 - 1 + pr), uw = (unsigned)(pc - 1);
+        const unsigned uh = (unsigned)(h0 - 1 + pr), uw = (unsigned)(w0 + pc - 1);
         const unsigned okh = ((uh - (unsigned)H) >> 31) & (~uh >> 31);          // 0 <= h < H
         const unsigned okw = ((uw - (unsigned)W) >> 31) & (~uw >> 31);
         const unsigned ok = okh & okw & ((unsigned)(pp - G::PP) >> 31);         // ... and the item exists (pp < PP)
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
                     if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
                     // now x_t = cout nq + t of the pixel behind register 4 rq + c4
                     const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
-                    const int h = h0 + m / TW, w = m % TW;
+                    const int h = h0 + m / TW, w = w0 + m % TW;
                     if (h < H && nq < Cout)
                         *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
                 }
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(256, halo_stage<BN_>() == 32 ? 2 : 3) void conv3x3_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = tile_m(i, r);
-                    const int h = h0 + m / TW, w = m % TW;
+                    const int h = h0 + m / TW, w = w0 + m % TW;
                     const int hc = h < H ? h : H - 1;
                     yv[r] = epi.yref[(((size_t)img * H + hc) * W + w) * Cout + nc];
                 }
@@ -1683,7 +1686,8 @@ template <int BN_, int TW>
 static void launch_halo(const float* x, const float* wp, int pro, const float* s, const float* t, float* y, float* stats,
                         const BnBwdEpi* epi, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
     using G = HaloGeom<TW>;
-    const int row_tiles = (H + G::TH - 1) / G::TH, n_tiles = (Cout + BN_ - 1) / BN_;
+    const int col_tiles = W / TW;                                          // 1, or 2 for the 64-wide images on 32-wide tiles
+    const int row_tiles = ((H + G::TH - 1) / G::TH) * col_tiles, n_tiles = (Cout + BN_ - 1) / BN_;
     const int grid = B * row_tiles * n_tiles;
     auto magic = [](unsigned d, unsigned* mul, unsigned* shr) {            // n / d = (mulhi(n, mul) + n) >> shr for n < 2^31
         unsigned l = 0;
@@ -1705,7 +1709,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
             attr_set = true;
         }
         hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
-                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr);
+                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);
         return;
     }
     const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1718,7 +1722,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
             attr_set = true;                                                                                      \
         }                                                                                                         \
         hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
-                           none, B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr);                             \
+                           none, B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);                             \
     }
     switch (pro) {
         case 0: LAUNCH_PRO(0) break;
@@ -1734,8 +1738,8 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 extern "C" int tag_conv3x3_stats_rows(int B, int H, int W, int Cout) {
     (void)Cout;
     if (!(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64))) return 0;
-    const int th = 128 / W;
-    return B * ((H + th - 1) / th) * 2;
+    const int tw = W == 64 ? 32 : W, th = 128 / tw;             // 64-wide images: two 4 x 32 tile columns
+    return B * ((H + th - 1) / th) * (W / tw) * 2;
 }
 
 extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prologue, const float* in_scale,
@@ -1756,7 +1760,7 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);        \
     else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
     else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
-    else launch_halo<BN_, 64>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);
+    else launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);   /* W == 64: two tile columns */
     if (halo) {
         if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
     } else if (Cout >= 128) {

@@ -830,10 +830,10 @@ CNN8_POOLS = [(2, 2), (2, 2), (1, 2), (1, 2)]
 
 #: weight-gradient convolutions are off the critical path of backward (only the optimiser needs them): on a second HIP stream
 #: their workgroups fill the tails / small-grid gaps of the dgrad + BatchNorm chain.  TAG_WGRAD_STREAM = 1 / 0 forces it on / off;
-#: the default ("auto", None here) is ON in the bf16 mode and OFF for the fp32-accurate arithmetics: with round 4's halo / all-taps
-#: kernels the fp32 step IS the sum of its kernels' isolated times and co-running two MFMA-bound kernels only stretches both
-#: (same box, alternating processes: 54.82 / 54.92 ms with the side stream, 54.18 / 54.15 ms without), while the bf16 mode's
-#: shorter kernels still gain (10.52-10.53 against 10.70-10.78 ms).
+#: the default ("auto", None here) is ON for the arithmetics on the bf16 MFMA (bf16 mode, x3, x9) and OFF for exact fp32: with
+#: round 4's halo / all-taps kernels the fp32 step IS the sum of its kernels' isolated times and co-running two of them only
+#: stretches both (same box, alternating processes: 54.82 / 54.92 ms with the side stream, 54.18 / 54.15 ms without), while the
+#: bf16-MFMA modes' shorter kernels still gain (bf16 10.52-10.53 against 10.70-10.78 ms, x3 34.6 against 35.3, x9 44.8 against 45.1).
 import os as _os
 _side_env = _os.environ.get("TAG_WGRAD_STREAM", "auto")
 WGRAD_SIDE_STREAM = None if _side_env == "auto" else (_side_env != "0")
@@ -841,7 +841,7 @@ _side_streams = {}
 
 
 def side_stream_enabled():
-    return WGRAD_SIDE_STREAM if WGRAD_SIDE_STREAM is not None else (CONV_MATH == "bf16")
+    return WGRAD_SIDE_STREAM if WGRAD_SIDE_STREAM is not None else (CONV_MATH != "fp32")
 
 
 #: TAG_WGRAD_CU_SKIP=k (k >= 2): the side stream may not use every k-th compute unit (hipExtStreamCreateWithCUMask), so that the

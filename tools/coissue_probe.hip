@@ -138,6 +138,8 @@ int main() {
     run<2, 13>("single ds_write_b32 beside bf16 MFMA");
     run<0, 14>("5 dependent SALU ops, partner idle");
     run<1, 14>("5 dependent SALU ops beside fp32 MFMA");
+    run<2, 14>("5 dependent SALU ops beside bf16 MFMA");
+    run<3, 14>("5 dependent SALU ops beside fp32 MFMA + LDS-read stream");
     run<1, 14, 3>("5 dependent SALU ops beside fp32 MFMA, s_setprio 3");
     run<1, 13, 3>("single ds_write_b32 beside fp32 MFMA, s_setprio 3");
     run<1, 6, 3>("global_store_dword beside fp32 MFMA, s_setprio 3");

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
     // let the MFMA stream get going
     for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(1);
     float v[16];
+    f32x4 vq[4] = {};
     for (int i = 0; i < 16; ++i) v[i] = lane * 0.001f + i;
     int su = __builtin_amdgcn_readfirstlane(work_iters);      // wave-uniform chain for the SALU / SMEM probes
     const float* __restrict__ csink = sink;
@@ -77,9 +78,12 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
             if (WORK == 14) { su = su * 3 + 7 + i; su ^= su >> 3; }
             if (WORK == 15 && i < 4) { su += reinterpret_cast<const int*>(csink)[64 + ((su + i) & 1023)]; }
             if (WORK == 16) { unsigned u_ = __float_as_uint(v[i]); u_ = u_ * 2654435761u + 12345u; v[i] = __uint_as_float((u_ & 0x007fffffu) | 0x3f800000u); }
+            if (WORK == 17 && i < 4) { f32x4 t_; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t_) : "v"(sink + 64 + ((it & 3) * 256 + i * 64 + lane) * 4) : "memory"); vq[i] = t_; }
+            if (WORK == 18 && i < 4) { f32x4 t_; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t_) : "v"((unsigned)(((it & 3) * 256 + i * 64 + lane) * 16)), "s"(sink + 64) : "memory"); vq[i] = t_; }
             if (WORK == 7 && i < 4) *reinterpret_cast<float2*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 2) = make_float2(v[i], v[i + 1]);
             if (WORK == 8 && i < 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 4); v[i] += t.x; }
         }
+        if (WORK == 17 || WORK == 18) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); v[0] += vq[0].x + vq[1].x + vq[2].x + vq[3].x; }
         if (WORK == 4 || WORK == 5 || WORK == 6 || (WORK >= 9 && WORK <= 12)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (WORK != 0) __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
     }
@@ -148,6 +152,10 @@ int main() {
     run<1, 15>("dependent s_load_dword (+2 SALU) beside fp32 MFMA");
     run<0, 16>("v_mul_lo_u32 + 3 int VALU, partner idle");
     run<1, 16>("v_mul_lo_u32 + 3 int VALU beside fp32 MFMA");
+    run<0, 17>("global_load_dwordx4 (64-bit VGPR addr), partner idle");
+    run<1, 17>("global_load_dwordx4 (64-bit VGPR addr) beside fp32");
+    run<2, 17>("global_load_dwordx4 (64-bit VGPR addr) beside bf16");
+    run<2, 18>("global_load_dwordx4 (SGPR base) beside bf16");
     run<0, 7>("ds_write_b64, partner idle");
     run<1, 7>("ds_write_b64 beside fp32 MFMA stream");
     run<0, 8>("ds_read_b128, partner idle");

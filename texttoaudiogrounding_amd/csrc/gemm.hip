@@ -4,9 +4,12 @@
 // backward GEMM of those, and align.DotProduct (models/align.py:14-31) through the fused
 // sigmoid/clamp + (B,B,T,N) scatter epilogue.
 //
-// 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 staged k-major in LDS
-// (As[k][m], Bs[k][n]) and double-buffered; a k-contiguous operand is transposed on its way into
-// LDS with a stride of 65 floats (conflict-free), an mn-contiguous one is copied with float4.
+// 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 double-buffered in LDS.
+// Both kinds of operand are COPIED into LDS with 16-byte writes (round 4: a ds_write_b32 waits for gaps in the co-resident
+// workgroups' fp32 MFMA streams, tools/coissue_probe.hip, and the transposing store of a k-contiguous operand was four of them
+// per float4): an mn-contiguous operand k-major (S[k][r]), a k-contiguous one row-major (S[r][32 k + 4 pad], the halo conv's
+// conflict-free 144-byte rows).  A fragment of the row-major image is ONE ds_read_b128 = the lane's operands of four k-steps:
+// k-step j of an 8-k group multiplies k = 8 g + 4 kl + j (kl = lane / 32); the k-major image is read at the same permuted rows.
 #include <type_traits>
 #include "tag_common.h"
 
@@ -26,10 +29,11 @@ __device__ __forceinline__ float4 load4(const float* p, int n, bool aligned) {
 }
 
 // KC = operand is k-contiguous in memory (element (r,k) at base[r*ld + k]); else mn-contiguous
-// (element (r,k) at base[k*ld + r]).  LDS image is always S[k][r].  T = tile edge (64 or 128).
+// (element (r,k) at base[k*ld + r]).  LDS image: S[r][LD] (KC) or S[k][LD] (else).  T = tile edge (64 or 128).
 template <bool KC, int T>
 struct Stage {
-    static constexpr int LD = KC ? T + 1 : T;
+    static constexpr int LD = KC ? GK + 4 : T;
+    static constexpr int SZ = KC ? T * (GK + 4) : GK * T;     // floats per buffer
     static constexpr int NL = T / 32;       // float4 per thread per chunk
     f32x4 reg[NL];
     // FAST: every tile and K chunk is whole and 16-byte aligned (checked by the launcher) -> plain float4 loads, no tail tests
@@ -57,10 +61,7 @@ struct Stage {
             const int idx = threadIdx.x + 256 * i;
             if (KC) {
                 const int r = idx >> 3, k = (idx & 7) * 4;
-                s[(k + 0) * LD + r] = reg[i].x;
-                s[(k + 1) * LD + r] = reg[i].y;
-                s[(k + 2) * LD + r] = reg[i].z;
-                s[(k + 3) * LD + r] = reg[i].w;
+                *reinterpret_cast<f32x4*>(s + r * LD + k) = reg[i];
             } else {
                 const int k = idx / (T / 4), r = (idx % (T / 4)) * 4;
                 *reinterpret_cast<f32x4*>(s + k * LD + r) = reg[i];
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
     constexpr int KCH = BF ? GKB : GK;     // K chunk per barrier
     constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
-    constexpr int ASZ = BF ? T * BFROW / 4 : ((GK * LDSA + 3) / 4) * 4;               // floats per buffer (16-byte aligned)
-    constexpr int BSZ = BF ? T * BFROW / 4 : ((GK * LDSB + 3) / 4) * 4;
+    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T>::SZ;                        // floats per buffer (16-byte aligned)
+    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T>::SZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][ASZ]
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
@@ -241,30 +242,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                                                                             0, 0, 0);
             }
         } else {
-        const float* a = As + buf * ASZ + kl * LDSA + wm0 + ml;
-        const float* b = Bs + buf * BSZ + kl * LDSB + wn0 + ml;
-        float af[2][TT], bf[2][TT];
+        // fragment of 8-k group g: four operands per lane and 32-row tile (k = 8 g + 4 kl + j, j = 0..3)
+        const float* a = As + buf * ASZ + (AKC ? (wm0 + ml) * LDSA + kl * 4 : (kl * 4) * LDSA + wm0 + ml);
+        const float* b = Bs + buf * BSZ + (BKC ? (wn0 + ml) * LDSB + kl * 4 : (kl * 4) * LDSB + wn0 + ml);
+        auto frag_a = [&](int g, f32x4 (&v)[TT]) {
 #pragma unroll
-        for (int i = 0; i < TT; ++i) af[0][i] = a[i * 32];
-#pragma unroll
-        for (int j = 0; j < TT; ++j) bf[0][j] = b[j * 32];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int ks = 0; ks < GK / 2; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < GK / 2) {
-#pragma unroll
-                for (int i = 0; i < TT; ++i) af[nxt][i] = a[(2 * ks + 2) * LDSA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TT; ++j) bf[nxt][j] = b[(2 * ks + 2) * LDSB + j * 32];
+            for (int i = 0; i < TT; ++i) {
+                if (AKC) v[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSA + 8 * g);
+                else v[i] = (f32x4){a[(8 * g) * LDSA + i * 32], a[(8 * g + 1) * LDSA + i * 32], a[(8 * g + 2) * LDSA + i * 32],
+                                    a[(8 * g + 3) * LDSA + i * 32]};
             }
+        };
+        auto frag_b = [&](int g, f32x4 (&v)[TT]) {
 #pragma unroll
-            for (int i = 0; i < TT; ++i)
+            for (int j = 0; j < TT; ++j) {
+                if (BKC) v[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSB + 8 * g);
+                else v[j] = (f32x4){b[(8 * g) * LDSB + j * 32], b[(8 * g + 1) * LDSB + j * 32], b[(8 * g + 2) * LDSB + j * 32],
+                                    b[(8 * g + 3) * LDSB + j * 32]};
+            }
+        };
+        f32x4 af[2][TT], bf[2][TT];
+        frag_a(0, af[0]);
+        frag_b(0, bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            if (ks + 1 < GK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);
+        for (int g = 0; g < GK / 8; ++g) {
+            if (g + 1 < GK / 8) { frag_a(g + 1, af[(g + 1) & 1]); frag_b(g + 1, bf[(g + 1) & 1]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -336,8 +347,8 @@ int gemm_splits(int M, int N, int K) {
 template <bool AKC, bool BKC, int T, bool BF = false>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st) {
-    constexpr int ASZ = BF ? T * BFROW / 4 : ((GK * Stage<AKC, T>::LD + 3) / 4) * 4;
-    constexpr int BSZ = BF ? T * BFROW / 4 : ((GK * Stage<BKC, T>::LD + 3) / 4) * 4;
+    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T>::SZ;
+    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T>::SZ;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

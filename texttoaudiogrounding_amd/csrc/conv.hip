@@ -1015,6 +1015,176 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_alltaps_kernel(const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// All-taps wgrad for the 32- and 64-wide images (round 4): the same decomposition (64 ci x 64 co x 9 taps per workgroup, 32-pixel
+// chunks = one image row of a 32-wide column strip), but a workgroup walks DOWN its strip and the input rows live in a RING of four
+// row slots: a chunk stages only its one new row (34 pixels) instead of the whole 3 x 34 patch -- the full-patch form staged every
+// input row three times, 7 + 2 float4 per thread and chunk against 4 + 2 on the narrow images, and ran at 0.85 MFMA busy against
+// 0.90 there.  New row and dy tile are written in the middle of the chunk's MFMA stream; one barrier per chunk; a new strip (once
+// per H chunks) rebuilds the ring synchronously.  Chunk order: (image, strip, row), rows fastest.
+// ------------------------------------------------------------------------------------------
+template <int TW, int PRO>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rowring_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ in_scale,
+                                                                       const float* __restrict__ in_shift,
+                                                                       const float* __restrict__ dy,
+                                                                       float* __restrict__ partial, int B, int H, int W,
+                                                                       int Cin, int Cout, int splits, int chunks_per_split) {
+    constexpr int CW = 32, PW = CW + 2, R = 4, ROWF = PW * 64;  // floats per ring slot
+    constexpr int XI = (PW * 16 + 255) / 256;                    // float4 per thread per input row (3; the items past the row: scratch)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xr = smem;                                            // [R][PW][64] + one scratch pixel
+    float* Ys = smem + R * ROWF + 64;                            // [2][32][64]
+
+    const int ci_tiles = (Cin + 63) / 64, co_tiles = (Cout + 63) / 64;
+    int L = xcd_remap(blockIdx.x, ci_tiles * co_tiles * splits);
+    const int cot = L % co_tiles; L /= co_tiles;
+    const int cit = L % ci_tiles; L /= ci_tiles;
+    const int split = L;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    constexpr int strips = TW / CW;
+    const int chunks_total = B * strips * H;
+    const int cbeg = split * chunks_per_split;
+    int cend = cbeg + chunks_per_split;
+    if (cend > chunks_total) cend = chunks_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wci = (wid >> 1) * 32, wco = (wid & 1) * 32;
+    const int kl = lane >> 5, ml = lane & 31;
+    const int c4 = (tid & 15) * 4;
+    const int ca = ci0 + c4 < Cin ? ci0 + c4 : 0, cb = co0 + c4 < Cout ? co0 + c4 : 0;
+    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRO != 0) { rs = ldg4(in_scale + ca); rt = ldg4(in_shift + ca); }
+
+    // position of the current chunk: image, strip origin column, row (division once per workgroup, then incremental)
+    int img, w0, h;
+    {
+        const int t = cbeg / H;
+        h = cbeg - t * H;
+        img = t / strips;
+        w0 = (t - img * strips) * CW;
+    }
+    const size_t img_x = (size_t)H * W * Cin * 4, img_d = (size_t)H * W * Cout * 4;
+    const char* xi = reinterpret_cast<const char*>(x) + (size_t)img * img_x;
+    const char* di = reinterpret_cast<const char*>(dy) + (size_t)img * img_d;
+
+    f32x4 rx[XI], rd[2];
+    unsigned xok = 0;
+    auto load_row = [&](int r) {                                 // input row r of the current strip (zeros outside the image)
+        const unsigned ur = (unsigned)r;
+        const unsigned okr = ((ur - (unsigned)H) >> 31) & (~ur >> 31);
+        xok = 0;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int pp = (tid + 256 * i) >> 4;
+            const unsigned uw = (unsigned)(w0 - 1 + pp);
+            const unsigned ok = okr & ((uw - (unsigned)W) >> 31) & (~uw >> 31) & ((unsigned)(pp - PW) >> 31);
+            xok |= ok << i;
+            const unsigned pix = (ur * (unsigned)W + uw) & (0u - ok);
+            rx[i] = *reinterpret_cast<const f32x4*>(xi + (pix * (unsigned)Cin + (unsigned)ca) * 4u);
+        }
+    };
+    auto store_row = [&](int r) {                                // -> ring slot r & 3
+        float* dst = Xr + ((r + 4) & 3) * ROWF;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int pp = (tid + 256 * i) >> 4;
+            f32x4 v = apply_prologue(rx[i], PRO, rs, rt);
+            if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            float* d = pp < PW ? dst + pp * 64 + c4 : Xr + R * ROWF + c4;
+            *reinterpret_cast<f32x4*>(d) = v;
+        }
+    };
+    auto load_dy = [&](int r) {                                  // dy row r (always inside the image), columns w0 .. w0 + 31
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;
+            rd[i] = *reinterpret_cast<const f32x4*>(di + (((unsigned)r * (unsigned)W + (unsigned)(w0 + k)) * (unsigned)Cout + (unsigned)cb) * 4u);
+        }
+    };
+    auto store_dy = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid + 256 * i) >> 4;
+            *reinterpret_cast<f32x4*>(Ys + buf * 2048 + k * 64 + c4) = rd[i];
+        }
+    };
+    // rows h - 1, h, h + 1 and dy(h) of a strip's first chunk in this workgroup, synchronously (once per strip)
+    auto prime = [&](int buf) {
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) { load_row(h + d); store_row(h + d); }
+        load_dy(h);
+        store_dy(buf);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    bool have_next_regs = false;                                 // rx / rd hold row h + 2 / dy(h + 1) of the current strip
+    if (cbeg < cend) {
+        prime(0);
+        if (cbeg + 1 < cend && h + 1 < H) { load_row(h + 2); load_dy(h + 1); have_next_regs = true; }
+    }
+    __syncthreads();
+    for (int c = cbeg; c < cend; ++c) {
+        const int buf = (c - cbeg) & 1;
+        const bool next = c + 1 < cend, next_same = next && h + 1 < H;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* a0 = Xr + ((h + 3) & 3) * ROWF + kl * 64 + wci + ml;        // row h - 1
+        const float* a1 = Xr + (h & 3) * ROWF + kl * 64 + wci + ml;              // row h
+        const float* a2 = Xr + ((h + 1) & 3) * ROWF + kl * 64 + wci + ml;        // row h + 1
+        const float* b = Ys + buf * 2048 + kl * 64 + wco + ml;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks == 8) {                                 // the next chunk's new row and dy tile (requested a chunk ago) -> LDS
+                __builtin_amdgcn_sched_barrier(0);
+                if (next_same && have_next_regs) {
+                    store_row(h + 2);
+                    store_dy(buf ^ 1);
+                    have_next_regs = false;
+                    if (c + 2 < cend && h + 2 < H) { load_row(h + 3); load_dy(h + 2); have_next_regs = true; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float bf = b[(2 * ks) * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float* ar = t < 3 ? a0 : (t < 6 ? a1 : a2);
+                const float af = ar[(2 * ks + t % 3) * 64];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // the next chunk is complete in LDS; every wave is done reading this one
+        // advance to the next chunk
+        ++h;
+        if (h == H) {
+            h = 0; w0 += CW;
+            if (w0 >= TW) { w0 = 0; ++img; xi += img_x; di += img_d; }
+            if (next) {                                    // new strip: rebuild the ring
+                prime(buf ^ 1);
+                have_next_regs = false;
+                if (c + 2 < cend && h + 1 < H) { load_row(h + 2); load_dy(h + 1); have_next_regs = true; }
+                __syncthreads();
+            }
+        }
+    }
+    // partial[split][tap][ci][co]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = partial + ((size_t)split * 9 + t) * Cin * Cout;
+        const int co = co0 + wco + ml;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[t][r];
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum_split partial[split][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cin,
                                                            int Cout, float* __restrict__ dw) {
@@ -1843,16 +2013,22 @@ static void launch_wgrad_alltaps(const float* x, int pro, const float* s, const 
                                  int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
     using G = WgGeom<TW>;
     const int grid = ((Cin + 63) / 64) * ((Cout + 63) / 64) * splits;
-    const size_t lds = (size_t)2 * ((G::PP + 1) * 64 + 32 * 64) * sizeof(float);
+    constexpr bool RING = TW >= 32;                                        // row-ring kernel for the wide images
+    const size_t lds = RING ? (size_t)(4 * 34 * 64 + 64 + 2 * 32 * 64) * sizeof(float)
+                            : (size_t)2 * ((G::PP + 1) * 64 + 32 * 64) * sizeof(float);
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_alltaps_kernel<TW, P>),          \
+            if (RING) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_rowring_kernel<(RING ? TW : 32), P>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+            else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_alltaps_kernel<TW, P>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((conv3x3_wgrad_alltaps_kernel<TW, P>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
+        if (RING) hipLaunchKernelGGL((conv3x3_wgrad_rowring_kernel<(RING ? TW : 32), P>), dim3(grid), dim3(256), lds, st, x, s, t, \
+                           dy, partial, B, H, W, Cin, Cout, splits, cps);                                           \
+        else hipLaunchKernelGGL((conv3x3_wgrad_alltaps_kernel<TW, P>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
                            B, H, W, Cin, Cout, splits, cps);                                                        \
     }
     switch (pro) {

@@ -452,6 +452,8 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
                  _X3_PRODUCTS[CONV_MATH], ptr(ws))
         return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+    # profile family: the all-taps decomposition (conv3x3_wgrad_alltaps_kernel at W = 8 / 16, its row-ring form
+    # conv3x3_wgrad_rowring_kernel at W = 32 / 64) or the per-tap fallback
     kname = "conv3x3_wgrad_alltaps_kernel" if W in (8, 16, 32, 64) else "conv3x3_wgrad_kernel"
     with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
         call("tag_conv3x3_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,

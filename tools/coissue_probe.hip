@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, float* sin
             if (WORK == 16) { unsigned u_ = __float_as_uint(v[i]); u_ = u_ * 2654435761u + 12345u; v[i] = __uint_as_float((u_ & 0x007fffffu) | 0x3f800000u); }
             if (WORK == 17 && i < 4) { f32x4 t_; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t_) : "v"(sink + 64 + ((it & 3) * 256 + i * 64 + lane) * 4) : "memory"); vq[i] = t_; }
             if (WORK == 18 && i < 4) { f32x4 t_; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t_) : "v"((unsigned)(((it & 3) * 256 + i * 64 + lane) * 16)), "s"(sink + 64) : "memory"); vq[i] = t_; }
+            if (WORK == 19 && i < 4) v[i] += __shfl_xor(v[i], 32, 64);
             if (WORK == 7 && i < 4) *reinterpret_cast<float2*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 2) = make_float2(v[i], v[i + 1]);
             if (WORK == 8 && i < 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(lds + (wid - 4) * 2048 + (i * 64 + lane) * 4); v[i] += t.x; }
         }
@@ -156,6 +157,8 @@ int main() {
     run<1, 17>("global_load_dwordx4 (64-bit VGPR addr) beside fp32");
     run<2, 17>("global_load_dwordx4 (64-bit VGPR addr) beside bf16");
     run<2, 18>("global_load_dwordx4 (SGPR base) beside bf16");
+    run<0, 19>("__shfl_xor 32 (ds_bpermute) + add, partner idle");
+    run<1, 19>("__shfl_xor 32 (ds_bpermute) + add beside fp32 MFMA");
     run<0, 7>("ds_write_b64, partner idle");
     run<1, 7>("ds_write_b64 beside fp32 MFMA stream");
     run<0, 8>("ds_read_b128, partner idle");

@@ -124,7 +124,12 @@ def test_bn_stats(ops, dev, C, rows):
                                                 (2, 1001, 64, 64, 64, 1), (2, 500, 32, 64, 128, 0),
                                                 (2, 500, 32, 128, 128, 1), (2, 250, 16, 128, 256, 0),
                                                 (2, 250, 16, 256, 256, 1), (2, 250, 8, 256, 512, 0),
-                                                (3, 250, 8, 512, 512, 1)])
+                                                (3, 250, 8, 512, 512, 1),
+                                                # round 4: 64-wide images run as two 4 x 32 tile columns, their weight gradient (and
+                                                # the 32-wide one) walks down a strip with the input rows in a ring of four slots:
+                                                # images shorter than the ring / the tile, a split that crosses strips and images
+                                                (1, 1, 64, 64, 64, 0), (3, 2, 64, 64, 128, 1), (2, 7, 64, 128, 64, 1),
+                                                (1, 1, 32, 64, 64, 1), (5, 3, 32, 64, 128, 0), (2, 5, 32, 128, 64, 3)])
 def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, Cin, H, W, generator=g)

@@ -1030,8 +1030,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rowring_kernel(const flo
                                                                        const float* __restrict__ dy,
                                                                        float* __restrict__ partial, int B, int H, int W,
                                                                        int Cin, int Cout, int splits, int chunks_per_split) {
-    constexpr int CW = 32, PW = CW + 2, R = 4, ROWF = PW * 64;  // floats per ring slot
-    constexpr int XI = (PW * 16 + 255) / 256;                    // float4 per thread per input row (3; the items past the row: scratch)
+    // chunk = CH rows x CW columns = 32 pixels of one column strip; ring of R row slots: the CH + 2 rows a chunk reads and the CH
+    // new rows of the next chunk
+    constexpr int CW = TW >= 32 ? 32 : TW, CH = 32 / CW, PW = CW + 2, R = 2 * CH + 2, ROWF = PW * 64;
+    constexpr int XI = (CH * PW * 16 + 255) / 256;               // float4 per thread per group of CH input rows (3)
+    constexpr int NPRIME = (CH + 2 + CH - 1) / CH;               // row groups that rebuild the ring at a strip's first chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xr = smem;                                            // [R][PW][64] + one scratch pixel
     float* Ys = smem + R * ROWF + 64;                            // [2][32][64]
@@ -1043,7 +1046,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rowring_kernel(const flo
     const int split = L;
     const int ci0 = cit * 64, co0 = cot * 64;
     constexpr int strips = TW / CW;
-    const int chunks_total = B * strips * H;
+    const int rb = (H + CH - 1) / CH;                            // row blocks (chunks) per strip
+    const int chunks_total = B * strips * rb;
     const int cbeg = split * chunks_per_split;
     int cend = cbeg + chunks_per_split;
     if (cend > chunks_total) cend = chunks_total;
@@ -1056,64 +1060,84 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rowring_kernel(const flo
     f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
     if (PRO != 0) { rs = ldg4(in_scale + ca); rt = ldg4(in_shift + ca); }
 
-    // position of the current chunk: image, strip origin column, row (division once per workgroup, then incremental)
-    int img, w0, h;
+    // position of the current chunk: image, strip origin column, first row h0, ring slot of row h0 - 1 (division once per workgroup)
+    int img, w0, h0, s0;
     {
-        const int t = cbeg / H;
-        h = cbeg - t * H;
+        const int t = cbeg / rb;
+        h0 = (cbeg - t * rb) * CH;
         img = t / strips;
         w0 = (t - img * strips) * CW;
+        s0 = (h0 + R - 1) % R;
     }
     const size_t img_x = (size_t)H * W * Cin * 4, img_d = (size_t)H * W * Cout * 4;
     const char* xi = reinterpret_cast<const char*>(x) + (size_t)img * img_x;
     const char* di = reinterpret_cast<const char*>(dy) + (size_t)img * img_d;
 
+    // staging geometry of a row group (loop invariant): item = (row pr of the group, patch column pc, channel quad)
+    int xpr[XI], xpc[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int pp = (tid + 256 * i) >> 4;
+        xpr[i] = pp / PW;                                        // >= CH: past the group -> scratch pixel
+        xpc[i] = pp - xpr[i] * PW;
+    }
     f32x4 rx[XI], rd[2];
-    unsigned xok = 0;
-    auto load_row = [&](int r) {                                 // input row r of the current strip (zeros outside the image)
-        const unsigned ur = (unsigned)r;
-        const unsigned okr = ((ur - (unsigned)H) >> 31) & (~ur >> 31);
+    unsigned xok = 0, dok = 0;
+    auto load_rows = [&](int first) {                            // input rows first .. first + CH - 1 of the strip (zeros outside the image)
         xok = 0;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const int pp = (tid + 256 * i) >> 4;
-            const unsigned uw = (unsigned)(w0 - 1 + pp);
-            const unsigned ok = okr & ((uw - (unsigned)W) >> 31) & (~uw >> 31) & ((unsigned)(pp - PW) >> 31);
+            const unsigned ur = (unsigned)(first + xpr[i]), uw = (unsigned)(w0 - 1 + xpc[i]);
+            const unsigned ok = ((ur - (unsigned)H) >> 31) & (~ur >> 31) & ((uw - (unsigned)W) >> 31) & (~uw >> 31) &
+                                ((unsigned)(xpr[i] - CH) >> 31);
             xok |= ok << i;
             const unsigned pix = (ur * (unsigned)W + uw) & (0u - ok);
             rx[i] = *reinterpret_cast<const f32x4*>(xi + (pix * (unsigned)Cin + (unsigned)ca) * 4u);
         }
     };
-    auto store_row = [&](int r) {                                // -> ring slot r & 3
-        float* dst = Xr + ((r + 4) & 3) * ROWF;
+    auto store_rows = [&](int slot_first) {                      // -> ring slots slot_first .. (mod R)
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const int pp = (tid + 256 * i) >> 4;
             f32x4 v = apply_prologue(rx[i], PRO, rs, rt);
             if (!((xok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            float* d = pp < PW ? dst + pp * 64 + c4 : Xr + R * ROWF + c4;
+            int sl = slot_first + xpr[i];
+            sl = sl >= R ? sl - R : sl;
+            float* d = xpr[i] < CH ? Xr + sl * ROWF + xpc[i] * 64 + c4 : Xr + R * ROWF + c4;
             *reinterpret_cast<f32x4*>(d) = v;
         }
     };
-    auto load_dy = [&](int r) {                                  // dy row r (always inside the image), columns w0 .. w0 + 31
+    auto load_dy = [&](int first) {                              // dy rows first .. first + CH - 1, columns w0 .. w0 + CW - 1
+        dok = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = (tid + 256 * i) >> 4;
-            rd[i] = *reinterpret_cast<const f32x4*>(di + (((unsigned)r * (unsigned)W + (unsigned)(w0 + k)) * (unsigned)Cout + (unsigned)cb) * 4u);
+            const unsigned ur = (unsigned)(first + k / CW), uw = (unsigned)(w0 + k % CW);
+            const unsigned ok = (ur - (unsigned)H) >> 31;
+            dok |= ok << i;
+            const unsigned pix = (ur * (unsigned)W + uw) & (0u - ok);
+            rd[i] = *reinterpret_cast<const f32x4*>(di + (pix * (unsigned)Cout + (unsigned)cb) * 4u);
         }
     };
     auto store_dy = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = (tid + 256 * i) >> 4;
-            *reinterpret_cast<f32x4*>(Ys + buf * 2048 + k * 64 + c4) = rd[i];
+            f32x4 v = rd[i];
+            if (!((dok >> i) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(Ys + buf * 2048 + k * 64 + c4) = v;
         }
     };
-    // rows h - 1, h, h + 1 and dy(h) of a strip's first chunk in this workgroup, synchronously (once per strip)
+    auto wrap = [](int sl) { return sl >= R ? sl - R : sl; };
+    // rows h0 - 1 .. h0 + CH (and up to CH - 2 rows beyond) and dy of a strip's first chunk in this workgroup, synchronously
     auto prime = [&](int buf) {
+        int sl = s0;
 #pragma unroll
-        for (int d = -1; d <= 1; ++d) { load_row(h + d); store_row(h + d); }
-        load_dy(h);
+        for (int g = 0; g < NPRIME; ++g) {
+            load_rows(h0 - 1 + g * CH);
+            store_rows(sl);
+            sl = wrap(sl + CH);
+        }
+        load_dy(h0);
         store_dy(buf);
     };
 
@@ -1123,51 +1147,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_rowring_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    bool have_next_regs = false;                                 // rx / rd hold row h + 2 / dy(h + 1) of the current strip
+    bool have_next_regs = false;                                 // rx / rd hold the next chunk's new rows / dy tile
     if (cbeg < cend) {
         prime(0);
-        if (cbeg + 1 < cend && h + 1 < H) { load_row(h + 2); load_dy(h + 1); have_next_regs = true; }
+        if (cbeg + 1 < cend && h0 + CH < H) { load_rows(h0 + CH + 1); load_dy(h0 + CH); have_next_regs = true; }
     }
     __syncthreads();
     for (int c = cbeg; c < cend; ++c) {
         const int buf = (c - cbeg) & 1;
-        const bool next = c + 1 < cend, next_same = next && h + 1 < H;
+        const bool next = c + 1 < cend, next_same = next && h0 + CH < H;
         __builtin_amdgcn_sched_barrier(0);
-        const float* a0 = Xr + ((h + 3) & 3) * ROWF + kl * 64 + wci + ml;        // row h - 1
-        const float* a1 = Xr + (h & 3) * ROWF + kl * 64 + wci + ml;              // row h
-        const float* a2 = Xr + ((h + 1) & 3) * ROWF + kl * 64 + wci + ml;        // row h + 1
+        const float* ar[CH + 2];                                 // rows h0 - 1 .. h0 + CH
+#pragma unroll
+        for (int j = 0; j < CH + 2; ++j) {
+            int sl = s0 + j;
+            sl = sl >= R ? sl - R : sl;
+            ar[j] = Xr + sl * ROWF + kl * 64 + wci + ml;
+        }
         const float* b = Ys + buf * 2048 + kl * 64 + wco + ml;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            if (ks == 8) {                                 // the next chunk's new row and dy tile (requested a chunk ago) -> LDS
+            if (ks == 8) {                                 // the next chunk's new rows and dy tile (requested a chunk ago) -> LDS
                 __builtin_amdgcn_sched_barrier(0);
                 if (next_same && have_next_regs) {
-                    store_row(h + 2);
+                    store_rows(wrap(wrap(s0 + CH) + 2));   // slots of rows h0 + CH + 1 ..
                     store_dy(buf ^ 1);
                     have_next_regs = false;
-                    if (c + 2 < cend && h + 2 < H) { load_row(h + 3); load_dy(h + 2); have_next_regs = true; }
+                    if (c + 2 < cend && h0 + 2 * CH < H) { load_rows(h0 + 2 * CH + 1); load_dy(h0 + 2 * CH); have_next_regs = true; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            const int pr = (2 * ks) / CW, pc = (2 * ks) % CW;   // pixel pair (2 ks, 2 ks + 1) of the chunk rectangle
             const float bf = b[(2 * ks) * 64];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const float* ar = t < 3 ? a0 : (t < 6 ? a1 : a2);
-                const float af = ar[(2 * ks + t % 3) * 64];
+                const float af = ar[pr + t / 3][(pc + t % 3) * 64];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // the next chunk is complete in LDS; every wave is done reading this one
         // advance to the next chunk
-        ++h;
-        if (h == H) {
-            h = 0; w0 += CW;
+        h0 += CH;
+        s0 = wrap(s0 + CH);
+        if (h0 >= H) {
+            h0 = 0; s0 = R - 1; w0 += CW;
             if (w0 >= TW) { w0 = 0; ++img; xi += img_x; di += img_d; }
             if (next) {                                    // new strip: rebuild the ring
                 prime(buf ^ 1);
                 have_next_regs = false;
-                if (c + 2 < cend && h + 1 < H) { load_row(h + 2); load_dy(h + 1); have_next_regs = true; }
+                if (c + 2 < cend && h0 + CH < H) { load_rows(h0 + CH + 1); load_dy(h0 + CH); have_next_regs = true; }
                 __syncthreads();
             }
         }
@@ -2008,25 +2037,32 @@ extern "C" size_t tag_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int C
     return (size_t)wgrad_splits(M, Cin, Cout, TC) * 9 * Cin * Cout * sizeof(float);
 }
 
+// narrowest image width that takes the row-ring kernel.  Measured over the layer shapes: W = 32 / 64 gain 4-5 % (one new row of 34
+// pixels instead of a 3 x 34 patch per chunk), W = 16 0.6 %, W = 8 LOSES 1.5 % (4 new rows of 10 pixels against a 6 x 10 patch:
+// the ring's per-item slot arithmetic costs more than the 20 pixels it saves)
+#ifndef TAG_WGRAD_RING_MINW
+#define TAG_WGRAD_RING_MINW 16
+#endif
 template <int TW>
 static void launch_wgrad_alltaps(const float* x, int pro, const float* s, const float* t, const float* dy, float* partial,
                                  int B, int H, int W, int Cin, int Cout, int splits, int cps, hipStream_t st) {
     using G = WgGeom<TW>;
     const int grid = ((Cin + 63) / 64) * ((Cout + 63) / 64) * splits;
-    constexpr bool RING = TW >= 32;                                        // row-ring kernel for the wide images
-    const size_t lds = RING ? (size_t)(4 * 34 * 64 + 64 + 2 * 32 * 64) * sizeof(float)
+    constexpr bool RING = TW >= TAG_WGRAD_RING_MINW;                       // row-ring kernel; the full-patch form below that width
+    constexpr int RCW = TW >= 32 ? 32 : TW, RCH = 32 / RCW;
+    const size_t lds = RING ? (size_t)((2 * RCH + 2) * (RCW + 2) * 64 + 64 + 2 * 32 * 64) * sizeof(float)
                             : (size_t)2 * ((G::PP + 1) * 64 + 32 * 64) * sizeof(float);
 #define LAUNCH_PRO(P)                                                                                               \
     {                                                                                                               \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            if (RING) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_rowring_kernel<(RING ? TW : 32), P>), \
+            if (RING) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_rowring_kernel<TW, P>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_alltaps_kernel<TW, P>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        if (RING) hipLaunchKernelGGL((conv3x3_wgrad_rowring_kernel<(RING ? TW : 32), P>), dim3(grid), dim3(256), lds, st, x, s, t, \
+        if (RING) hipLaunchKernelGGL((conv3x3_wgrad_rowring_kernel<TW, P>), dim3(grid), dim3(256), lds, st, x, s, t, \
                            dy, partial, B, H, W, Cin, Cout, splits, cps);                                           \
         else hipLaunchKernelGGL((conv3x3_wgrad_alltaps_kernel<TW, P>), dim3(grid), dim3(256), lds, st, x, s, t, dy, partial, \
                            B, H, W, Cin, Cout, splits, cps);                                                        \

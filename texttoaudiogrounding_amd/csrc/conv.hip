@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 
 // ------------------------------------------------------------------------------------------
 // Halo-tile forward / dgrad kernel (images whose width is 8, 16, 32 or 64 -- every Cnn8Rnn / CrnnEncoder layer).
-// The 128 output pixels of a workgroup form a TH x TW rectangle of ONE image; for each 32-channel chunk the
+// The 128 output pixels of a workgroup form a TH x TW rectangle of ONE image (TW = W, or W / 2 for the 64-wide images); for each 32-channel chunk the
 // (TH+2) x (TW+2) input patch is staged ONCE in LDS (BN+ReLU prologue and zero padding applied there) and all 9 taps
 // read it at a shifted base -- 4-7x fewer global loads and LDS stores than the tap-by-tap kernel above, no per-tap masks.
 //
@@ -263,8 +263,14 @@ __global__ __launch_bounds__(256, TAG_NBUF == 2 ? 2 : 3) void conv3x3_fwd_kernel
 //    the middle of the current half's MFMA stream, one barrier ends each half.  Same LDS and barrier count as the single
 //    buffer (free / full) it replaces, but no store phase between two barriers in which the wave issues no MFMA
 //    (127.7 -> 131.1 TFLOP/s forward, 131.2 -> 133.8 dgrad over the layer shapes at B = 64).
-//  * measured and dropped on the way: weight operands straight from L2 into registers (no LDS buffer, no per-tap barrier):
-//    121 TFLOP/s; a second full-tap buffer for the 64-cout tiles: 2.59 -> 2.61 ms.
+//  * scalar instructions (and dword stores) of a wave WITHOUT an MFMA stream of its own wait for the co-resident waves' fp32 MFMA
+//    streams to pause (a new workgroup's set-up took 1.5 us on an idle chip, 9 us beside running ones: tools/halo_wg_timeline.py):
+//    loop state is carried incrementally, the set-up uses host-made multiply-shift pairs and sign-bit validity arithmetic, the
+//    output leaves as 16-byte stores after a 4 x 4 DPP transpose inside each lane quad.
+//  * 64-wide images run as TWO tile columns of 4 x 32 pixels (204- instead of 264-pixel patch: four 64-cout workgroups per CU).
+//  * measured and dropped on the way: weight operands straight from L2 into registers, whole-tap weight
+//    stages at 2 workgroups per CU, 16-channel chunks with a double-buffered patch, a cout-major weight image read with
+//    ds_read_b128, several tiles per workgroup (two forms), 256-pixel tiles for the 64-channel layers.
 // ------------------------------------------------------------------------------------------
 // -DTAG_HALO_PROF (tools/run_halo_prof.sh, never in the product build): s_memtime deltas of the phases of ONE workgroup's wave 0
 #ifdef TAG_HALO_PROF

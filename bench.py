@@ -106,7 +106,7 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
     """`roofline` object of the dominant MFMA kernel family of a timed leg: achieved = sum of the algorithmic FLOP of its
     launches / sum of their HIP-event durations (events on the launch stream).  mode = "fp32" | "bf16" selects the committed PMC
     traffic profile (profiles/r*_pmc_hbm_traffic_<mode>.json); the profile is only quoted when it was collected on the kernel
-    sources this library was built from (csrc sha256)."""
+    sources the loaded libtag_hip.so attests it was built from (tag_build_id = sha256 of csrc/ at compile time)."""
     if not fam:
         return None
     dom = max(fam, key=lambda k: fam[k]["flop"])
@@ -116,7 +116,7 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
     # figure is read from the committed profile of the SAME command (tools/collect_profiles.sh: two separate --pmc passes,
     # FETCH_SIZE x2 + WRITE_SIZE) and labelled with where and when it was collected -- it is offline data.
     traffic, traffic_src = None, None
-    from texttoaudiogrounding_amd.lib import csrc_sha256
+    from texttoaudiogrounding_amd.lib import build_id as csrc_sha256   # the id the LOADED BINARY attests (tag_build_id), not a hash of the checkout
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{mode}.json")), reverse=True)
     if not cands or conv_math not in ("fp32", "bf16"):
         traffic_src = {"reason": "no PMC traffic profile for this arithmetic under profiles/"}
@@ -156,6 +156,20 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
             "isolated_avg_launch_ms": round(fam_iso[dom]["ms"] / fam_iso[dom]["launches"], 4),
             "families_isolated": {k: {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
                                       "ms_per_step": round(v["ms"] / steps, 3)} for k, v in fam_iso.items()}}
+
+
+def run_steps(runner, batch, k, sync):
+    """k training steps; returns (wall seconds incl. the closing sync, host seconds spent INSIDE train_step = the time one core
+    needs to enqueue a step: ctypes launches + autograd bookkeeping, no synchronisation), and the last loss."""
+    host = 0.0
+    loss = None
+    t0 = time.perf_counter()
+    for _ in range(k):
+        th = time.perf_counter()
+        loss = runner.train_step(dict(batch))
+        host += time.perf_counter() - th
+    sync()
+    return time.perf_counter() - t0, host, loss
 
 
 def build_workload(name, device):
@@ -205,16 +219,15 @@ def other_workloads(args, device, log, budget_s=5.0):
         torch.cuda.synchronize()
         one = time.perf_counter() - t0
         k = max(3, min(args.steps, int(budget_s / 2 / max(one, 1e-4))))
-        dt = None
-        for _ in range(2):                    # two timed blocks of k steps, the faster one is reported (the first block after a model
-            t0 = time.perf_counter()          # switch has been seen 3x slow once: allocator / clock state, not the workload)
-            for _ in range(k):
-                loss = runner.train_step(dict(batch))
-            torch.cuda.synchronize()
-            d_ = time.perf_counter() - t0
-            dt = d_ if dt is None else min(dt, d_)
+        blocks = []
+        for _ in range(2):                    # two timed blocks of k steps; BOTH are reported, `value` is the faster one (the first
+            d_, h_, loss = run_steps(runner, batch, k, torch.cuda.synchronize)   # block after a model switch has been seen 3x slow once:
+            blocks.append((d_, h_))           # allocator / clock state, not the workload) and the estimator is named in the record
+        dt, host = min(blocks)
         res[name] = {"workload": WORKLOAD_TEXT[name], "value": round(args.batch * k / dt, 2), "unit": "clips/s",
-                     "ms_per_step": round(dt / k * 1e3, 3), "steps": k, "dtype": "f32", "loss": round(runner.loss_value(loss), 6)}
+                     "ms_per_step": round(dt / k * 1e3, 3), "steps": k, "dtype": "f32", "loss": round(runner.loss_value(loss), 6),
+                     "estimator": "min_of_2_blocks", "blocks_ms_per_step": [round(b[0] / k * 1e3, 3) for b in blocks],
+                     "host_enqueue_ms_per_step": round(host / k * 1e3, 3)}
         log(f"other workload {name}: {res[name]['value']} clips/s")
         del runner
         torch.cuda.empty_cache()
@@ -232,9 +245,12 @@ def other_workloads(args, device, log, budget_s=5.0):
     model(audio, audio_len, text)
     torch.cuda.synchronize()
     k = 3
+    host = 0.0
     t0 = time.perf_counter()
     for _ in range(k):
+        th = time.perf_counter()
         fs = model(audio, audio_len, text)
+        host += time.perf_counter() - th
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()
@@ -244,6 +260,7 @@ def other_workloads(args, device, log, budget_s=5.0):
     dtt = time.perf_counter() - t1
     res["infer_30s_b256"] = {"workload": WORKLOAD_TEXT["infer_30s_b256"], "value": round(B * k / dt, 2), "unit": "clips/s",
                              "ms_per_step": round(dt / k * 1e3, 2), "steps": k, "dtype": "f32", "frame_sim_shape": list(fs.shape),
+                             "estimator": "one_block_after_one_warm_up_pass", "host_enqueue_ms_per_step": round(host / k * 1e3, 3),
                              # forward of a 30 s clip = 3 x 33.90 GFLOP (T' = 750) -- numerically FLOP_PER_CLIP
                              "whole_forward_mfma_frac": round(B * k / dt * 3 * 33.90e9 / 1e12 / PEAK_FP32_MFMA, 4),
                              "text_tower_ms_per_batch": round(dtt / k * 1e3, 2)}
@@ -324,7 +341,7 @@ def main():
     import torch.distributed as dist
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match, text_encoder
-    from texttoaudiogrounding_amd.runner import StrongRunner, init_distributed
+    from texttoaudiogrounding_amd.runner import StrongRunner, barrier, comm_environment, init_distributed
 
     if args.dtype == "bf16":
         args.conv_math = "bf16"
@@ -344,7 +361,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            barrier(local)                     # names this rank's device to RCCL (no "device under current context" guess)
         torch.cuda.synchronize()
 
     def log(msg):
@@ -403,12 +420,12 @@ def main():
     ops.PROFILE = {}
     if runner.buckets is not None:
         runner.buckets.record = True          # per-bucket events on the communication stream + the exposed wait
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = runner.train_step(dict(batch))
-    sync()
-    dt = time.perf_counter() - t0
-    log(f"timed {args.steps} steps in {dt:.3f} s")
+    from texttoaudiogrounding_amd.utils.telemetry import BoardSampler, mfma_probe
+    sampler = BoardSampler(local)              # hwmon power + shader clock every 25 ms while a leg runs (a sysfs read: no GPU work)
+    sampler.start()
+    dt, host_s, loss = run_steps(runner, batch, args.steps, sync)
+    board = sampler.stop()
+    log(f"timed {args.steps} steps in {dt:.3f} s (host enqueue {host_s / args.steps * 1e3:.2f} ms/step)")
     prof, ops.PROFILE = ops.PROFILE, None
     comm_timing = None
     if runner.buckets is not None:
@@ -454,18 +471,17 @@ def main():
             runner.train_step(dict(batch))
             sync()
             ops.PROFILE = {} if mode == "bf16" else None          # the bf16 mode gets its own roofline (events as in the main leg)
-            ta = time.perf_counter()
-            for _ in range(args.steps):
-                runner.train_step(dict(batch))
-            sync()
-            dta = time.perf_counter() - ta
+            sampler.start()
+            dta, host_a, _ = run_steps(runner, batch, args.steps, sync)
+            board_a = sampler.stop()
             prof_a, ops.PROFILE = ops.PROFILE, None
             if world > 1:
                 t = torch.tensor([dta], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dta = t.item()
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
-                         "ms_per_step": round(dta / args.steps * 1e3, 3)}
+                         "ms_per_step": round(dta / args.steps * 1e3, 3),
+                         "host_enqueue_ms_per_step": round(host_a / args.steps * 1e3, 3), "board": board_a}
             alt[mode]["wgrad_side_stream"] = bool(ops.side_stream_enabled())
             if mode == "bf16":
                 fam_a = fam_a_iso = families(prof_a)
@@ -480,10 +496,22 @@ def main():
                     ops.WGRAD_SIDE_STREAM = side_setting
                 alt[mode]["whole_step_mfma_frac"] = round(clips / dta / world * FLOP_PER_CLIP / 1e12 / 2500.0, 4)
                 alt[mode]["roofline"] = roofline_of(fam_a, fam_a_iso, args.steps, "bf16", "bf16", args.batch, overlap_a)
+                if alt[mode]["roofline"] is not None:
+                    # what the bf16 matrix pipe sustains on THIS box right now with operands that toggle like a kernel's (the
+                    # part's power limit) and with constant operands (datasheet conditions), ~50 ms each
+                    alt[mode]["roofline"]["measured_ceiling"] = {"random_operands": mfma_probe("bf16_random", 50.0, local),
+                                                                 "constant_operands": mfma_probe("bf16_constant", 50.0, local)}
+                    mc = alt[mode]["roofline"]["measured_ceiling"]["random_operands"]["TFLOP/s"]
+                    alt[mode]["roofline"]["isolated_frac_of_measured_ceiling"] = round(
+                        alt[mode]["roofline"]["isolated_achieved"] / mc, 4) if mc else None
         ops.CONV_MATH = "fp32"
         ops.ACT_DTYPE = "fp32"
     loss_value = round(runner.loss_value(loss), 6)
     roof = roofline_of(fam, fam_iso, args.steps, "bf16" if args.dtype == "bf16" else "fp32", args.conv_math, args.batch, overlap)
+    if roof is not None and rank == 0:
+        kind = "bf16" if args.conv_math in ("bf16", "x3", "x9") else "f32"
+        roof["measured_ceiling"] = {"random_operands": mfma_probe(f"{kind}_random", 50.0, local),
+                                    "constant_operands": mfma_probe(f"{kind}_constant", 50.0, local)}
     others = None
     main_wl = not (args.crnn or args.cross_attention or args.cross_encoder)
     if world == 1 and main_wl and args.conv_math == "fp32" and not args.no_others:
@@ -494,7 +522,11 @@ def main():
     if rank == 0:
         out = {"metric": "clips/sec (10 s@32 kHz, 1-phrase) fwd+bwd", "value": round(value, 2), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 3),
+               # wall time one host core spends inside train_step per step (launch enqueue through ctypes + autograd bookkeeping,
+               # no synchronisation): must stay below ms_per_step or the GPU starves
+               "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": ("bf16 (conv arithmetic + activation storage; f32 accumulate, statistics, GRU, heads, master weights, "
                          f"{args.grad_wire} all-reduce payload)" if args.dtype == "bf16" else
@@ -507,7 +539,9 @@ def main():
                "loss": loss_value,
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /
                                              (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4),
-               "roofline": roof}
+               "roofline": roof,
+               # socket power and shader clock sampled (hwmon, every 25 ms) while the timed region ran
+               "board": board}
         if alt:
             out["alt_conv_math"] = alt
         if others:
@@ -518,6 +552,7 @@ def main():
             out["comm"] = {"collective": "all-reduce(sum) of the flat fp32 gradient in buckets, launched from inside backward",
                            "buckets_MB": [round((e - s0) * 4 / 2 ** 20, 2) for (s0, e, _, _) in runner.buckets.bounds],
                            "overlap": runner.overlap_comm,
+                           "environment": comm_environment(),
                            "payload": args.grad_wire,
                            # rank 0's events over the timed region: each bucket's all-reduce start->end on the communication
                            # stream (includes waiting for slower ranks to arrive) and the time the compute stream spent blocked

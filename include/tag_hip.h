@@ -33,7 +33,17 @@ extern "C" {
 #define TAG_ELAUNCH (-2)
 
 int tag_abi_version(void);
+/* sha256 (hex) over the kernel sources the library was compiled from, as lib.csrc_sha256() forms it: the BINARY attests its
+ * sources, so a stale libtag_hip.so beside edited sources is refused by lib.load() and a PMC profile is only quoted by
+ * bench.py for the binary that actually ran (the reference has no native code: nothing is replaced) */
+const char* tag_build_id(void);
 const char* tag_last_error(void);
+/* Measurement aid of bench.py (csrc/probe.hip; nothing of the reference is replaced): `workgroups` x 4 waves of register-resident
+ * MFMA work for `iters` iterations.  kind 0: bf16 32x32x16 on RANDOM operands (what a real kernel's toggling costs: the part's
+ * power limit), 1: bf16 constant operands (datasheet conditions), 2 / 3: the same for the exact-fp32 32x32x2.  clocks: 3 x u64,
+ * device; [0] shader clocks and [1] 100 MHz reference ticks workgroup 0 ran for.  tag_mfma_probe_flop: the FLOP of such a launch. */
+int tag_mfma_probe(int kind, int iters, int workgroups, unsigned seed, void* clocks, void* stream);
+double tag_mfma_probe_flop(int kind, int iters, int workgroups);
 /* number of CUs of the current device (used by the host to size split-K workspaces) */
 int tag_device_cu_count(void);
 

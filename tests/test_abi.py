@@ -34,6 +34,21 @@ def test_library_exports_every_declared_symbol():
     assert handle.tag_abi_version() == lib.ABI_VERSION == 2
 
 
+def test_binary_attests_its_sources(tmp_path):
+    """tag_build_id() = sha256 of csrc/ at compile time: equal to lib.csrc_sha256() for a current build, and lib.load() refuses a
+    library whose id differs from the checked-out sources (a stale .so beside edited kernels)."""
+    import sys
+    from texttoaudiogrounding_amd import lib
+    lib.load()
+    assert re.fullmatch(r"[0-9a-f]{64}", lib.build_id())
+    assert lib.build_id() == lib.csrc_sha256()
+    code = ("import texttoaudiogrounding_amd.lib as L\n"
+            "L.csrc_sha256 = lambda: '0' * 64\n"
+            "try:\n    L.load()\nexcept RuntimeError as e:\n    print('REFUSED' if 'other kernel sources' in str(e) else e)\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode()
+    assert "REFUSED" in out, out
+
+
 def test_code_object_is_gfx950_only():
     from texttoaudiogrounding_amd import lib
     blob = open(lib.LIB_PATH, "rb").read()

@@ -3,6 +3,7 @@ of StrongRunner in stream order with the HIP kernels (the N > 1 logic itself is 
 real multi-GPU runs are the driver's)."""
 import os
 import socket
+import warnings
 
 import pytest
 import torch
@@ -21,8 +22,22 @@ def test_rccl_allreduce_of_flat_gradients(dev):
     port = s.getsockname()[1]
     s.close()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        _rccl_step(dev, port)
+    # first-contact hygiene: the communicator is bound to the device at init time and the barrier names it -- torch must not
+    # have had to guess ("using the device under current context")
+    bad = [str(w.message) for w in caught if "device" in str(w.message).lower() and "barrier" in str(w.message).lower()]
+    assert not bad, bad
+
+
+def _rccl_step(dev, port):
+    from tests.test_gpu_path import build_hip_model
+    from texttoaudiogrounding_amd.runner import StrongRunner, barrier, comm_environment
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
+        env = comm_environment()
+        assert env["rccl_version"][0].isdigit(), env
         st = O.init_state(seed=1, logit_gain=40.0)
         batch = O.synthetic_batch(2, 32000, seed=3)
         model = build_hip_model(st, "dot", dev).train()
@@ -31,7 +46,7 @@ def test_rccl_allreduce_of_flat_gradients(dev):
         loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
         g0 = runner.flat.grad.clone()
         dist.all_reduce(runner.flat.grad)               # what forward_backward does when world > 1
-        dist.barrier()
+        barrier(dev.index or 0)
         torch.cuda.synchronize()
         assert torch.equal(runner.flat.grad, g0) and torch.isfinite(loss)
         runner.optimizer_step()
@@ -47,7 +62,8 @@ def _one_rank_group():
     port = s.getsockname()[1]
     s.close()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
 
 
 def test_rccl_buckets_in_flight_beside_cooperative_gru_backward(dev):

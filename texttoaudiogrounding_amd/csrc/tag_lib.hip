@@ -11,7 +11,12 @@ void tag_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+#ifndef TAG_CSRC_SHA256
+#define TAG_CSRC_SHA256 "unknown"
+#endif
 extern "C" int tag_abi_version(void) { return TAG_ABI_VERSION; }
+// sha256 of the kernel sources this binary was compiled from (csrc/Makefile); equals lib.csrc_sha256() for a current build
+extern "C" const char* tag_build_id(void) { return TAG_CSRC_SHA256; }
 extern "C" const char* tag_last_error(void) { return g_err; }
 extern "C" int tag_device_cu_count(void) {
     int dev = 0, n = 0;

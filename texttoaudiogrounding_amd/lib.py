@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
 
 import torch  # noqa: F401  (loads libamdhip64 first)
 
@@ -24,8 +24,11 @@ ABI_VERSION = 2
 P = c_void_p
 _SIGS = {
     "tag_abi_version": (c_int, []),
+    "tag_build_id": (c_char_p, []),
     "tag_last_error": (c_char_p, []),
     "tag_device_cu_count": (c_int, []),
+    "tag_mfma_probe": (c_int, [c_int, c_int, c_int, ctypes.c_uint, P, P]),
+    "tag_mfma_probe_flop": (c_double, [c_int, c_int, c_int]),
     "tag_stream_create_cu_mask": (c_int, [P, c_int, P]),
     "tag_logmel_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "tag_bn_stats_ws_bytes": (c_size_t, [c_long, c_int]),
@@ -171,8 +174,19 @@ def load():
     if lib.tag_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libtag_hip.so ABI version {lib.tag_abi_version()} != {ABI_VERSION} expected by lib.py: the "
                            "shared library is stale, rebuild it (make -C texttoaudiogrounding_amd/csrc)")
+    # the binary attests the sources it was compiled from: a stale .so beside edited kernels is refused (a private build named by
+    # TAG_HIP_LIB is compiled from the same sources with extra -D flags and passes; TAG_ALLOW_STALE_LIB=1 is the developer's override)
+    built = lib.tag_build_id().decode()
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and built != csrc_sha256() and os.environ.get("TAG_ALLOW_STALE_LIB") != "1":
+        raise RuntimeError(f"{LIB_PATH} was built from other kernel sources (build id {built[:12]} != csrc sha256 "
+                           f"{csrc_sha256()[:12]}): rebuild it (make -C texttoaudiogrounding_amd/csrc)")
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """sha256 of the kernel sources the LOADED binary was compiled from (tag_build_id)."""
+    return load().tag_build_id().decode()
 
 
 def declared_symbols():

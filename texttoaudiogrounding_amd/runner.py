@@ -336,5 +336,39 @@ def init_distributed(backend: Optional[str] = None):
         local = 0
     torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # device_id binds the communicator to THIS rank's GPU at init time (eager RCCL initialisation): without it the first
+        # collective / barrier picks "the device under current context" lazily -- the classic wrong-device hang of a first
+        # N > 1 run -- and torch warns about it on every barrier
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def barrier(local: Optional[int] = None):
+    """dist.barrier() naming the rank's device to RCCL (no lazy device guess); plain barrier on gloo / without a group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device() if local is None else local])
+    else:
+        dist.barrier()
+
+
+def comm_environment() -> Dict:
+    """What a scaling record needs to be read later (rank 0 calls it): RCCL version, the NCCL_* / RCCL_* / HSA_* settings in
+    force, and the GPU-to-GPU link types `rocm-smi --showtopo` reports (XGMI vs PCIE), when the tool is there."""
+    import subprocess
+    info: Dict = {"env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+    try:
+        info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:                                    # noqa: BLE001 - diagnostic only
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    try:
+        out = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20).stdout
+        rows = [ln.split() for ln in out.splitlines() if ln.startswith("GPU") and len(ln.split()) > 1]
+        kinds = sorted({c for r in rows for c in r[1:] if c.isalpha()})
+        info["link_types"] = kinds or None
+        info["gpus_in_topology"] = len(rows) or None
+    except Exception as e:                                    # noqa: BLE001
+        info["link_types"] = f"rocm-smi unavailable ({type(e).__name__})"
+    return info

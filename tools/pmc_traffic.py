@@ -45,7 +45,7 @@ print(f"per step: fetch {tf / steps / 1e9:.2f} GB, write {tw / steps / 1e9:.2f} 
 import datetime
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from texttoaudiogrounding_amd.lib import csrc_sha256          # the profile is only valid for THESE kernel sources
+from texttoaudiogrounding_amd.lib import build_id as csrc_sha256          # the profile is only valid for THESE kernel sources
 res["_meta"] = {"csrc_sha256": csrc_sha256(), "collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "steps_in_run": steps,
                 "fetch_GB_per_step": round(tf / steps / 1e9, 3), "write_GB_per_step": round(tw / steps / 1e9, 3),
                 "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, HBM section); "

@@ -274,13 +274,32 @@ def cnn8rnn_dropout_masks(seeds, B: int, n_frames: int, p_drop=(0.2, 0.5), dtype
     return masks
 
 
-def conv_block(x, st, prefix, pool_size, training, taps=None):
-    """ConvBlock.forward with pool_type='avg+max' (models/panns.py:46-62)."""
+def _imposed_max_pool(a, pool_size, index):
+    """max_pool2d (kernel = stride, floor) with the arg-max IMPOSED: index (B,C,Ho,Wo) = position dh * pw + dw inside the window."""
+    ph, pw = pool_size
+    B, C, H, W = a.shape
+    Ho, Wo = H // ph, W // pw
+    win = a[:, :, :Ho * ph, :Wo * pw].reshape(B, C, Ho, ph, Wo, pw).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Ho, Wo, ph * pw)
+    return torch.gather(win, 4, index.long().unsqueeze(-1)).squeeze(-1)
+
+
+def conv_block(x, st, prefix, pool_size, training, taps=None, decisions=None):
+    """ConvBlock.forward with pool_type='avg+max' (models/panns.py:46-62).
+
+    decisions (test aid, tests/test_gpu_path.py): the hard decisions of ANOTHER implementation imposed on this one -- keys
+    "relu/<prefix>bn1", "relu/<prefix>bn2" (0/1 masks, NCHW) and "argmax/<prefix>" (window position per pooled element).  Two
+    fp32 implementations whose BatchNorm outputs differ by round-off can take different sides of a ReLU / arg-max whose operands
+    are closer than that round-off; with the decisions imposed the remaining difference is round-off only."""
+    dec = decisions or {}
     y1 = F.conv2d(x, st[prefix + "conv1.weight"], None, 1, 1)
-    a1 = F.relu(_bn(y1, st, prefix + "bn1.", training))
+    b1 = _bn(y1, st, prefix + "bn1.", training)
+    a1 = b1 * dec["relu/" + prefix + "bn1"].to(b1.dtype) if "relu/" + prefix + "bn1" in dec else F.relu(b1)
     y2 = F.conv2d(a1, st[prefix + "conv2.weight"], None, 1, 1)
-    a2 = F.relu(_bn(y2, st, prefix + "bn2.", training))
-    out = F.avg_pool2d(a2, kernel_size=pool_size) + F.max_pool2d(a2, kernel_size=pool_size)
+    b2 = _bn(y2, st, prefix + "bn2.", training)
+    a2 = b2 * dec["relu/" + prefix + "bn2"].to(b2.dtype) if "relu/" + prefix + "bn2" in dec else F.relu(b2)
+    mx = (_imposed_max_pool(a2, pool_size, dec["argmax/" + prefix]) if "argmax/" + prefix in dec
+          else F.max_pool2d(a2, kernel_size=pool_size))
+    out = F.avg_pool2d(a2, kernel_size=pool_size) + mx
     if taps is not None:
         taps[prefix + "conv1"] = y1
         taps[prefix + "conv2"] = y2
@@ -308,12 +327,13 @@ def cnn8rnn_forward(st, waveform, waveform_len, training=False, p_drop=(0.2, 0.5
         taps["bn0"] = x
     pools = [(2, 2), (2, 2), (1, 2), (1, 2)]
     for i, ps in enumerate(pools, start=1):
-        x = conv_block(x, st, f"{prefix}conv_block{i}.", ps, training, taps)
+        x = conv_block(x, st, f"{prefix}conv_block{i}.", ps, training, taps, decisions=masks)
         x = _dropout(x, p_drop[0], training, masks, f"drop{i}")
     x = torch.mean(x, dim=3)                          # (B, 512, T')
     x = x.transpose(1, 2)
     x = _dropout(x, p_drop[1], training, masks, "drop5")
-    x = F.relu(F.linear(x, st[prefix + "fc1.weight"], st[prefix + "fc1.bias"]))
+    x = F.linear(x, st[prefix + "fc1.weight"], st[prefix + "fc1.bias"])
+    x = x * masks["relu/" + prefix + "fc1"].to(x.dtype) if masks is not None and "relu/" + prefix + "fc1" in masks else F.relu(x)
     if taps is not None:
         taps["fc1"] = x
     x = gru_bidir(x, st, prefix + "rnn.")

@@ -70,3 +70,26 @@ def test_two_claims_fall_back_to_accumulate(flat_w):
     x = torch.arange(4.0).view(1, 4)
     (_Scale.apply(x, w).sum() + _Scale.apply(2 * x, w).sum()).backward()      # hook fires legitimately: claims == 2
     assert torch.equal(fp.grad, 3 * torch.arange(4.0))
+
+
+def test_claimed_but_unused_node_plus_plain_consumer_has_one_writer(flat_w):
+    """the guard decides on what HAPPENED in the step.  A parameter claimed by a HIP node whose output never takes part
+    in this backward (a metric-only forward under grad mode) and also used by a plain torch op has ONE writer -- autograd --
+    and must train normally instead of raising."""
+    w, fp = flat_w
+    x = torch.arange(4.0).view(1, 4)
+    _ = _Scale.apply(x, w)                                   # claimed (claims == 1), never backpropagated
+    (0.5 * (w * w).sum()).backward()
+    assert ops._CLAIMS[id(w)] == 1
+    assert torch.equal(fp.grad, w.detach().reshape(-1))      # d/dw 0.5 w^2 = w, accumulated by AccumulateGrad into the flat view
+
+
+def test_second_writer_is_caught_in_either_order(flat_w):
+    """Autograd may run the plain consumer's gradient before OR after the node's in-place delivery: both orders raise."""
+    w, fp = flat_w
+    x = torch.arange(4.0).view(1, 4)
+    for build in (lambda: _Scale.apply(x, w).sum() + 0.5 * (w * w).sum(), lambda: 0.5 * (w * w).sum() + _Scale.apply(x, w).sum()):
+        ops.begin_direct_step()
+        fp.zero_grad()
+        with pytest.raises(RuntimeError, match="also received a gradient through plain autograd"):
+            build().backward()

@@ -180,3 +180,40 @@ def test_grounding_model_30s_full_pass_b67(dev):
             mism += int(not np.array_equal(got[j][ti], O.segments(ref[j].numpy(), tt, 1, 13)))
     print(f"segments vs the oracle's own scores: {mism} of {3 * len(th)} (clip, threshold) pairs differ")
     assert mism == 0
+
+
+def test_hf_surface_round_trip_and_string_prompts(dev, tmp_path):
+    """The reference's entry point as the README uses it (models/hf_modeling_grounding.py:305-352; README.md:7-39): the model is
+    saved with save_pretrained, loaded back with from_pretrained (and through AutoModel), and called with STRINGS -- tokenised by
+    a tokenizer that resolves locally (a tiny word-level one built in the test: there is no network for the CLAP tokenizer).
+    frame_sim is bit-identical across the round trip, and the string call equals the call with the tokenizer's output."""
+    transformers = pytest.importorskip("transformers")
+    from tests.test_hf_surface import TINY, tiny_tokenizer_dir
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import (Cnn8RnnLaionClapGroundingConfig,
+                                                                      Cnn8RnnLaionClapGroundingModel)
+    tok_dir = tiny_tokenizer_dir(str(tmp_path / "tok"))
+    torch.manual_seed(12)
+    cfg = Cnn8RnnLaionClapGroundingConfig(text_encoder_name=tok_dir, text_config=TINY)
+    model = Cnn8RnnLaionClapGroundingModel(cfg)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.uniform_(-0.2, 0.2)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    wave = 0.1 * torch.randn(3, 64000, generator=g)
+    lens = [64000, 50000, 33333]
+    text = ["a man speaks", "the dog is barking loudly", "rain falls on the roof"]
+    fs = model(audio=wave, audio_len=lens, text=text)                      # the README's call
+    assert fs.shape == (3, 50) and torch.isfinite(fs).all()
+    tokens = model.text_tokenizer(text, padding=True, return_tensors="pt", truncation=True)
+    assert torch.equal(fs, model(wave, lens, tokens))
+    model.save_pretrained(tmp_path / "ckpt")
+    for loader in (Cnn8RnnLaionClapGroundingModel, transformers.AutoModel):
+        back = loader.from_pretrained(tmp_path / "ckpt").to(dev).eval()
+        assert back.text_tokenizer is not None
+        assert torch.equal(back(audio=wave, audio_len=lens, text=text), fs)
+    model.text_tokenizer = None
+    with pytest.raises(RuntimeError, match="no tokenizer"):
+        model(wave, lens, text)

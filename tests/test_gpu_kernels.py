@@ -292,6 +292,27 @@ def test_conv3x3_bf16_storage(ops, dev, B, H, W, Cin, Cout, pro):
     """configs[2] storage: bf16 tensors in, bf16 tensors out, fp32 accumulate.  Forward (with / without the producer's
     BN+ReLU folded into the operand load), dgrad and wgrad equal the fp64 convolution of the SAME bf16 operands up to one
     bf16 rounding of the result (forward / dgrad outputs are bf16) or fp32 round-off (wgrad output is fp32)."""
+    _bf16_storage_case(ops, dev, B, H, W, Cin, Cout, pro)
+
+
+@pytest.mark.parametrize("rows,dma", [(0, 1), (1, 0), (1, 2), (0, 0)])
+@pytest.mark.parametrize("pro", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 1001, 64, 64, 64), (2, 64, 32, 64, 128), (2, 90, 16, 128, 128), (1, 19, 8, 256, 256)])
+def test_conv3x3_bf16_storage_switchable_paths(ops, dev, B, H, W, Cin, Cout, pro, rows, dma):
+    """The switchable code paths behind the bf16 entry points hold the SAME bounds as the defaults (round-4 advice: they had no
+    test): tag_conv_rows_enable(0) = the tile-kernel fallback for the 64-channel shapes (unreached by default since conv_rows.hip),
+    tag_wgrad_dma_enable(0) = the register-staged weight gradient everywhere, (2) = the DMA weight gradient with the producer's
+    BatchNorm+ReLU applied in place in LDS (prologue-1 layers; off by default because it measures 3-5 % slower)."""
+    from texttoaudiogrounding_amd.lib import query
+    was_rows, was_dma = query("tag_conv_rows_enable", rows), query("tag_wgrad_dma_enable", dma)
+    try:
+        _bf16_storage_case(ops, dev, B, H, W, Cin, Cout, pro)
+    finally:
+        query("tag_conv_rows_enable", was_rows)
+        query("tag_wgrad_dma_enable", was_dma)
+
+
+def _bf16_storage_case(ops, dev, B, H, W, Cin, Cout, pro):
     g = torch.Generator().manual_seed(H + W + pro)
     x = bf(torch.randn(B, Cin, H, W, generator=g))
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)

@@ -107,6 +107,42 @@ def test_golden_eval(dev, golden_dir, conv_math):
     assert logit_err < 2e-3        # logits span +-3.3
 
 
+def test_golden_eval_at_the_benched_clip_length(dev, golden_dir, conv_math):
+    """The HIP path against the IMPORTED REFERENCE at 10 s clips (tests/golden/make_golden_10s.py: B = 2, second clip ragged, eval
+    mode): the frame chain F = 1001 -> 500 -> 250 (models/audio_encoder.py:202-227) pinned to the reference itself.  frame_sim
+    within the north_star tolerance of the reference's fp64 twin, `length` exact, and the reference's OWN segment lists
+    (utils/eval_util.py functions on its fp32 scores, 50 thresholds, n_connect 13) reproduced bit-exactly by tag_segments at
+    every threshold that no score sits on (margin > 2 x (this path's error + the reference's own fp32 error); >= 98 of 100)."""
+    from tests.test_oracle_golden import gold_10s_inputs, gold_10s_segments
+    from texttoaudiogrounding_amd.utils import eval_util
+    gold = np.load(f"{golden_dir}/cnn8rnn_dot_eval_10s.npz")
+    st, batch = gold_10s_inputs(gold)
+    model = build_hip_model(st, "dot", dev).eval()
+    with torch.no_grad():
+        emb = model.audio_encoder({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"],
+                                   "specaug": False})
+        out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"],
+                     "text": batch["text"], "text_len": batch["text_len"], "specaug": False})
+    assert np.array_equal(out["length"].numpy(), gold["length"]) and out["frame_sim"].shape == (2, 250)
+    e_err = (emb["embedding"].cpu()[:, ::5] - torch.from_numpy(gold["embedding_f64_as_f32_every5"])).abs().max().item()
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    ref32_err = np.abs(gold["frame_sim_f32"].astype(np.float64) - gold["frame_sim_f64"]).max()
+    assert e_err < 1e-4 and fs_err < 1e-4
+    th = eval_util.eval_thresholds(50)
+    assert np.allclose(th, gold["thresholds"])
+    got = eval_util.segments_for_thresholds(out["frame_sim"], th, 1, eval_util.n_connect_for(0.04))
+    checked = 0
+    for b in range(2):
+        for ti in range(len(th)):
+            if gold["margin"][b, ti] <= 2 * (fs_err + ref32_err):
+                continue
+            assert np.array_equal(got[b][ti], gold_10s_segments(gold, b, ti)), (b, ti)
+            checked += 1
+    print(f"10 s reference fixture: embedding err {e_err:.2e}, frame_sim err {fs_err:.2e} (reference fp32: {ref32_err:.2e}); "
+          f"{checked} of 100 (clip, threshold) segment lists checked, all identical to the reference's")
+    assert checked >= 98
+
+
 def test_golden_eval_bf16_conv_math(dev, golden_dir):
     """BASELINE configs[2] arithmetic for the convolutions (operands rounded to bf16, fp32 accumulate, everything else
     fp32): the frame probabilities stay within bf16 tolerance of the fp64 golden values."""
@@ -163,23 +199,81 @@ def test_golden_train_step_grads(dev, golden_dir, conv_math):
             assert np.allclose(sd[name].cpu().numpy(), gold[k], rtol=2e-4, atol=1e-5), name
 
 
-def test_proj_expnegl2_dropout_replay_vs_oracle(dev):
-    """Cnn8Rnn(512)+EmbeddingAgg(256)+audio/text proj+ExpNegL2, train mode WITH dropout: the HIP path's
-    keep-masks are exported (tag_dropout_mask) and replayed in the oracle."""
+def _window_first_argmax(r, ph, pw):
+    """r (B,C,H,W) -> (B,C,Ho,Wo) position dh * pw + dw of the FIRST maximum of each pooling window (scan order h then w: ATen's
+    max_pool2d and bn_pool.hip pick that one; torch.argmax documents first-index tie breaking)."""
+    B, C, H, W = r.shape
+    Ho, Wo = H // ph, W // pw
+    win = r[:, :, :Ho * ph, :Wo * pw].reshape(B, C, Ho, ph, Wo, pw).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Ho, Wo, ph * pw)
+    return win.argmax(-1)
+
+
+def hip_decisions(saved, pools=((2, 2), (2, 2), (1, 2), (1, 2))):
+    """The hard decisions the HIP step took, recomputed from ITS OWN saved tensors (raw conv outputs + the BatchNorm scale / shift
+    its kernels apply as fmaf(y, scale, shift)): sign of the exact y * scale + shift (fp64 product of fp32 factors is exact) = sign
+    of the kernels' fmaf; arg-max over the fp32-rounded values.  Keys as oracle.conv_block(decisions=...) reads them."""
+    dec = {}
+    for i, (x, y1, s1, y2, s2, _, _) in enumerate(saved["acts"], start=1):
+        pre = f"audio_encoder.conv_block{i}."
+        for j, (y, stt) in enumerate(((y1, s1), (y2, s2)), start=1):
+            a = (y.double() * stt.scale.double() + stt.shift.double()).permute(0, 3, 1, 2)          # NCHW
+            dec[f"relu/{pre}bn{j}"] = (a > 0).cpu()
+        dec[f"argmax/{pre}"] = _window_first_argmax(torch.relu(a.float()), *pools[i - 1]).cpu()
+    fc = saved["fc"]                                                                            # (B * T', 512) after the ReLU
+    B = saved["acts"][0][1].shape[0]
+    dec["relu/audio_encoder.fc1"] = (fc > 0).view(B, -1, fc.shape[1]).cpu()
+    return dec
+
+
+def oracle_decisions(st, taps, pools=((2, 2), (2, 2), (1, 2), (1, 2))):
+    """The same decisions as the oracle run that filled `taps` took them (train-mode BatchNorm of its own raw conv outputs)."""
+    import torch.nn.functional as F
+    dec = {}
+    for i in range(1, 5):
+        pre = f"audio_encoder.conv_block{i}."
+        for j in (1, 2):
+            y = taps[pre + f"conv{j}"].detach()
+            a = F.batch_norm(y, None, None, st[pre + f"bn{j}.weight"].detach().to(y.dtype), st[pre + f"bn{j}.bias"].detach().to(y.dtype),
+                             True, 0.0, 1e-5)
+            dec[f"relu/{pre}bn{j}"] = a > 0
+        dec[f"argmax/{pre}"] = _window_first_argmax(torch.relu(a), *pools[i - 1])
+    dec["relu/audio_encoder.fc1"] = taps["fc1"].detach() > 0
+    return dec
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 1234])
+def test_proj_expnegl2_dropout_replay_vs_oracle(dev, seed, monkeypatch):
+    """Cnn8Rnn(512)+EmbeddingAgg(256)+audio/text proj+ExpNegL2, train mode WITH dropout, over seven generator seeds (round 4 kept
+    ONE hand-picked seed: "a realisation without a flipped decision").  The HIP path's keep-masks are exported (tag_dropout_mask)
+    and replayed in the oracle.  At this 2-clip size a conv-block gradient hangs on single ReLU / arg-max decisions whose operands
+    two fp32 implementations can round to different sides; what is asserted for EVERY seed:
+
+    1. loss within 2e-5 of the fp64 oracle; every tensor ABOVE the last ReLU of the conv stack (fc1, GRU, embedding, projections)
+       within 4 x max(floor, 1e-6) of the plain fp64 oracle -- no decision of the conv stack reaches them in backward;
+    2. with the HIP step's OWN decisions imposed on the oracle (oracle.conv_block(decisions=...): every BatchNorm+ReLU mask, every
+       max-pool arg-max, recomputed from the step's saved raw conv outputs), EVERY tensor -- conv blocks and bn0 included -- is
+       within 4 x max(floor, 1e-6), floor = the fp32 CPU oracle under the same decisions: all that separates the HIP path from the
+       reference arithmetic is round-off plus the counted decisions;
+    3. a conv-block tensor that misses the strict bound against the PLAIN oracle must have at least one flipped decision at or
+       above its layer (the error is explained, not tolerated)."""
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.runner import StrongRunner
     st = O.init_state(seed=11, text_dim=256, shared_dim=256, logit_gain=120.0)
     batch = make_batch(320)
-    # dropout seeds are drawn from torch's global generator.  At this 2-clip size the conv-block gradients hang on single
-    # ReLU / arg-max decisions (assert_grad_close): over generator seeds 1, 2, 3, 4, 5, 6, 1234 the worst conv-block error of the
-    # SAME code is 5.2e-2, 9.0e-3, 1.4e-2, 1.6e-2, 4.2e-6, 1.5e-3, 5.7e-2 (one flipped decision in block 4 moves 5.7e-2 of conv2's
-    # gradient; round 3's kernels, which add the channels of a tap in another order, gave 1.4e-3, 2.2e-3, 1.8e-2, -, -, -,
-    # 5.7e-2) while everything above the last ReLU stays at 1e-6 -- the seed picks a realisation, not a tolerance.  Seed 5 is a
-    # realisation without a flipped decision; the strict rule for every tensor is asserted at B = 6 and B = 64 below.
-    torch.manual_seed(5)
+    captured = []
+    orig_fwd = ops.Cnn8RnnFunction.forward
+
+    def fwd(ctx, *a):
+        y = orig_fwd(ctx, *a)
+        captured.append(hip_decisions(ctx.saved))            # now: backward frees the saved activations
+        return y
+
+    monkeypatch.setattr(ops.Cnn8RnnFunction, "forward", staticmethod(fwd))
+    torch.manual_seed(seed)                       # dropout seeds are drawn from torch's global generator
     model = build_hip_model(st, "expnegl2", dev).train()
     runner = StrongRunner(model, device=str(dev))
     loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    dec = captured[0]
     info = model.audio_encoder._last_dropout
     assert info["p"] == (0.2, 0.5)
     shapes = [(2, 75, 32, 64), (2, 37, 16, 128), (2, 37, 8, 256), (2, 37, 4, 512)]
@@ -189,27 +283,52 @@ def test_proj_expnegl2_dropout_replay_vs_oracle(dev):
         masks[f"drop{i + 1}"] = m.permute(0, 3, 1, 2).double()
         assert 0.7 < m.float().mean().item() < 0.9
     masks["drop5"] = ops.dropout_mask(info["seeds"][4], (2, 37, 512), 0.5, dev).cpu().double()
-    grads = {}
-    for dt in (torch.float64, torch.float32):
+
+    def oracle_grads(dt, decisions, taps=None):
         st_o = O.state_to(st, dt, requires_grad=True)
         bo = dict(batch)
         bo["waveform"], bo["label"] = batch["waveform"].to(dt), batch["label"].to(dt)
-        oloss, oout = O.train_step_loss(st_o, bo, "expnegl2", "cnn8rnn", True, None,
-                                        {k: v.to(dt) for k, v in masks.items()})
+        mk = {k: v.to(dt) for k, v in masks.items()}
+        mk.update(decisions or {})
+        oloss, _ = O.train_step_loss(st_o, bo, "expnegl2", "cnn8rnn", True, None, mk, taps)
         oloss.backward()
-        grads[dt] = {k: v.grad.double() for k, v in st_o.items() if v.is_floating_point() and v.grad is not None}
-        if dt == torch.float64:
-            assert abs(loss.item() - oloss.item()) < 2e-5
-    errs = {}
+        return oloss.item(), {k: v.grad.double() for k, v in st_o.items() if v.is_floating_point() and v.grad is not None}, st_o
+
+    taps = {}
+    l64, g64, st64 = oracle_grads(torch.float64, None, taps)
+    _, g32, _ = oracle_grads(torch.float32, None)
+    assert abs(loss.item() - l64) < 2e-5
+    own = oracle_decisions(st64, taps)
+    flips = {k: int((own[k] != dec[k]).sum()) for k in dec}
+    _, g64i, _ = oracle_grads(torch.float64, dec)
+    _, g32i, _ = oracle_grads(torch.float32, dec)
+    # layers whose decisions can reach a tensor's gradient: its own block's and everything above it (backward flows downwards)
+    order = [f"conv_block{i}" for i in range(1, 5)]
+
+    def flips_at_or_above(name):
+        if "bn0" in name:
+            lo = 0
+        else:
+            lo = next((i for i, b in enumerate(order) if b in name), 4)
+        return sum(v for k, v in flips.items() if any(b in k for b in order[lo:]) or "fc1" in k)
+
+    worst_plain, worst_imposed = 0.0, 0.0
     for name, p in model.named_parameters():
-        g64, g32 = grads[torch.float64][name], grads[torch.float32][name]
-        scale = g64.abs().max().item() + 1e-30
-        err = (p.grad.cpu().double() - g64).abs().max().item() / scale
-        e32 = (g32 - g64).abs().max().item() / scale
-        print(f"  {name:55s} hip-vs-f64 {err:.2e}   cpu-f32-oracle-vs-f64 {e32:.2e}")
-        errs[name] = (err, e32)
-    for name, (err, e32) in errs.items():
-        assert_grad_close(name, err, e32)
+        g = p.grad.cpu().double()
+        scale = g64[name].abs().max().item() + 1e-30
+        err, e32 = (g - g64[name]).abs().max().item() / scale, (g32[name] - g64[name]).abs().max().item() / scale
+        scale_i = g64i[name].abs().max().item() + 1e-30
+        err_i, e32_i = (g - g64i[name]).abs().max().item() / scale_i, (g32i[name] - g64i[name]).abs().max().item() / scale_i
+        conv = "conv_block" in name or "bn0" in name
+        print(f"  {name:55s} plain {err:.2e} (cpu-f32 {e32:.2e})   decisions imposed {err_i:.2e} (cpu-f32 {e32_i:.2e})")
+        assert err_i <= 4.0 * max(e32_i, 1e-6), (name, err_i, e32_i)                      # rule 2: every tensor
+        if not conv:
+            assert err <= 4.0 * max(e32, 1e-6), (name, err, e32)                          # rule 1
+        elif err > 4.0 * max(e32, 1e-6):
+            assert flips_at_or_above(name) > 0, (name, err, e32, flips)                   # rule 3
+        worst_plain, worst_imposed = max(worst_plain, err), max(worst_imposed, err_i)
+    print(f"seed {seed}: flipped decisions vs the fp64 oracle {sum(flips.values())} ({ {k: v for k, v in flips.items() if v} }); "
+          f"worst error plain {worst_plain:.2e}, with the HIP decisions imposed {worst_imposed:.2e}")
 
 
 def test_full_length_frame_sim_and_segments(dev, conv_math):
@@ -512,54 +631,83 @@ def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_)
     print(f"B=64 gradients: worst tensor at {worst:.2f} of its 4 x floor bound")
 
 
+BF16_BUDGET_REALISATIONS = 5
+
+
 def test_bf16_mode_train_step_budget(dev, golden_dir, monkeypatch):
     """BASELINE configs[2] as a real mode (TAG_CONV_MATH=bf16 + TAG_ACT_DTYPE=bf16): bf16 conv arithmetic AND bf16 storage
-    of the conv stack's activations / gradients, everything else fp32 -- one B = 64, 10 s training step (T' = 250, dropout
-    on) against the fp64 fixture of the benched step.  Stated budget (asserted below): loss within 2e-3, frame_sim within
-    6e-2 (the fixture's logit gain of 120 spreads the logits over +-3.3: 6e-2 in probability = 0.25 in logit), every gradient tensor: norm within 8 % (conv blocks / bn0) or 5 % (the rest), cosine on the sampled entries >= 0.97 (conv
-    blocks / bn0: eight bf16 layers and their BatchNorm cancellations deep), >= 0.999 (fc1), >= 0.9999 (GRU, embedding: above the encoder's last ReLU).  bf16 has 8 significand bits: per-element agreement is 1e-2-ish by construction; what training needs is
-    an unbiased gradient direction, which the cosine / norm pair measures.
-    Round 4: the conv-block norm bound went from 5 % to 8 %.  It was set on ONE realisation of the bf16 rounding noise (the tile
-    kernels: conv_block1.conv1.weight 4.9 %); the row-streaming kernel of conv_rows.hip gives the same per-kernel results up to
-    one-ulp ties (1e-4 of the elements, tools/conv_rows_bench.py) and lands at 6.5 % -- tools/diag_rows_budget.py: the two
-    realisations differ from EACH OTHER by 4-7 % per conv-block tensor (cosine 0.998-0.999) while both stay 0.99 in cosine to
-    fp64, i.e. the norm of these tensors moves by +-1.5 % with the rounding ties alone.  What pins the arithmetic now are the
-    per-stage tests (forward and backward rounding-point emulations above); this budget is the end-to-end sanity check."""
+    of the conv stack's activations / gradients, everything else fp32 -- the B = 64, 10 s training step (T' = 250, dropout
+    on) against the fp64 fixture of the benched step, as a STATISTIC over rounding realisations instead of one sample.
+
+    bf16 has 8 significand bits: per-element agreement is 1e-2-ish by construction; what training needs is an unbiased gradient
+    direction, which the (norm, cosine) pair measures -- but ONE step is one realisation of the rounding noise: rounds 2-4 moved
+    the conv-block norm bound 5 % -> 8 % when a new kernel changed which ties round which way (round-4 review).  Here the step is
+    run BF16_BUDGET_REALISATIONS times, realisation r > 0 on the waveform perturbed by one part in 1.7e7 (6e-8 relative, a coin
+    flip on the last bit of each fp32 sample: the fp64 fixture's gradients move by 1e-8 under it, tools/diag_flip.py) so that
+    the rounding ties of all eight bf16 layers fall differently, and per gradient tensor the SIGNED relative norm error
+    e_r = (|g_r| - |g_fp64|) / |g_fp64| is summarised by its mean (the mode's bias) and standard deviation (its noise):
+
+      * loss within 2e-3 and frame_sim within 6e-2 of fp64 for every realisation (logit gain 120 spreads the logits over +-3.3);
+      * bias:  |mean e| <= 6 % (conv blocks / bn0: eight bf16 layers and their BatchNorm cancellations deep), 3 % (the rest);
+      * noise: std e <= 2.5 % (conv blocks / bn0), 1 % (the rest) -- and therefore no single realisation is asserted against a
+        constant that a kernel change could move: a kernel that only re-orders ties changes e_r, not (mean, std);
+      * direction, every realisation: cosine on the sampled entries >= 0.97 (conv blocks / bn0), 0.999 (fc1), 0.9999 (GRU,
+        embedding: above the encoder's last ReLU); the MEAN gradient over the realisations must be at least as close in cosine as
+        the worst single one (noise averages out, a bias would not).
+    What pins the arithmetic itself are the per-stage rounding-point emulation tests below; this is the end-to-end check."""
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.runner import StrongRunner
     gold = np.load(f"{golden_dir}/b64_train_step.npz")
     st = O.init_state(seed=5, logit_gain=120.0)
     batch = O.synthetic_batch(64, 320000, seed=99, ragged=True)
-    seeds = iter(int(v) for v in gold["dropout_seeds"])
-    monkeypatch.setattr(ops, "new_seed", lambda: next(seeds))
     monkeypatch.setattr(ops, "CONV_MATH", "bf16")
     monkeypatch.setattr(ops, "ACT_DTYPE", "bf16")
-    model = build_hip_model(st, "dot", dev).train()
-    runner = StrongRunner(model, device=str(dev))
-    torch.cuda.reset_peak_memory_stats()
-    loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
-    lv = runner.loss_value(loss)
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    seeds2 = iter(int(v) for v in gold["dropout_seeds"])
-    monkeypatch.setattr(ops, "new_seed", lambda: next(seeds2))
-    with torch.no_grad():
-        out = runner.forward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, training=True)
-    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
-    print(f"bf16 mode B=64: loss {lv:.6f} vs {float(gold['loss_f64']):.6f}; frame_sim err {fs_err:.2e}; peak memory {peak:.1f} GiB")
-    assert abs(lv - float(gold["loss_f64"])) < 2e-3 and fs_err < 6e-2
+    names, sampled, norms, stats = None, {}, {}, []
+    for r in range(BF16_BUDGET_REALISATIONS):
+        b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if r:
+            gen = torch.Generator().manual_seed(1000 + r)
+            b["waveform"] = (b["waveform"].double() * (1 + 6e-8 * torch.randn(b["waveform"].shape, generator=gen,
+                                                                               dtype=torch.float64))).float()
+        seeds = iter(int(v) for v in gold["dropout_seeds"])
+        monkeypatch.setattr(ops, "new_seed", lambda: next(seeds))
+        model = build_hip_model(st, "dot", dev).train()
+        runner = StrongRunner(model, device=str(dev))
+        torch.cuda.reset_peak_memory_stats()
+        loss = runner.forward_backward(dict(b))
+        lv = runner.loss_value(loss)
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        seeds2 = iter(int(v) for v in gold["dropout_seeds"])
+        monkeypatch.setattr(ops, "new_seed", lambda: next(seeds2))
+        with torch.no_grad():
+            out = runner.forward(dict(b), training=True)
+        fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+        stats.append((lv, fs_err))
+        assert abs(lv - float(gold["loss_f64"])) < 2e-3 and fs_err < 6e-2, (r, lv, fs_err)
+        names = [n for n, _ in model.named_parameters()]
+        for name, p in model.named_parameters():
+            g = p.grad.detach().double().flatten().cpu()
+            gi = torch.Generator().manual_seed(sum(map(ord, name)))
+            idx = torch.randint(0, g.numel(), (min(1024, g.numel()),), generator=gi)
+            sampled.setdefault(name, []).append(g[idx].numpy())
+            norms.setdefault(name, []).append(g.norm().item())
+        del runner, model
+    print(f"bf16 mode B=64, {BF16_BUDGET_REALISATIONS} rounding realisations: loss {[round(s[0], 6) for s in stats]} vs "
+          f"{float(gold['loss_f64']):.6f}; frame_sim err {[f'{s[1]:.1e}' for s in stats]}; peak memory {peak:.1f} GiB")
     bad = []
-    for name, p in model.named_parameters():
+    for name in names:
         want = gold[f"grad/{name}"]
-        g = p.grad.detach().double().flatten().cpu()
-        gi = torch.Generator().manual_seed(sum(map(ord, name)))
-        idx = torch.randint(0, g.numel(), (min(1024, g.numel()),), generator=gi)
-        a, b = g[idx].numpy(), want[2:]
-        cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
-        nerr = abs(g.norm().item() - want[0]) / (want[0] + 1e-300)
-        print(f"  {name:55s} norm err {nerr:.2e}  cosine {cos:.6f}")
+        e = np.array([(n - want[0]) / (want[0] + 1e-300) for n in norms[name]])
+        cos = [float(np.dot(a, want[2:]) / (np.linalg.norm(a) * np.linalg.norm(want[2:]) + 1e-300)) for a in sampled[name]]
+        mean_g = np.mean(sampled[name], axis=0)
+        cos_mean = float(np.dot(mean_g, want[2:]) / (np.linalg.norm(mean_g) * np.linalg.norm(want[2:]) + 1e-300))
         deep = "conv_block" in name or "bn0" in name
         floor = 0.97 if deep else (0.999 if "fc1" in name else 0.9999)
-        bad += [] if (nerr < (8e-2 if deep else 5e-2) and cos >= floor) else [(name, nerr, cos)]
+        print(f"  {name:55s} norm err mean {e.mean():+.2e} std {e.std(ddof=1):.2e} [{e.min():+.2e}, {e.max():+.2e}]  "
+              f"cosine min {min(cos):.6f} of-the-mean {cos_mean:.6f}")
+        ok = (abs(e.mean()) <= (6e-2 if deep else 3e-2) and e.std(ddof=1) <= (2.5e-2 if deep else 1e-2)
+              and min(cos) >= floor and cos_mean >= min(cos) - 1e-6)
+        bad += [] if ok else [(name, float(e.mean()), float(e.std(ddof=1)), min(cos), cos_mean)]
     assert not bad, bad
 
 
@@ -867,6 +1015,41 @@ def test_training_step_is_bitwise_deterministic(dev, math_):
     assert res[0][0] == res[1][0]
     same = res[0][1] == res[1][1]
     assert bool(same.all()), f"{int((~same).sum())} gradient elements differ between two identical runs"
+
+
+@pytest.mark.parametrize("cu_skip", [0, 2])
+def test_fp32_step_with_the_wgrad_side_stream_switched_on(dev, monkeypatch, cu_skip):
+    """The switches that are off by default in fp32 (round-4 advice: untested): TAG_WGRAD_STREAM=1 runs the weight-gradient convs
+    on the side stream, TAG_WGRAD_CU_SKIP=k makes that stream a CU-masked hipExtStreamCreateWithCUMask stream.  Stream placement
+    changes WHEN a kernel runs, never what it computes: loss and every gradient are bit-identical to the single-stream step."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=3, logit_gain=40.0)
+    batch = O.synthetic_batch(4, 64000, seed=8, ragged=True)
+    res = []
+    for side in (False, True):
+        monkeypatch.setattr(ops, "WGRAD_SIDE_STREAM", side)
+        monkeypatch.setattr(ops, "WGRAD_CU_SKIP", cu_skip if side else 0)
+        monkeypatch.setattr(ops, "_side_streams", {})             # the masked stream is created on first use
+        torch.manual_seed(123)
+        model = build_hip_model(st, "dot", dev).train()
+        runner = StrongRunner(model, device=str(dev))
+        assert ops.side_stream_enabled() == side
+        loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        torch.cuda.synchronize()
+        res.append((loss.item(), runner.flat.grad.clone()))
+        if side:
+            assert len(ops.side_streams(dev)) == 1
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+def test_env_switches_are_parsed_defensively(monkeypatch):
+    from texttoaudiogrounding_amd import ops
+    monkeypatch.setenv("TAG_WGRAD_CU_SKIP", "two")
+    with pytest.raises(RuntimeError, match="TAG_WGRAD_CU_SKIP"):
+        ops._env_int("TAG_WGRAD_CU_SKIP", 0)
+    monkeypatch.setenv("TAG_WGRAD_CU_SKIP", " ")
+    assert ops._env_int("TAG_WGRAD_CU_SKIP", 0) == 0
 
 
 def test_device_segments_to_th_auc_and_psds(dev):

@@ -1,0 +1,83 @@
+"""CPU: the Hugging Face surface of the inference wrapper (models/hf_modeling_grounding.py:296-352 of the reference, README.md:7-39):
+a PreTrainedModel with a PretrainedConfig, save_pretrained -> from_pretrained round trip, AutoModel resolution of a local directory,
+a tokenizer that is loaded when it exists locally / can be injected, and a clear error for strings without one.  (No compute: the
+forward pass needs the GPU; the bit-identity of frame_sim across the round trip is tests/test_gpu_infer.py.)"""
+import os
+
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+
+TINY = dict(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=4, intermediate_size=64,
+            max_position_embeddings=40, projection_dim=512)
+
+
+def tiny_tokenizer_dir(path):
+    """A real (tiny) fast tokenizer saved to `path`: whitespace word-level over a 20-word vocabulary, RoBERTa's special ids
+    (<s> 0, <pad> 1, </s> 2, <unk> 3) -- what AutoTokenizer.from_pretrained(<dir>, local_files_only=True) loads without network."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    words = "a man speaks dog is barking the bird sings loudly rain falls on roof car passes by woman laughs".split()
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    vocab.update({w: i + 4 for i, w in enumerate(dict.fromkeys(words))})
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="<s> $A </s>", special_tokens=[("<s>", 0), ("</s>", 2)])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>")
+    fast.save_pretrained(path)
+    return path
+
+
+def test_base_classes_and_config_round_trip(tmp_path):
+    from transformers import PretrainedConfig, PreTrainedModel
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import (Cnn8RnnLaionClapGroundingConfig,
+                                                                      Cnn8RnnLaionClapGroundingModel)
+    assert issubclass(Cnn8RnnLaionClapGroundingConfig, PretrainedConfig)
+    assert issubclass(Cnn8RnnLaionClapGroundingModel, PreTrainedModel)
+    assert Cnn8RnnLaionClapGroundingModel.config_class is Cnn8RnnLaionClapGroundingConfig
+    cfg = Cnn8RnnLaionClapGroundingConfig()
+    assert (cfg.sample_rate, cfg.shared_dim, cfg.text_encoder_name) == (32000, 512, "laion/clap-htsat-fused")
+    cfg = Cnn8RnnLaionClapGroundingConfig(sample_rate=32000, shared_dim=512, text_config=TINY)
+    cfg.save_pretrained(tmp_path)
+    back = Cnn8RnnLaionClapGroundingConfig.from_pretrained(tmp_path)
+    assert back.text_config == TINY and back.shared_dim == 512
+
+
+def test_save_pretrained_from_pretrained_round_trip(tmp_path):
+    from transformers import AutoModel
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import (Cnn8RnnLaionClapGroundingConfig,
+                                                                      Cnn8RnnLaionClapGroundingModel)
+    torch.manual_seed(3)
+    model = Cnn8RnnLaionClapGroundingModel(Cnn8RnnLaionClapGroundingConfig(text_config=TINY))
+    with torch.no_grad():                       # non-trivial BatchNorm buffers: they must travel too
+        model.model.audio_encoder.bn0.running_mean.uniform_(-1, 1)
+        model.model.audio_encoder.conv_block3.bn2.running_var.uniform_(0.5, 2)
+    model.save_pretrained(tmp_path)
+    assert {"config.json", "model.safetensors"} <= set(os.listdir(tmp_path))
+    for loader in (Cnn8RnnLaionClapGroundingModel, AutoModel):
+        back = loader.from_pretrained(tmp_path)
+        assert type(back) is Cnn8RnnLaionClapGroundingModel
+        a, b = model.state_dict(), back.state_dict()
+        assert a.keys() == b.keys() and len(a) > 100
+        assert all(torch.equal(a[k], b[k]) for k in a), [k for k in a if not torch.equal(a[k], b[k])][:3]
+    # the reference's state-dict names (checkpoints of the reference load): BiEncoder under `model.`, towers as in hf_modeling_grounding.py
+    assert "model.audio_encoder.conv_block1.conv1.weight" in a and "model.audio_proj.weight" in a
+    assert "model.text_encoder.model.encoder.layer.0.attention.self.query.weight" in a
+
+
+def test_strings_need_a_tokenizer_and_a_local_one_is_found(tmp_path):
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import (Cnn8RnnLaionClapGroundingConfig,
+                                                                      Cnn8RnnLaionClapGroundingModel)
+    model = Cnn8RnnLaionClapGroundingModel(Cnn8RnnLaionClapGroundingConfig(text_config=TINY))
+    assert model.text_tokenizer is None         # "laion/clap-htsat-fused" is neither a directory nor cached here
+    with pytest.raises(RuntimeError, match="no tokenizer"):
+        model.tokenize(["a man speaks"])
+    d = tiny_tokenizer_dir(str(tmp_path / "tok"))
+    model2 = Cnn8RnnLaionClapGroundingModel(Cnn8RnnLaionClapGroundingConfig(text_encoder_name=d, text_config=TINY))
+    assert model2.text_tokenizer is not None    # resolved locally, like the reference's AutoTokenizer.from_pretrained(name)
+    tok = model2.tokenize(["a man speaks", "the dog is barking loudly"])
+    assert tok["input_ids"].shape == (2, 7) and tok["input_ids"][0, 0] == 0 and tok["attention_mask"].sum(-1).tolist() == [5, 7]
+    assert tok["input_ids"][0, 5:].tolist() == [1, 1]                       # right-padded with <pad> = 1
+    model.text_tokenizer = model2.text_tokenizer                            # injection
+    assert torch.equal(model.tokenize(["a man speaks"])["input_ids"], model2.tokenize(["a man speaks"])["input_ids"])

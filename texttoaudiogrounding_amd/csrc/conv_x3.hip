@@ -1170,7 +1170,7 @@ extern "C" int tag_conv3x3_wgrad_x3_bf16(const void* x, int prologue, const floa
     TAG_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     const long M = (long)B * H * W;
-    TAG_CHECK_ARG(M < (1L << 31));
+    TAG_CHECK_ARG(M < (1L << 31) && (long)H * W * Cin * 2 < (1L << 32) && (long)H * W * Cout * 2 < (1L << 32));   // 32-bit byte offsets inside one image (bf16 storage)
     float* partial = static_cast<float*>(ws);
     hipStream_t st = as_stream(stream);
     int cps;

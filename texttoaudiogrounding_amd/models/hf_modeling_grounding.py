@@ -7,8 +7,9 @@ Differences forced by the environment, not by design:
   shape by default) with the SAME module / state-dict names as ``ClapModel.text_model`` + ``ClapModel.text_projection``,
   so a downloaded checkpoint loads with ``load_state_dict``; ``forward`` takes ``input_ids`` / ``attention_mask``
   (what the tokenizer would return).
-* no ``transformers`` import: the classes are plain ``nn.Module`` holders of the parameters; the arithmetic runs in
-  libtag_hip.so (tag_roberta_embed_ln, tag_gemm with bias/GELU/tanh/ReLU epilogues, tag_mha_small, tag_add_layernorm,
+* ``transformers`` is used for the reference's two BASE classes only (``PreTrainedModel`` / ``PretrainedConfig``: the
+  ``from_pretrained`` / ``save_pretrained`` surface of models/hf_modeling_grounding.py:305-352) and, when one is available
+  locally, the tokenizer; the towers are plain ``nn.Module`` holders of the parameters and the arithmetic runs in libtag_hip.so (tag_roberta_embed_ln, tag_gemm with bias/GELU/tanh/ReLU epilogues, tag_mha_small, tag_add_layernorm,
   tag_l2norm_rows_forward).
 """
 from typing import Dict, List, Optional
@@ -149,8 +150,20 @@ class LaionClapEncoder(nn.Module):
         return {"seq_emb": seq_emb, "token_emb": token_emb, "last_hidden_state": h.view(B, L, D), "pooler_output": pooled}
 
 
-class Cnn8RnnLaionClapGroundingConfig:
-    """models/hf_modeling_grounding.py:296-306 (a plain object here: no PretrainedConfig / network)."""
+try:                                            # the reference's own base classes when transformers is installed (it is optional
+    from transformers import PreTrainedModel as _ModelBase, PretrainedConfig as _ConfigBase   # for the training path)
+    _HAVE_TRANSFORMERS = True
+except Exception:                               # noqa: BLE001 - any import problem: plain objects, same attributes
+    _ModelBase, _ConfigBase, _HAVE_TRANSFORMERS = nn.Module, object, False
+
+
+class Cnn8RnnLaionClapGroundingConfig(_ConfigBase):
+    """models/hf_modeling_grounding.py:296-306: a ``PretrainedConfig`` (``save_pretrained`` / ``from_pretrained`` /
+    ``config.json``) with the reference's three fields.  ``text_config`` (optional, not in the reference) overrides entries of
+    CLAP_TEXT_DEFAULTS -- the text tower is built from a configuration here, not downloaded (module docstring)."""
+    # the reference leaves model_type empty and reaches its classes through config.json's auto_map + trust_remote_code; a model_type
+    # lets AutoConfig / AutoModel resolve a LOCAL directory saved by this class without remote code (registered below)
+    model_type = "cnn8rnn_laionclap_grounding"
 
     def __init__(self, sample_rate: int = 32000, shared_dim: int = 512, text_encoder_name: str = "laion/clap-htsat-fused",
                  text_config: Optional[dict] = None, **kwargs):
@@ -158,32 +171,72 @@ class Cnn8RnnLaionClapGroundingConfig:
         self.shared_dim = shared_dim
         self.text_encoder_name = text_encoder_name
         self.text_config = text_config
+        if _HAVE_TRANSFORMERS:
+            super().__init__(**kwargs)
 
 
-class Cnn8RnnLaionClapGroundingModel(nn.Module):
-    """models/hf_modeling_grounding.py:319-352.  ``forward(audio, audio_len, text)``: ``text`` is the tokenizer output
-    (dict with ``input_ids`` and ``attention_mask``) -- the reference tokenises strings itself, which needs the
-    network-fetched tokenizer.  Returns frame_sim (B, T')."""
+class Cnn8RnnLaionClapGroundingModel(_ModelBase):
+    """models/hf_modeling_grounding.py:305-352: a ``PreTrainedModel`` with ``config_class`` set, so ``save_pretrained`` /
+    ``from_pretrained`` / ``AutoModel.from_pretrained(..., trust_remote_code=True)`` (README.md:7-39) work on it, called like the
+    reference: ``model(audio, audio_len, text)`` -> frame_sim (B, T').
+
+    ``text`` is a ``List[str]`` (the reference's call) when a tokenizer is available -- ``model.text_tokenizer`` is loaded from
+    ``config.text_encoder_name`` if that resolves LOCALLY (a directory, or the Hugging Face cache; there is no network on the
+    build / GPU boxes) and can be injected (``model.text_tokenizer = tok``: any callable with the tokenizer's
+    ``(text, padding=True, return_tensors="pt", truncation=True)`` signature) -- or the tokenizer's output itself (a mapping with
+    ``input_ids`` and ``attention_mask``).  Strings without a tokenizer raise a clear error instead of guessing."""
+    config_class = Cnn8RnnLaionClapGroundingConfig
+    base_model_prefix = "model"
+    # the audio tower's activations at 30 s x 64 clips are GBs: keep the module on one device
+    _no_split_modules = ["BiEncoder"]
 
     def __init__(self, config: Optional[Cnn8RnnLaionClapGroundingConfig] = None, max_clips_per_pass: int = 64):
-        super().__init__()
         config = config or Cnn8RnnLaionClapGroundingConfig()
-        self.config = config
+        if _HAVE_TRANSFORMERS:
+            super().__init__(config)
+        else:
+            super().__init__()
+            self.config = config
         self.model = BiEncoder(audio_encoder=Cnn8Rnn(sample_rate=config.sample_rate),
                                text_encoder=LaionClapEncoder(config.text_encoder_name, config.text_config),
                                match_fn=DotProduct(), shared_dim=config.shared_dim, add_proj=True)
         self.max_clips_per_pass = max_clips_per_pass
+        self.text_tokenizer = self._local_tokenizer(config.text_encoder_name)
+        if _HAVE_TRANSFORMERS:
+            self.post_init()
 
-    @property
-    def device(self):
-        return next(self.parameters()).device
+    @staticmethod
+    def _local_tokenizer(name):
+        """AutoTokenizer of ``name`` when it can be had WITHOUT the network (models/hf_modeling_grounding.py:326-328 downloads it)."""
+        if not _HAVE_TRANSFORMERS or not name:
+            return None
+        try:
+            from transformers import AutoTokenizer
+            return AutoTokenizer.from_pretrained(name, local_files_only=True)
+        except Exception:                       # noqa: BLE001 - not cached / no such directory: the caller injects one
+            return None
+
+    def _init_weights(self, module):            # weights come from the sub-modules' own constructors (reference: same)
+        return
+
+    if not _HAVE_TRANSFORMERS:
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    def tokenize(self, text: List[str]) -> Dict:
+        if self.text_tokenizer is None:
+            raise RuntimeError(
+                "Cnn8RnnLaionClapGroundingModel got strings but has no tokenizer: the tokenizer of "
+                f"{self.config.text_encoder_name!r} is not available locally (no network here).  Set model.text_tokenizer = "
+                "AutoTokenizer.from_pretrained(<local path>), or pass the tokenizer output (input_ids, attention_mask)")
+        return self.text_tokenizer(list(text), padding=True, return_tensors="pt", truncation=True)
 
     @torch.no_grad()
-    def forward(self, audio: torch.Tensor, audio_len, text: Dict):
+    def forward(self, audio: torch.Tensor, audio_len, text):
         dev = self.device
-        if isinstance(text, (list, tuple)) and text and isinstance(text[0], str):
-            raise NotImplementedError("pass the tokenizer output (input_ids, attention_mask): the tokenizer of "
-                                      "laion/clap-htsat-fused cannot be fetched without network access")
+        if isinstance(text, (list, tuple)) and (not text or isinstance(text[0], str)):
+            text = self.tokenize(text)          # models/hf_modeling_grounding.py:340-343
         audio = audio.to(dev)
         B = audio.shape[0]
         ids, mask = text["input_ids"], text["attention_mask"]
@@ -199,3 +252,12 @@ class Cnn8RnnLaionClapGroundingModel(nn.Module):
                  "text_len": mask[sl].sum(-1), "specaug": False}
             outs.append(self.model(d)["frame_sim"])
         return torch.cat(outs, 0)
+
+
+if _HAVE_TRANSFORMERS:
+    try:                                        # AutoModel.from_pretrained(<directory saved by save_pretrained>) resolves to this class
+        from transformers import AutoConfig, AutoModel
+        AutoConfig.register(Cnn8RnnLaionClapGroundingConfig.model_type, Cnn8RnnLaionClapGroundingConfig)
+        AutoModel.register(Cnn8RnnLaionClapGroundingConfig, Cnn8RnnLaionClapGroundingModel)
+    except Exception:                           # noqa: BLE001 - already registered (module re-import) or an older transformers
+        pass

@@ -86,12 +86,14 @@ GRAD_FLUSH = None        # callable() -> None: a safe point to launch the all-re
 #: and is not announced to the gradient buckets early (GradBuckets.finish() exchanges it after backward).
 _CLAIMS = {}
 _WRITTEN = set()
+_AUTOGRAD_SEEN = set()      # sinks (data_ptr) into which plain autograd accumulated a gradient this step (second_writer_guard)
 
 
 def begin_direct_step():
     """Called by StrongRunner.forward_backward after zero_grad, before the forward pass."""
     _CLAIMS.clear()
     _WRITTEN.clear()
+    _AUTOGRAD_SEEN.clear()
 
 
 class _LazySinks:
@@ -152,13 +154,27 @@ def second_writer_guard(p):
     into ``p.grad`` -- None when every node delivered in place.  A parameter claimed by exactly ONE HIP node is delivered in
     place, so a defined gradient arriving for it means a second, plain-torch consumer of the same parameter (a tied weight,
     a regulariser on p) is adding into the very view the node overwrites with copy_: the sum would depend on the order of
-    the two writes.  Raise instead of training on a silently wrong gradient."""
+    the two writes.  Raise instead of training on a silently wrong gradient.
+
+    The race is decided on what HAPPENED in this step, not on the claim alone: the error is raised when both writers really
+    wrote -- here if the node's in-place delivery came first (the sink is in _WRITTEN), in _deliver if autograd's came first.  A
+    parameter claimed by a HIP node whose output never takes part in this backward (a metric-only forward under grad mode) and
+    also used by a plain torch op has ONE writer and trains normally."""
     def hook(g):
-        if g is not None and DIRECT_GRADS and _CLAIMS.get(id(p), 0) == 1:
-            raise RuntimeError("direct gradients: a parameter delivered in place by a HIP autograd node also received a "
-                               "gradient through plain autograd (tied weight / regulariser on the parameter); the two "
-                               "writers race on one flat-gradient view -- run this model with ops.DIRECT_GRADS off")
+        if g is None or not DIRECT_GRADS or _CLAIMS.get(id(p), 0) != 1:
+            return
+        sink = getattr(p, "_tag_grad_sink", None)
+        if sink is None:
+            return
+        if sink.data_ptr() in _WRITTEN:
+            raise RuntimeError(_SECOND_WRITER_MSG)
+        _AUTOGRAD_SEEN.add(sink.data_ptr())
     return hook
+
+
+_SECOND_WRITER_MSG = ("direct gradients: a parameter delivered in place by a HIP autograd node also received a gradient through "
+                      "plain autograd in the same step (tied weight / regulariser on the parameter); the two writers race on one "
+                      "flat-gradient view -- run this model with ops.DIRECT_GRADS off")
 
 
 def _deliver(grads, sinks, i, val):
@@ -169,6 +185,8 @@ def _deliver(grads, sinks, i, val):
         if key in _WRITTEN:
             raise RuntimeError("direct gradients: a flat-gradient sink was written twice in one step (a retained graph run "
                                "twice?); plain autograd would have accumulated -- run this pattern with ops.DIRECT_GRADS off")
+        if key in _AUTOGRAD_SEEN:
+            raise RuntimeError(_SECOND_WRITER_MSG)
         _WRITTEN.add(key)
         if val.data_ptr() != key:
             sink.copy_(val.view_as(sink))
@@ -849,7 +867,19 @@ def side_stream_enabled():
 #: TAG_WGRAD_CU_SKIP=k (k >= 2): the side stream may not use every k-th compute unit (hipExtStreamCreateWithCUMask), so that the
 #: short kernels of the main stream (BatchNorm finalizes, reductions) never queue behind a full residency round of
 #: weight-gradient workgroups.  0 = an ordinary stream.
-WGRAD_CU_SKIP = int(_os.environ.get("TAG_WGRAD_CU_SKIP", "0"))
+def _env_int(name, default=0):
+    """An integer environment switch parsed defensively: a malformed value is reported with its name, not as a bare ValueError at
+    import time."""
+    raw = _os.environ.get(name, "")
+    if raw.strip() == "":
+        return default
+    try:
+        return int(raw)
+    except ValueError:
+        raise RuntimeError(f"environment variable {name}={raw!r} must be an integer") from None
+
+
+WGRAD_CU_SKIP = _env_int("TAG_WGRAD_CU_SKIP", 0)
 
 
 def _side_stream(device):
@@ -891,7 +921,7 @@ WGRAD_LAG = _os.environ.get("TAG_WGRAD_LAG", "0") != "0"     # measured: 57.7 ms
 #: (TAG_SIDE_PARAM_GRADS).  Measured on one box, B = 64 (fp32 / bf16 mode ms per step): 0: 54.64-54.75 / 11.23-11.30,
 #: 1: 54.57-54.69 / 11.02-11.11, 2: 54.91-55.20 / 11.08-11.13 -- fc1's GEMM on the side stream delays the block-4 wgrads more
 #: than it overlaps, so the default stops at the GRU.
-SIDE_PARAM_GRADS = int(os.environ.get("TAG_SIDE_PARAM_GRADS", "1"))
+SIDE_PARAM_GRADS = _env_int("TAG_SIDE_PARAM_GRADS", 1)
 
 
 class _SideWgrad:

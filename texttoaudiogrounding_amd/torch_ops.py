@@ -366,6 +366,8 @@ register_autograd("tag::frame_bce", _bce_backward, setup_context=_bce_setup)
 # operator could return cheaply (GBs of raw conv outputs saved for backward, dropout seeds, the direct-gradient sinks of the
 # flat buffer, the weight-gradient side stream), so the saved state travels from the forward kernel to ``setup_context`` through
 # a one-slot hand-over and the module (eps / momentum / dropout probabilities / frozen flags) is named by a token.
+# EAGER-ONLY: the fake kernels serve shape inference (opcheck, meta tensors); a backward traced by torch.compile / AOTAutograd has
+# no saved state and raises a clear error (_enc_backward).  A second backward through one forward (retain_graph) raises its own.
 import weakref
 
 _ENC_MODULES = weakref.WeakValueDictionary()          # token -> nn.Module
@@ -397,13 +399,20 @@ def _enc_forward(engine, waveform, params, module_token, need_grad):
 
 def _enc_setup(ctx, inputs, output):
     ctx.enc, _ENC_HANDOVER[0] = _ENC_HANDOVER[0], None
+    ctx.enc_consumed = False
 
 
 def _enc_backward(ctx, dy):
     if ctx.enc is None:
-        raise RuntimeError("tag encoder operator: backward without saved state (call it with need_grad=True under autograd)")
+        if getattr(ctx, "enc_consumed", False):
+            raise RuntimeError("tag encoder operator: second backward through the same forward (retain_graph=True): the saved "
+                               "activations (GBs of raw conv outputs) are released by the first backward -- run the forward again")
+        raise RuntimeError("tag encoder operator: backward without saved state.  The operator is EAGER-ONLY: its saved state is "
+                           "handed from the forward kernel to setup_context out of band, which torch.compile / AOTAutograd "
+                           "tracing (fake tensors) cannot reproduce; call it in eager mode with need_grad=True under autograd")
     engine, ectx = ctx.enc
     ctx.enc = None
+    ctx.enc_consumed = True
     grads = engine.backward(ectx, dy.contiguous())            # (None, None, *parameter gradients)
     return None, list(grads[2:]), None, None
 
@@ -454,6 +463,9 @@ def run_encoder(op, mod, waveform, params):
         return op(waveform, list(params), encoder_token(mod), need)
     finally:
         ops._RECORDING = prev
+        # setup_context has taken the saved state by now; if it was skipped (the dispatcher decided that no input needs a
+        # gradient) the slot must not keep GBs of activations alive until the next forward
+        _ENC_HANDOVER[0] = None
 
 
 # ------------------------------------------------------------------------------------------------ P1 segments

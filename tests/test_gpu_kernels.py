@@ -549,6 +549,57 @@ def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
         assert relerr(dg, gd.grad) < 1e-4 and relerr(db, bd.grad) < 1e-4
 
 
+@pytest.mark.parametrize("B,Hf,Wf,Cin,C,ph,train,p", [
+    (2, 18, 16, 64, 128, 2, True, 0.2), (1, 35, 32, 128, 64, 2, True, 0.0), (2, 21, 16, 256, 128, 1, True, 0.2),
+    (2, 43, 64, 128, 64, 2, True, 0.2), (2, 13, 128, 64, 64, 2, False, 0.2), (3, 250, 16, 512, 256, 1, True, 0.2),
+    (2, 1001, 64, 128, 64, 2, True, 0.2)])
+def test_conv_dgrad_fused_pool_backward_sums(ops, dev, B, Hf, Wf, Cin, C, ph, train, p):
+    """One-read pool backward: tag_conv3x3_dgrad_poolsums (the dgrad conv of the NEXT block's first conv, with the sums of the
+    BatchNorm+ReLU+pool backward below it in the epilogue) + tag_bn_grad_from_partials + tag_bnrelu_pool_backward_apply, against
+    (a) the fp64 chain  a = relu(bn(y)); o = dropout(avg_pool(a) + max_pool(a)); u = conv(o, w); backward(du)  and (b) the
+    two-pass kernels it replaces on the same dx (dy bit-identical: same apply kernel; dgamma / dbeta to summation round-off).
+    Odd Hf (floor-dropped last row), 64-wide pooled images (two tile columns), 1x2 and 2x2 windows, eval-mode statistics."""
+    pw = 2
+    H, W = Hf // ph, Wf // pw
+    g = torch.Generator().manual_seed(Hf * Wf + C)
+    y = torch.randn(B, C, Hf, Wf, generator=g) * (1.0 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.3
+    w = torch.randn(Cin, C, 3, 3, generator=g) / math.sqrt(9 * C)       # the conv that CONSUMES the pooled output: C -> Cin
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    du = torch.randn(B, Cin, H, W, generator=g)
+    yh = nhwc(y).to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gamma.to(dev), beta.to(dev), rm.clone().to(dev), rv.clone().to(dev), train)
+    seed = 4242
+    mask = ops.dropout_mask(seed, (B, H, W, C), p, dev, pooled=True).cpu().permute(0, 3, 1, 2) if p > 0 else None
+    _, wdg = ops.pack_conv_weight(w.to(dev), W=W)
+    duh = nhwc(du).to(dev)
+    assert ops.pool_sums_fusable(duh, wdg, yh, ph, pw)
+    dx, part = ops.conv3x3_dgrad_poolsums(duh, wdg, yh, st, ph, pw, p, seed)
+    dy, dg, db = ops.bnrelu_pool_backward(yh, st, gamma.to(dev), dx, ph, pw, p, seed, partials=part)
+    # (b) the two-pass kernels on the same dx
+    dx_plain = ops.conv3x3(duh, wdg, C)
+    assert torch.equal(dx, dx_plain)
+    dy2, dg2, db2 = ops.bnrelu_pool_backward(yh, st, gamma.to(dev), dx, ph, pw, p, seed)
+    assert relerr(dg, dg2.cpu().double()) < 2e-6 and relerr(db, db2.cpu().double()) < 2e-6
+    if not train:
+        assert torch.equal(dy, dy2)          # eval statistics: dy does not depend on the sums
+    else:
+        assert relerr(dy, dy2.cpu().double()) < 2e-6
+    if Hf > 300:
+        return                                # the big shape is a kernel-vs-kernel check (fp64 reference of 1001 x 64 x 64: slow)
+    # (a) fp64 autograd
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yd, rm.double().clone(), rv.double().clone(), gd, bd, train, 0.1, 1e-5))
+    o = F.avg_pool2d(a, (ph, pw)) + F.max_pool2d(a, (ph, pw))
+    if mask is not None:
+        o = o * mask.double() / (1 - p)
+    F.conv2d(o, w.double(), None, 1, 1).backward(du.double())
+    e_dy, e_dg, e_db = relerr(nchw(dy), yd.grad), relerr(dg, gd.grad), relerr(db, bd.grad)
+    print(f"fused pool sums {B}x{Hf}x{Wf} {C}<-{Cin} window {ph}x2 train={train} p={p}: dy {e_dy:.2e} dgamma {e_dg:.2e} dbeta {e_db:.2e}")
+    assert e_dy < 1e-5 and e_dg < 1e-5 and e_db < 1e-5
+
+
 def test_bnrelu_backward(ops, dev):
     B, C, H, W = 2, 128, 5, 6
     g = torch.Generator().manual_seed(3)

@@ -9,7 +9,7 @@ import torch
 
 transformers = pytest.importorskip("transformers")
 
-TINY = dict(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=4, intermediate_size=64,
+TINY = dict(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
             max_position_embeddings=40, projection_dim=512)
 
 

@@ -1069,6 +1069,57 @@ extern "C" int tag_bnrelu_pool_backward_bf16(const void* y, const float* scale, 
                                              C, ph, pw, pool, drop_p, seed, bn_train, ws, stream);
 }
 
+// the APPLY half of tag_bnrelu_pool_backward alone: dgamma / dbeta already hold sum(dz * xhat) / sum(dz) (folded from the partial
+// rows the dgrad conv that PRODUCED dout wrote in its epilogue: tag_conv3x3_dgrad_poolsums + tag_bn_grad_from_partials)
+template <class TS>
+static int bnrelu_pool_backward_apply_impl(const TS* y, const float* scale, const float* shift, const float* mean,
+                                           const float* invstd, const float* gamma, const TS* dout, TS* dy,
+                                           const float* dgamma, const float* dbeta, int B, int H, int W, int C, int ph, int pw,
+                                           int pool, float drop_p, uint64_t seed, int bn_train, void* stream) {
+    TAG_CHECK_ARG(y && scale && shift && mean && invstd && gamma && dout && dy && dgamma && dbeta);
+    TAG_CHECK_ARG(pool == 0 || pool == 2 || pool == 3);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    TAG_CHECK_ARG(vec_ok(C) && H / ph > 0 && W / pw > 0);
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31));
+    const bool nc8 = pool_nc8_type<TS>() && pool_nc8_ok(C) && TAG_POOL_BWD_NC8;
+    const int nb = apply_blocks((long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw), C, nc8 ? 8 : 4);
+    bool launched = false;
+#define POOL_APPLY_NC(NC_)                                                                                         \
+    {                                                                                                              \
+        PoolBwdCtx<PH, PW, TS, NC_> ctx{y, scale, shift, mean, invstd, dout, B, H, W, C, drop_p, seed, wavg, wmax}; \
+        hipLaunchKernelGGL((pool_bwd_apply_kernel<PH, PW, TS, NC_>), dim3(nb), dim3(256), 0, as_stream(stream), ctx, gamma, \
+                           dgamma, dbeta, bn_train, dy);                                                           \
+    }
+#define POOL_APPLY_BODY                                                                                            \
+    if constexpr (pool_nc8_type<TS>()) {                                                                           \
+        if (nc8) POOL_APPLY_NC(8) else POOL_APPLY_NC(4)                                                            \
+    } else POOL_APPLY_NC(4)
+    DISPATCH_POOL(2, 2, POOL_APPLY_BODY)
+    DISPATCH_POOL(1, 2, POOL_APPLY_BODY)
+    DISPATCH_POOL(1, 1, POOL_APPLY_BODY)
+    DISPATCH_POOL(2, 1, POOL_APPLY_BODY)
+#undef POOL_APPLY_BODY
+#undef POOL_APPLY_NC
+    TAG_CHECK_ARG(launched);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tag_bnrelu_pool_backward_apply(const float* y, const float* scale, const float* shift, const float* mean,
+                                              const float* invstd, const float* gamma, const float* dout, float* dy,
+                                              const float* dgamma, const float* dbeta, int B, int H, int W, int C, int ph,
+                                              int pw, int pool, float drop_p, uint64_t seed, int bn_train, void* stream) {
+    return bnrelu_pool_backward_apply_impl<float>(y, scale, shift, mean, invstd, gamma, dout, dy, dgamma, dbeta, B, H, W, C, ph,
+                                                  pw, pool, drop_p, seed, bn_train, stream);
+}
+extern "C" int tag_bnrelu_pool_backward_apply_bf16(const void* y, const float* scale, const float* shift, const float* mean,
+                                                   const float* invstd, const float* gamma, const void* dout, void* dy,
+                                                   const float* dgamma, const float* dbeta, int B, int H, int W, int C, int ph,
+                                                   int pw, int pool, float drop_p, uint64_t seed, int bn_train, void* stream) {
+    return bnrelu_pool_backward_apply_impl<bf16_t>(static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
+                                                   static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dy), dgamma, dbeta, B, H,
+                                                   W, C, ph, pw, pool, drop_p, seed, bn_train, stream);
+}
+
 template <class TS>
 static int bnrelu_backward_impl(const TS* y, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const float* gamma, const TS* da, TS* dy, float* dgamma,

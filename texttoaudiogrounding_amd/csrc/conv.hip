@@ -312,6 +312,11 @@ struct BnBwdEpi {
     const float* shift;     // beta - mean * gamma * invstd
     const float* mean;
     const float* invstd;
+    // EPI == 2 only: the gradient flows into relu(bn(yref)) -> ph x 2 pool -> dropout; yref is the UNPOOLED (B,Hf,Wf,Cout) tensor
+    int Hf, Wf, ph;
+    float wavg, wmax;       // pool_type: 'avg+max' (1/(ph*2), 1) | 'avg' (1/(ph*2), 0) | 'max' (0, 1)
+    float drop_p;
+    unsigned long long seed;
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
@@ -561,31 +566,121 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
     {
         const int c4 = lane & 3;                                // position inside the lane quad = cout offset before, pixel offset after
         const bool odd = c4 & 1, hi = c4 & 2;
+        // ---- EPI == 2 (the dgrad launch of the first conv of block i+1, whose output is the gradient of block i's POOLED output):
+        // the reduction half of the backward of relu(bn(yref)) -> avg/max pool (ph x 2) -> dropout that this gradient flows into
+        // next (models/panns.py:51-60 backward; what pool_bwd_reduce_kernel of bn_pool.hip computes in a pass of its own over the
+        // largest tensors of the step).  After the quad transpose a lane holds g = dL/d(pooled, dropped-out output) of ONE pooled
+        // pixel and 4 consecutive channels: it undoes the dropout (the forward's counter-based mask is one hash per 4 consecutive
+        // channels = exactly this lane's), loads the ph x 2 window of yref as 16-byte pieces, recomputes a = bn(yref), the ReLU mask
+        // and the arg-max (first maximum in scan order, as ATen's max_pool2d), forms dz = [a > 0] * g * (wavg + [arg-max] * wmax)
+        // and accumulates sum(dz), sum(dz * xhat) per channel.  Partial-row layout as EPI == 1 ([prow][2][Cout]);
+        // tag_bn_grad_from_partials folds the rows; pool_bwd_apply_kernel stays as the one pass that writes dy. ----
+        const int pHf = EPI == 2 ? epi.Hf : 0, pWf = EPI == 2 ? epi.Wf : 0, pph = EPI == 2 ? epi.ph : 1;
+        const bool pdrop = EPI == 2 && epi.drop_p > 0.0f;
+        const float keep_scale = pdrop ? 1.0f / (1.0f - epi.drop_p) : 1.0f;
+        const unsigned keep_thr = tag_keep4_threshold(EPI == 2 ? epi.drop_p : 0.0f);
+        const size_t rowf = (size_t)pWf * Cout;                  // one unpooled image row of yref
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int nq = n0 + wn0 + j * 32 + (ml & ~3);       // first of the quad's 4 couts
+            const int nqc = nq < Cout ? nq : 0;
+            f32x4 bsc, bsh, bmu, bis;                           // BatchNorm constants of the lane's 4 channels (EPI == 2)
+            float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* ybase = nullptr;
+            if (EPI == 2) {
+                bsc = ldg4(epi.scale + nqc); bsh = ldg4(epi.shift + nqc); bmu = ldg4(epi.mean + nqc); bis = ldg4(epi.invstd + nqc);
+                ybase = epi.yref + (size_t)img * pHf * rowf + nqc;
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nq = n0 + wn0 + j * 32 + (ml & ~3);   // first of the quad's 4 couts
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
-                    // round 1: exchange with lane c4 ^ 1 (quad_perm [1,0,3,2]): even lanes send x1 / x3, odd lanes x0 / x2
-                    const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
-                    const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
-                    const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
-                    if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
-                    // round 2: exchange with lane c4 ^ 2 (quad_perm [2,3,0,1]): low lanes send x2 / x3, high lanes x0 / x1
-                    const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
-                    const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
-                    const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
-                    if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
-                    // now x_t = cout nq + t of the pixel behind register 4 rq + c4
-                    const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
-                    const int h = h0 + m / TW, w = w0 + m % TW;
-                    if (h < H && nq < Cout)
-                        *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
+                for (int rh = 0; rh < 2; ++rh) {                // two register quads (= 2 pixels per lane) at a time
+                    f32x4 gq[2], vw[2][4];
+                    int ph_[2], pw_[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int rq = 2 * rh + u;
+                        float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
+                        // round 1: exchange with lane c4 ^ 1 (quad_perm [1,0,3,2]): even lanes send x1 / x3, odd lanes x0 / x2
+                        const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
+                        const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                        const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                        if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
+                        // round 2: exchange with lane c4 ^ 2 (quad_perm [2,3,0,1]): low lanes send x2 / x3, high lanes x0 / x1
+                        const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
+                        const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                        const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                        if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
+                        // now x_t = cout nq + t of the pixel behind register 4 rq + c4
+                        const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
+                        const int h = h0 + m / TW, w = w0 + m % TW;
+                        if (h < H && nq < Cout)
+                            *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
+                        if (EPI == 2) {
+                            gq[u] = h < H ? (f32x4){x0, x1, x2, x3} : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                            ph_[u] = h; pw_[u] = w;
+                            const int hc = h < H ? h : H - 1;
+                            const float* p = ybase + (size_t)(hc * pph) * rowf + (size_t)(2 * w) * Cout;
+                            vw[u][0] = ldg4(p);
+                            vw[u][1] = ldg4(p + Cout);
+                            if (pph == 2) { vw[u][2] = ldg4(p + rowf); vw[u][3] = ldg4(p + rowf + Cout); }
+                            else { vw[u][2] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; vw[u][3] = vw[u][2]; }
+                        }
+                    }
+                    if (EPI == 2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            f32x4 g = gq[u];
+                            if (pdrop) {
+                                const size_t oi = (((size_t)img * H + ph_[u]) * W + pw_[u]) * Cout + nqc;
+                                const uint64_t bits = tag_keep4_bits(epi.seed, (uint64_t)(oi >> 2));
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) g[t] = tag_keep4(bits, t, keep_thr) ? g[t] * keep_scale : 0.0f;
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                float a[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) a[k] = fmaf(vw[u][k][t], bsc[t], bsh[t]);
+                                if (pph != 2) { a[2] = -INFINITY; a[3] = -INFINITY; }
+                                const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                                const float gw = g[t] * epi.wavg, gwm = g[t] * (epi.wavg + epi.wmax);
+                                bool found = false;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const bool eq = a[k] == mx;
+                                    const bool hit = eq && !found;
+                                    found = found || eq;
+                                    const float dz = a[k] > 0.0f ? (hit ? gwm : gw) : 0.0f;
+                                    s1[t] += dz;
+                                    s2[t] = fmaf(dz, (vw[u][k][t] - bmu[t]) * bis[t], s2[t]);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // the next pair's loads stay behind this pair's arithmetic (registers)
+                    }
+                }
+            if (EPI == 2) {
+                // the 8 lanes that hold the same 4 channels (the quad's 4 pixels x the two lane halves) -> one partial row entry
+                f32x4 o1, o2;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float a = s1[t], b = s2[t];
+                    a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+                    b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
+                    a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
+                    b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x4E, 0xF, 0xF, true));
+                    a += __shfl_xor(a, 32, 64);
+                    b += __shfl_xor(b, 32, 64);
+                    o1[t] = a; o2[t] = b;
+                }
+                float* ps = stats + (size_t)(mt * 2 + (wid >> 1)) * 2 * Cout;
+                if (c4 == 0 && kl == 0 && nq < Cout) {
+                    *reinterpret_cast<f32x4*>(ps + nq) = o1;
+                    *reinterpret_cast<f32x4*>(ps + Cout + nq) = o2;
                 }
             }
+        }
     }
     HP_MARK(5)
     // ---- fused BatchNorm statistics of the output (training): per (64-pixel wave tile, channel) a pivot mu (the tile
@@ -1906,6 +2001,17 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
     // third workgroup of a CU fits only without the unused part of a 512-channel table)
     const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
+    if (epi && epi->ph > 0) {      // dgrad + the sums of the BatchNorm+ReLU+pool backward below it (EPI == 2)
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, 0, TW, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 2>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
+                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);
+        return;
+    }
     if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
         static bool attr_set = false;
         if (!attr_set) {
@@ -1917,7 +2023,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
                            B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);
         return;
     }
-    const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull};
 #define LAUNCH_PRO(P)                                                                                             \
     {                                                                                                             \
         static bool attr_set = false;                                                                             \
@@ -1990,9 +2096,39 @@ extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, flo
     TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
     hipStream_t st = as_stream(stream);
-    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd};
+    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull};
     const float* x = dy;
     float* y = da;
+    float* stats = bnpart;
+    const int prologue = 0;
+    const float *in_scale = nullptr, *in_shift = nullptr;
+#define EPI_PTR (&epi)
+    if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+#undef EPI_PTR
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgrad convolution of a block's FIRST conv + the reduction half of the backward of the block BELOW it: the conv's output dx
+// (B,H,W,Cout) is the gradient of relu(bn(yref)) -> pool(ph x pw, floor) -> dropout(drop_p, seed) with yref (B,Hf,Wf,Cout),
+// H = Hf / ph, W = Wf / pw (see the EPI == 2 epilogue).  bnpart: tag_conv3x3_stats_rows(B,H,W,Cout) rows of [2][Cout]
+// (sum dz | sum dz * xhat) for tag_bn_grad_from_partials; tag_bnrelu_pool_backward_apply then writes dy from dx and the sums.
+// Windows ph x 2 with ph = 1 or 2 (the Cnn8Rnn pools); other windows keep the separate reduction (tag_bnrelu_pool_backward).
+extern "C" int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, float* dx, const float* yref,
+                                          const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                          const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout, int Hf,
+                                          int Wf, int ph, int pw, int pool, float drop_p, uint64_t seed, void* stream) {
+    TAG_CHECK_ARG(dy && wpack && dx && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart);
+    TAG_CHECK_ARG(B > 0 && H > 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512);
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32) && (long)B * Hf * Wf < (1L << 31));
+    TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
+    TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H == Hf / ph && W == Wf / pw);
+    TAG_CHECK_ARG((pool == 0 || pool == 2 || pool == 3) && drop_p >= 0.0f && drop_p < 1.0f);
+    hipStream_t st = as_stream(stream);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, Hf, Wf, ph, wavg, wmax, drop_p, (unsigned long long)seed};
+    const float* x = dy;
+    float* y = dx;
     float* stats = bnpart;
     const int prologue = 0;
     const float *in_scale = nullptr, *in_shift = nullptr;

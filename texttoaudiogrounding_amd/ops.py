@@ -451,6 +451,35 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
     return da, dg, db
 
 
+#: the reduction half of the pool backward in the epilogue of the dgrad conv that PRODUCES the pooled gradient
+#: (tag_conv3x3_dgrad_poolsums) instead of a pass of its own over the largest tensors (pool_bwd_reduce_kernel)
+FUSE_POOL_BWD_SUMS = os.environ.get("TAG_FUSE_POOL_BWD", "1") != "0"
+
+
+def pool_sums_fusable(dy_in, wpack, yref, ph, pw):
+    """Can the dgrad conv of (dy_in, wpack) carry the pool-backward sums of the block below (raw output yref, window ph x pw)?
+    Exact-fp32 halo-tile shapes, windows 1x2 / 2x2."""
+    B, H, W, _ = dy_in.shape
+    return (FUSE_POOL_BWD_SUMS and dy_in.dtype == F32 and yref.dtype == F32 and wpack.dtype != torch.uint8
+            and W in (8, 16, 32, 64) and pw == 2 and ph in (1, 2) and H == yref.shape[1] // ph and W == yref.shape[2] // pw
+            and query("tag_conv3x3_stats_rows", B, H, W, yref.shape[3]) > 0)
+
+
+def conv3x3_dgrad_poolsums(dy_in, wpack, yref, st: BNStat, ph, pw, drop_p=0.0, seed=0, pool=0):
+    """dx = conv(dy_in, wpack) -- the gradient of the pooled (and dropped-out) output of the block whose second conv produced
+    yref -- and, from the conv's epilogue, the partial sums (P, buffer) of that block's BatchNorm+ReLU+pool backward
+    -> bnrelu_pool_backward(..., partials=...)."""
+    B, H, W, Cin = dy_in.shape
+    _, Hf, Wf, C = yref.shape
+    P = query("tag_conv3x3_stats_rows", B, H, W, C)
+    dx = _empty(B, H, W, C, like=dy_in)
+    part = _empty(P * 2 * C, like=dy_in)
+    with _timed(("conv3x3_halo_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+        call("tag_conv3x3_dgrad_poolsums", ptr(dy_in), ptr(wpack), ptr(dx), ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+             ptr(st.invstd), ptr(part), B, H, W, Cin, C, Hf, Wf, ph, pw, int(pool), float(drop_p), seed)
+    return dx, (P, part)
+
+
 def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
@@ -562,13 +591,23 @@ def bnact_pool(y, st: Optional[BNStat], ph, pw, act=1, pool=0, drop_p=0.0, seed=
     return out
 
 
-def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None, pool=0):
+def bnrelu_pool_backward(y, st: BNStat, gamma, dout, ph, pw, drop_p=0.0, seed=0, dg_out=None, db_out=None, pool=0,
+                         partials=None):
+    """partials = (P, buffer) from conv3x3_dgrad_poolsums: the sums were taken by the conv that produced dout; only the apply
+    pass runs here."""
     B, H, W, C = y.shape
     if dout.dtype != y.dtype:
         raise RuntimeError("bnrelu_pool_backward: y and dout must share their storage type")
     dy = _empty(B, H, W, C, like=y, dtype=y.dtype)
     dg = dg_out if dg_out is not None else _empty(C, like=y)
     db = db_out if db_out is not None else _empty(C, like=y)
+    if partials is not None:
+        P, part = partials
+        ws = _ws(query("tag_bn_grad_from_partials_ws_bytes", P, C), y)
+        call("tag_bn_grad_from_partials", ptr(part), P, C, ptr(dg), ptr(db), ptr(ws))
+        call("tag_bnrelu_pool_backward_apply" + _sfx(y), ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+             ptr(gamma), ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, int(pool), float(drop_p), seed, int(st.train))
+        return dy, dg, db
     ws = _ws(query("tag_bn_backward_ws_bytes", B * H * W, C), y)
     call("tag_bnrelu_pool_backward" + _sfx(y), ptr(y), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          ptr(dout), ptr(dy), ptr(dg), ptr(db), B, H, W, C, ph, pw, int(pool), float(drop_p), seed, int(st.train), ptr(ws))
@@ -1073,13 +1112,16 @@ class Cnn8RnnFunction(TagFunction):
         call("tag_mean_w_backward" + _sfx(dx), ptr(dxm), Bx * Tp, Wp, C, float(drop[1]), seeds[4], ptr(dx))
         # ---- conv blocks, last to first ----
         lm, st0 = sv["lm"], sv["st0"]
+        poolpart = None                            # sums of block i's pool backward, taken by block i+1's dgrad conv
         for i in range(3, -1, -1):
             x_in, y1, s1, y2, s2, wd1, wd2 = sv["acts"][i]
             c1w, g1, b1, c2w, g2, b2 = p[2 + 6 * i: 8 + 6 * i]
             o = 2 + 6 * i
             ph, pw = CNN8_POOLS[i]
             C = y2.shape[3]
-            dy2, dg2, db2 = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0], seeds[i], dg_out=sk[o + 4], db_out=sk[o + 5])
+            dy2, dg2, db2 = bnrelu_pool_backward(y2, s2, g2, dx, ph, pw, drop[0], seeds[i], dg_out=sk[o + 4], db_out=sk[o + 5],
+                                                 partials=poolpart)
+            poolpart = None
             _deliver(grads, sk, o + 4, dg2)
             _deliver(grads, sk, o + 5, db2)
             del dx
@@ -1095,7 +1137,11 @@ class Cnn8RnnFunction(TagFunction):
             _deliver(grads, sk, o + 2, db1)
             if i > 0:
                 _deliver(grads, sk, o, sw.wgrad(x_in, dy1, out=sk[o]))
-                dx = conv3x3(dy1, wd1, x_in.shape[3])
+                below = sv["acts"][i - 1]          # (x, y1, s1, y2, s2, ...) of the block whose pooled output x_in is
+                if pool_sums_fusable(dy1, wd1, below[3], *CNN8_POOLS[i - 1]):
+                    dx, poolpart = conv3x3_dgrad_poolsums(dy1, wd1, below[3], below[4], *CNN8_POOLS[i - 1], drop[0], seeds[i - 1])
+                else:
+                    dx = conv3x3(dy1, wd1, x_in.shape[3])
                 sw.release()
             else:
                 dw0, dbn0 = conv3x3_c1_backward(lm, dy1, c1w, st0.scale, st0.shift, out=sk[2],   # dbn0: (B,F,64) grad wrt bn0 output

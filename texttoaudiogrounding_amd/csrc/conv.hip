@@ -288,6 +288,12 @@ __device__ unsigned long long tag_halo_wg[4 * 65536];   // [start of the pipelin
 #ifndef TAG_HALO_STAGE128
 #define TAG_HALO_STAGE128 16
 #endif
+// -DTAG_HALO_VALU_PROBE=n (tools/run_valu_probe.sh, never in the product build): n dummy v_pk_fma_f32 per k-step beside the MFMAs --
+// does packed-fp32 VALU work issue for free in the shadow of the fp32 MFMA stream of the REAL kernel (tools/dual_issue_probe.hip
+// says the two pipes run concurrently on register operands)?
+#ifndef TAG_HALO_VALU_PROBE
+#define TAG_HALO_VALU_PROBE 0
+#endif
 template <int BN_> constexpr int halo_stage() { return 16; }
 template <int TW>
 struct HaloGeom {
@@ -448,6 +454,10 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
     // The ST / 2 k-steps of one stage (channels ST h .. ST h + ST - 1 of the chunk, one tap) from weight buffer buf; mid() runs in the
     // middle.  k-step ks = 4 g + j multiplies channel 8 g + 4 kl + j of the stage: A = element j of the lane's float4 of channel
     // group g, B = that row of the buffer.
+#if TAG_HALO_VALU_PROBE > 0
+    typedef float probe_f2 __attribute__((ext_vector_type(2)));
+    probe_f2 pacc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#endif
     auto mma_stage = [&](int buf, int shift, int h, auto&& mid) {      // shift = (ky - 1) * PW + (kx - 1) of the tap
         const float* a0 = As + (pbase[0] + shift) * G::AROW + h * ST + kl * 4;
         const float* a1 = As + (pbase[1] + shift) * G::AROW + h * ST + kl * 4;
@@ -481,6 +491,14 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks >> 2][i][ks & 3], bf[cur][j], acc[i][j], 0, 0, 0);
+#if TAG_HALO_VALU_PROBE > 0
+            {
+                const probe_f2 pa = {af[ks >> 2][0][ks & 3], af[ks >> 2][1][ks & 3]}, pb = {bf[cur][0], bf[cur][TN - 1]};
+#pragma unroll
+                for (int u = 0; u < TAG_HALO_VALU_PROBE; ++u)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pacc[u & 3]) : "v"(pa), "v"(pb));
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);                  // keeps the operand reads of k-step ks + 2 ahead of their use
             if (ks == NS / 2 - 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
         }
@@ -682,6 +700,9 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
             }
         }
     }
+#if TAG_HALO_VALU_PROBE > 0
+    if (pacc[0][0] + pacc[1][0] + pacc[2][1] + pacc[3][1] == 12345.678f) y[0] = pacc[0][0];
+#endif
     HP_MARK(5)
     // ---- fused BatchNorm statistics of the output (training): per (64-pixel wave tile, channel) a pivot mu (the tile
     // mean as rounded in fp32), r = sum(y - mu) and q = sum((y - mu)^2): the tile's sum is n*mu + r EXACTLY up to the

@@ -44,6 +44,9 @@ const char* tag_last_error(void);
  * device; [0] shader clocks and [1] 100 MHz reference ticks workgroup 0 ran for.  tag_mfma_probe_flop: the FLOP of such a launch. */
 int tag_mfma_probe(int kind, int iters, int workgroups, unsigned seed, void* clocks, void* stream);
 double tag_mfma_probe_flop(int kind, int iters, int workgroups);
+/* the VALU member of the probe family (tools/hybrid_probe.py): `workgroups` x 4 waves of v_pk_fma_f32 on register operands,
+ * iters x 32 instructions x 256 FLOP per wave; clocks as above */
+int tag_valu_probe(int iters, int workgroups, unsigned seed, void* clocks, void* stream);
 /* number of CUs of the current device (used by the host to size split-K workspaces) */
 int tag_device_cu_count(void);
 

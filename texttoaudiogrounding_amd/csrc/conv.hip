@@ -2021,7 +2021,11 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     magic((unsigned)row_tiles, &rt_mul, &rt_shr);
     // patch + weight buffer(s) + the producer BatchNorm table [2][Cin] (sized by Cin: at 64 cout with two weight buffers the
     // third workgroup of a CU fits only without the unused part of a 512-channel table)
-    const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float);
+    // TAG_HALO_LDS_PAD (environment, experiments only: tools/hybrid_probe.py): extra dynamic LDS per workgroup, i.e. FEWER workgroups
+    // per CU, to leave registers for waves of another kernel
+    static int lds_pad = -1;
+    if (lds_pad < 0) { const char* e = getenv("TAG_HALO_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float) + (size_t)lds_pad;
     if (epi && epi->ph > 0) {      // dgrad + the sums of the BatchNorm+ReLU+pool backward below it (EPI == 2)
         static bool attr_set = false;
         if (!attr_set) {

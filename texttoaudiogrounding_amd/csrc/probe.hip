@@ -76,7 +76,49 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(unsigned long long* __r
     }
 }
 
+// Packed-fp32 VALU loop (v_pk_fma_f32 on 16 independent float2 accumulators, registers only), 4 waves per workgroup: the partner of
+// tools/hybrid_probe.py, which runs it on a second stream BESIDE a real MFMA convolution to see what the two pipes deliver together.
+__global__ __launch_bounds__(256) void valu_probe_kernel(unsigned long long* __restrict__ clocks, int iters, unsigned seed) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x2 acc[16], a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned ra = mix32(seed + threadIdx.x * 16 + u), rb = mix32(ra + 0x9e3779b9u);
+        a[u] = (f32x2){__uint_as_float((ra & 0x81ffffffu) | 0x3c000000u), __uint_as_float((rb & 0x81ffffffu) | 0x3c000000u)};
+        b[u] = (f32x2){__uint_as_float((rb & 0x80ffffffu) | 0x3c000000u), __uint_as_float((ra & 0x80ffffffu) | 0x3c000000u)};
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[u & 15]) : "v"(a[u & 3]), "v"(b[(u >> 2) & 3]));
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= 0.001f;
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1];
+    if (s == 12345.678f) clocks[2] = (unsigned long long)s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = __builtin_amdgcn_s_memtime() - t0;
+        clocks[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 }  // namespace
+
+// kind 4 of the probe family: the VALU loop above; FLOP of a launch = workgroups * 4 waves * iters * 32 * 256
+extern "C" int tag_valu_probe(int iters, int workgroups, unsigned seed, void* clocks, void* stream) {
+    TAG_CHECK_ARG(iters > 0 && workgroups > 0 && clocks);
+    hipLaunchKernelGGL(valu_probe_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long*>(clocks), iters, seed);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" double tag_mfma_probe_flop(int kind, int iters, int workgroups) {
     const double per_mfma = kind < 2 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;

@@ -29,6 +29,7 @@ _SIGS = {
     "tag_device_cu_count": (c_int, []),
     "tag_mfma_probe": (c_int, [c_int, c_int, c_int, ctypes.c_uint, P, P]),
     "tag_mfma_probe_flop": (c_double, [c_int, c_int, c_int]),
+    "tag_valu_probe": (c_int, [c_int, c_int, ctypes.c_uint, P, P]),
     "tag_stream_create_cu_mask": (c_int, [P, c_int, P]),
     "tag_logmel_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "tag_bn_stats_ws_bytes": (c_size_t, [c_long, c_int]),

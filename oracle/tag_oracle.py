@@ -283,7 +283,7 @@ def _imposed_max_pool(a, pool_size, index):
     return torch.gather(win, 4, index.long().unsqueeze(-1)).squeeze(-1)
 
 
-def conv_block(x, st, prefix, pool_size, training, taps=None, decisions=None):
+def conv_block(x, st, prefix, pool_size, training, taps=None, decisions=None, bn_training=None):
     """ConvBlock.forward with pool_type='avg+max' (models/panns.py:46-62).
 
     decisions (test aid, tests/test_gpu_path.py): the hard decisions of ANOTHER implementation imposed on this one -- keys
@@ -291,11 +291,12 @@ def conv_block(x, st, prefix, pool_size, training, taps=None, decisions=None):
     fp32 implementations whose BatchNorm outputs differ by round-off can take different sides of a ReLU / arg-max whose operands
     are closer than that round-off; with the decisions imposed the remaining difference is round-off only."""
     dec = decisions or {}
+    bn_training = training if bn_training is None else bn_training      # Cnn8Rnn(freeze_bn=True): BatchNorm in eval mode while training
     y1 = F.conv2d(x, st[prefix + "conv1.weight"], None, 1, 1)
-    b1 = _bn(y1, st, prefix + "bn1.", training)
+    b1 = _bn(y1, st, prefix + "bn1.", bn_training)
     a1 = b1 * dec["relu/" + prefix + "bn1"].to(b1.dtype) if "relu/" + prefix + "bn1" in dec else F.relu(b1)
     y2 = F.conv2d(a1, st[prefix + "conv2.weight"], None, 1, 1)
-    b2 = _bn(y2, st, prefix + "bn2.", training)
+    b2 = _bn(y2, st, prefix + "bn2.", bn_training)
     a2 = b2 * dec["relu/" + prefix + "bn2"].to(b2.dtype) if "relu/" + prefix + "bn2" in dec else F.relu(b2)
     mx = (_imposed_max_pool(a2, pool_size, dec["argmax/" + prefix]) if "argmax/" + prefix in dec
           else F.max_pool2d(a2, kernel_size=pool_size))
@@ -314,20 +315,22 @@ def output_length(waveform_len, hop_length: int, downsample_ratio: int = 4) -> t
 
 
 def cnn8rnn_forward(st, waveform, waveform_len, training=False, p_drop=(0.2, 0.5),
-                    masks=None, taps=None, prefix="audio_encoder."):
-    """Cnn8Rnn.forward with specaug=False and no mixup (models/audio_encoder.py:178-232)."""
+                    masks=None, taps=None, prefix="audio_encoder.", bn_training=None):
+    """Cnn8Rnn.forward with specaug=False and no mixup (models/audio_encoder.py:178-232).  bn_training=False with training=True is
+    Cnn8Rnn(freeze_bn=True).train() (models/audio_encoder.py:159-169: every BatchNorm module stays in eval mode)."""
+    bn_training = training if bn_training is None else bn_training
     x = logmel(waveform, "cnn8rnn")                   # (B, 64, F)
     if taps is not None:
         taps["logmel"] = x
     x = x.transpose(1, 2).unsqueeze(1)                # (B, 1, F, 64)
     x = x.transpose(1, 3)
-    x = _bn(x, st, prefix + "bn0.", training)
+    x = _bn(x, st, prefix + "bn0.", bn_training)
     x = x.transpose(1, 3)
     if taps is not None:
         taps["bn0"] = x
     pools = [(2, 2), (2, 2), (1, 2), (1, 2)]
     for i, ps in enumerate(pools, start=1):
-        x = conv_block(x, st, f"{prefix}conv_block{i}.", ps, training, taps, decisions=masks)
+        x = conv_block(x, st, f"{prefix}conv_block{i}.", ps, training, taps, decisions=masks, bn_training=bn_training)
         x = _dropout(x, p_drop[0], training, masks, f"drop{i}")
     x = torch.mean(x, dim=3)                          # (B, 512, T')
     x = x.transpose(1, 2)
@@ -594,10 +597,12 @@ def align_dot_product(audio, text, l2norm=False, scaled=False):
 
 
 def biencoder_forward(st, batch, match="dot", audio="cnn8rnn", training=False, p_drop=None,
-                      masks=None, taps=None):
+                      masks=None, taps=None, bn_training=None):
     """BiEncoder.forward (models/audio_text_model.py:58-98), cross_encoder=None, upsample=False."""
     if audio == "cnn8rnn":
         kw = {} if p_drop is None else {"p_drop": p_drop}
+        if bn_training is not None:
+            kw["bn_training"] = bn_training
         ao = cnn8rnn_forward(st, batch["waveform"], batch["waveform_len"], training, masks=masks,
                              taps=taps, **kw)
     else:
@@ -642,9 +647,9 @@ def frame_bce_loss(frame_sim, label, length):
 
 
 def train_step_loss(st, batch, match="dot", audio="cnn8rnn", training=True, p_drop=None,
-                    masks=None, taps=None):
+                    masks=None, taps=None, bn_training=None):
     """zero_grad -> forward -> FrameBceLoss, the timed unit of BASELINE.md section 3."""
-    out = biencoder_forward(st, batch, match, audio, training, p_drop, masks, taps)
+    out = biencoder_forward(st, batch, match, audio, training, p_drop, masks, taps, bn_training)
     out = runner_truncate(out, batch["label"])
     return frame_bce_loss(out["frame_sim"], out["label"], out["length"]), out
 

@@ -333,6 +333,60 @@ def test_proj_expnegl2_dropout_replay_vs_oracle(dev, seed, monkeypatch):
           f"worst error plain {worst_plain:.2e}, with the HIP decisions imposed {worst_imposed:.2e}")
 
 
+@pytest.mark.parametrize("freeze_cnn", [False, True])
+def test_frozen_batchnorm_and_frozen_cnn_train_step(dev, golden_dir, freeze_cnn):
+    """The reference's fine-tuning switches (models/audio_encoder.py:90-97,159-169): Cnn8Rnn(freeze_bn=True).train() keeps every
+    BatchNorm in eval mode (running statistics normalise, nothing is updated) while dropout stays on; freeze_cnn=True additionally
+    freezes everything below the GRU.  One training step (dropout off for a mask-free comparison) against the fp64 oracle with
+    bn_training=False: loss, every trainable gradient, running statistics and counters untouched, frozen parameters without a
+    gradient -- and with the CNN frozen the engine skips the conv stack's backward altogether."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.models import audio_encoder, audio_text_model, match as match_mod, text_encoder
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    gold = np.load(f"{golden_dir}/cnn8rnn_dot_eval.npz")
+    st = gold_state(gold)                              # calibrated running statistics: eval-mode BatchNorm is well conditioned
+    batch = make_batch(320)
+    model = audio_text_model.BiEncoder(audio_encoder.Cnn8Rnn(32000, freeze_cnn=freeze_cnn, freeze_bn=True),
+                                       text_encoder.EmbeddingAgg(5221, 512), match_mod.DotProduct(), 512)
+    model.load_state_dict(st, strict=False)
+    model = model.to(dev).train()
+    ae = model.audio_encoder
+    assert ae.training and not ae.bn0.training and not ae.conv_block3.bn2.training
+    ae.dropout_p = (0.0, 0.0)
+    before = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    launched = []
+    orig = ops.conv3x3_wgrad
+    ops.conv3x3_wgrad = lambda *a, **k: (launched.append(1), orig(*a, **k))[1]
+    try:
+        runner = StrongRunner(model, device=str(dev))
+        loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    finally:
+        ops.conv3x3_wgrad = orig
+    assert (len(launched) == 0) == freeze_cnn          # frozen CNN: not one weight-gradient conv was launched
+    grads = {}
+    for dt in (torch.float64, torch.float32):
+        st_o = O.state_to(st, dt, requires_grad=True)
+        bo = dict(batch)
+        bo["waveform"], bo["label"] = batch["waveform"].to(dt), batch["label"].to(dt)
+        oloss, _ = O.train_step_loss(st_o, bo, "dot", "cnn8rnn", True, (0.0, 0.0), bn_training=False)
+        oloss.backward()
+        grads[dt] = {k: v.grad.double() for k, v in st_o.items() if v.is_floating_point() and v.grad is not None}
+        if dt == torch.float64:
+            assert abs(loss.item() - oloss.item()) < 2e-5
+    for name, p in model.named_parameters():
+        frozen = freeze_cnn and name.startswith("audio_encoder.") and ".rnn." not in name
+        assert p.requires_grad != frozen
+        if frozen:
+            assert p.grad is None
+            continue
+        g64, g32 = grads[torch.float64][name], grads[torch.float32][name]
+        scale = g64.abs().max().item() + 1e-30
+        err = (p.grad.cpu().double() - g64).abs().max().item() / scale
+        assert_grad_close(name, err, (g32 - g64).abs().max().item() / scale)
+    after = model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items())          # eval-mode BatchNorm updates nothing
+
+
 def test_full_length_frame_sim_and_segments(dev, conv_math):
     """BASELINE clip length (10 s @ 32 kHz -> T'=250), eval mode, B=3 ragged: frame_sim within 1e-4 of the
     CPU oracle and bit-exact integer segments at all 50 thresholds (n_connect 13 @ 0.04 s)."""

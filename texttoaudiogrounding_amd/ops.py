@@ -1105,6 +1105,11 @@ class Cnn8RnnFunction(TagFunction):
             # this stream (never beside the spinning GRU workgroups: the collective is ordered after them)
             _ready(prm[26:36])
             _flush()
+        if not any(ctx.needs_input_grad[2:28]):
+            # Cnn8Rnn(freeze_cnn=True) (models/audio_encoder.py:164-168: everything but the GRU frozen): no parameter below the
+            # GRU takes a gradient and the waveform never does -- the conv stack's backward (97 % of the step) is not run
+            sw.join()
+            return (None, None, *grads)
         dxm = gemm(dfc, fc_w, M, fc_w.shape[1], fc_w.shape[0])
         x_last = sv["x_last"]
         Bx, Tp, Wp, C = x_last.shape

@@ -237,6 +237,13 @@ int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, float* dx, c
                                const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B, int H,
                                int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool, float drop_p, uint64_t seed,
                                void* stream);
+/* bf16-storage twin (BASELINE configs[2] mode): the sums are taken from the bf16 values of dx the apply pass will read back; rows:
+ * tag_conv3x3_dgrad_poolsums_bf16_rows (0 = shape not served: keep tag_bnrelu_pool_backward_bf16) */
+int tag_conv3x3_dgrad_poolsums_bf16_rows(int B, int H, int W, int Cin, int Cout);
+int tag_conv3x3_dgrad_poolsums_bf16(const void* dy, const void* wpack, void* dx, const void* yref, const float* bn_scale,
+                                    const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B,
+                                    int H, int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool, float drop_p,
+                                    uint64_t seed, void* stream);
 int tag_bnrelu_pool_backward_apply(const float* y, const float* scale, const float* shift, const float* mean,
                                    const float* invstd, const float* gamma, const float* dout, float* dy, const float* dgamma,
                                    const float* dbeta, int B, int H, int W, int C, int ph, int pw, int pool, float drop_p,

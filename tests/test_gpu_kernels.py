@@ -600,6 +600,45 @@ def test_conv_dgrad_fused_pool_backward_sums(ops, dev, B, Hf, Wf, Cin, C, ph, tr
     assert e_dy < 1e-5 and e_dg < 1e-5 and e_db < 1e-5
 
 
+@pytest.mark.parametrize("B,Hf,Wf,Cin,C,ph,p", [(2, 36, 16, 256, 128, 2, 0.2), (2, 21, 16, 512, 256, 1, 0.2), (3, 250, 16, 512, 256, 1, 0.2),
+                                               (2, 70, 64, 128, 64, 2, 0.2), (1, 35, 32, 256, 128, 2, 0.0), (2, 500, 32, 256, 128, 2, 0.2)])
+def test_conv_dgrad_fused_pool_backward_sums_bf16(ops, dev, B, Hf, Wf, Cin, C, ph, p):
+    """The bf16-storage twin (BASELINE configs[2] mode): tag_conv3x3_dgrad_poolsums_bf16 takes the sums from the bf16 tile it stages
+    for its own output -- the very values the two-pass kernels read back from HBM -- so dgamma / dbeta agree with the two-pass
+    kernels to fp32 summation round-off and dy (bf16) is identical up to the rare element whose fp32 value sits on a bf16 rounding
+    boundary.  The conv output itself is bit-identical to the plain dgrad launch."""
+    pw = 2
+    H, W = Hf // ph, Wf // pw
+    g = torch.Generator().manual_seed(Hf * Wf + C)
+    y = bf(torch.randn(B, Hf, Wf, C, generator=g) * (1.0 + torch.arange(C).view(1, 1, 1, C) % 5) + 0.3).to(dev)
+    w = torch.randn(Cin, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    du = bf(torch.randn(B, H, W, Cin, generator=g)).to(dev)
+    st = ops.bn_stats(y.float().view(-1, C), gamma, beta, None, None, True)
+    seed = 777
+    old, old_sw = ops.CONV_MATH, ops.FUSE_POOL_BWD_SUMS_BF16
+    ops.CONV_MATH, ops.FUSE_POOL_BWD_SUMS_BF16 = "bf16", True        # off by default (measured neutral): exercised here
+    try:
+        _, wdg = ops.pack_conv_weight(w.to(dev), W=W)
+        if not ops.pool_sums_fusable(du, wdg, y, ph, pw):
+            pytest.skip("this shape goes to the row-streaming kernel: two-pass pool backward")
+        dx, part = ops.conv3x3_dgrad_poolsums(du, wdg, y, st, ph, pw, p, seed)
+        dx_plain = ops.conv3x3(du, wdg, C)
+    finally:
+        ops.CONV_MATH, ops.FUSE_POOL_BWD_SUMS_BF16 = old, old_sw
+    assert dx.dtype == torch.bfloat16 and torch.equal(dx, dx_plain)
+    dy, dg, db = ops.bnrelu_pool_backward(y, st, gamma, dx, ph, pw, p, seed, partials=part)
+    dy2, dg2, db2 = ops.bnrelu_pool_backward(y, st, gamma, dx, ph, pw, p, seed)
+    e_g, e_b = relerr(dg, dg2.cpu().double()), relerr(db, db2.cpu().double())
+    diff = (dy.float() != dy2.float()).float().mean().item()
+    print(f"bf16 fused pool sums {B}x{Hf}x{Wf} {C}<-{Cin} window {ph}x2 p={p}: dgamma {e_g:.2e} dbeta {e_b:.2e}, dy elements differing {diff:.2e}")
+    assert e_g < 5e-6 and e_b < 5e-6 and diff < 5e-4
+    # an element differs only where the 1e-7 relative difference of the folded sums moves its fp32 value across a bf16 rounding
+    # boundary: by one bf16 ulp of the value, or -- where dy is a near-cancellation of its three terms -- by 1e-5 of the tensor's range
+    d, r = (dy.float() - dy2.float()).abs().cpu().double(), dy2.float().abs().cpu().double()
+    assert bool((d <= r * 2.0 ** -7 + 1e-5 * r.max()).all())
+
+
 def test_bnrelu_backward(ops, dev):
     B, C, H, W = 2, 128, 5, 6
     g = torch.Generator().manual_seed(3)

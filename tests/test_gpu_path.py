@@ -1099,6 +1099,35 @@ def test_fp32_step_with_the_wgrad_side_stream_switched_on(dev, monkeypatch, cu_s
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
 
 
+def test_bf16_mode_pool_sum_fusion_switch(dev, monkeypatch):
+    """TAG_FUSE_POOL_BWD_BF16=1 (off by default: measured level in step time, docs/experiments_r05.md) through a whole bf16-mode
+    training step: the forward is untouched (loss identical) and every gradient tensor agrees with the two-pass pool backward up to
+    the bf16 rounding ties the 1e-7 differences of the folded sums can flip (cosine >= 0.99999, norms within 1e-3)."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=3, logit_gain=40.0)
+    batch = O.synthetic_batch(4, 160000, seed=8, ragged=True)
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    monkeypatch.setattr(ops, "ACT_DTYPE", "bf16")
+    res, fused_calls = [], []
+    orig = ops.conv3x3_dgrad_poolsums
+    monkeypatch.setattr(ops, "conv3x3_dgrad_poolsums", lambda *a, **k: (fused_calls.append(a[0].dtype), orig(*a, **k))[1])
+    for on in (False, True):
+        monkeypatch.setattr(ops, "FUSE_POOL_BWD_SUMS_BF16", on)
+        torch.manual_seed(123)
+        model = build_hip_model(st, "dot", dev).train()
+        runner = StrongRunner(model, device=str(dev))
+        loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        res.append((runner.loss_value(loss), {n: p.grad.detach().double().cpu().flatten().clone() for n, p in model.named_parameters()}))
+        assert (len(fused_calls) > 0) == on
+    assert fused_calls and all(d == torch.bfloat16 for d in fused_calls)
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        a, b = res[0][1][n], res[1][1][n]
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        assert cos >= 0.99999 and abs(a.norm() - b.norm()) <= 1e-3 * a.norm(), (n, cos, a.norm().item(), b.norm().item())
+
+
 def test_env_switches_are_parsed_defensively(monkeypatch):
     from texttoaudiogrounding_amd import ops
     monkeypatch.setenv("TAG_WGRAD_CU_SKIP", "two")

@@ -144,14 +144,21 @@ struct BnBwdEpiX {
     const float* shift;     // beta - mean * gamma * invstd
     const float* mean;
     const float* invstd;
+    // EPI == 2 only (conv.hip, EPI == 2): the gradient flows into relu(bn(yref)) -> ph x 2 pool -> dropout; yref is the UNPOOLED
+    // (B,Hf,Wf,Cout) tensor
+    int Hf, Wf, ph;
+    float wavg, wmax, drop_p;
+    unsigned long long seed;
 };
 
 // WM = waves along M: 1 (4 waves side by side along N: tile MB*32 px x 128 co) or 2 (2 x 2 waves: tile 2*MB*32 px x 64 co).
 // MB = 2, WM = 2 is the 128 px x 64 co tile of the 64-cout layers; the bf16-storage launches take MB = 4, WM = 2
 // (256 px x 64 co) there: with one product per operand pair a 128 x 64 tile is 2 chunks x 18 short steps of work behind a
 // full HBM round trip (MFMA busy 0.17-0.20), the larger tile halves the fixed cost per output and the weight re-reads.
+// (EPI == 2 on the 64-cout tiles asks for the 4 waves per SIMD the instance's main loop runs at -- 117 VGPRs -- so that the pool-sum
+// epilogue, which alone would take 150, is fitted into that budget instead of costing the whole kernel a wave of occupancy)
 template <int MB, int PRO, int TW, int NP, class TS = float, int EPI = 0, int WM = (MB == 4 ? 1 : 2)>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict__ x, const u32x4* __restrict__ wp,
+__global__ __launch_bounds__(256, (EPI == 2 && MB == 2) ? 4 : (EPI == 2 ? 3 : 2)) void conv3x3_x3_kernel(const TS* __restrict__ x, const u32x4* __restrict__ wp,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, TS* __restrict__ y,
                                                             float* __restrict__ stats, BnBwdEpiX epi, int B, int H, int W,
@@ -408,6 +415,104 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const TS* __restrict
             if (TAG_X3_ABL != 1 && TAG_X3_ABL != 4 && h < H)
                 *reinterpret_cast<u32x4*>(y + (((size_t)img * H + h) * W + tx) * Cout + n0 + c8 * 8) =
                     *reinterpret_cast<const u32x4*>(smem + pm * OROWB + c8 * 16);
+        }
+    }
+    // ---- EPI == 2 (bf16 storage; the dgrad launch of a block's FIRST conv, whose output is the gradient of the pooled output of the
+    // block below): the reduction half of the backward of relu(bn(yref)) -> avg/max pool (ph x 2) -> dropout (conv.hip, EPI == 2;
+    // what pool_bwd_reduce_kernel computes in a pass of its own).  The output tile is still in LDS as the bf16 values the apply pass
+    // will read back from HBM: a thread takes (pixel, channel octet) pieces of it -- its octet is FIXED (256 % pieces-per-pixel == 0),
+    // so the 8 + 8 running sums stay in registers over its pieces --, undoes the dropout (two hashes per piece), loads the ph x 2
+    // window of yref as 16-byte pieces, recomputes a = bn(yref), ReLU mask and first-maximum arg-max, and accumulates sum(dz),
+    // sum(dz * xhat); the threads of an octet are folded through LDS in a fixed order: ONE partial row per workgroup m-tile. ----
+    if constexpr (EPI == 2) {
+        static_assert(LDS_EPI, "the pool-backward sums read the staged bf16 tile");
+        constexpr int TP = WM * MB * 32, PPP = BN_ / 8, NPC = TP * PPP / 256;
+        const int c8 = tid % PPP, nb = n0 + c8 * 8;
+        float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = epi.scale[nb + e]; sh[e] = epi.shift[nb + e]; mu[e] = epi.mean[nb + e]; is[e] = epi.invstd[nb + e];
+            s1[e] = 0.0f; s2[e] = 0.0f;
+        }
+        const int Hf = epi.Hf, Wf = epi.Wf, ph = epi.ph;
+        const size_t rowf = (size_t)Wf * Cout;
+        const bf16_t* ybase = epi.yref + (size_t)img * Hf * rowf + nb;
+        const bool drop = epi.drop_p > 0.0f;
+        const float keep_scale = drop ? 1.0f / (1.0f - epi.drop_p) : 1.0f;
+        const unsigned keep_thr = tag_keep4_threshold(epi.drop_p);
+        auto bfe = [](const u32x4& w, int e) {                    // element e (0..7) of 8 packed bf16 (e is a compile-time constant)
+            const unsigned d = w[e >> 1];
+            return (e & 1) ? tag_bf16_hi(d) : tag_bf16_lo(d);
+        };
+        // pieces per iteration: 2 (8 window loads in flight) where the main loop's own register count leaves room for them at the
+        // same occupancy (128-cout tiles: 143 VGPRs, 3 waves per SIMD up to 170), 1 for the 64-cout tiles (117 VGPRs: 4 waves up to 128)
+        constexpr int PB = MB == 4 ? 2 : 1;
+#pragma unroll 1
+        for (int k2 = 0; k2 < NPC; k2 += PB) {                    // (a real loop, not unrolled: registers)
+            u32x4 vw[PB][4], gq[PB];
+            int hh[PB], ww[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int piece = tid + 256 * (k2 + u);
+                const int pm = piece / PPP;
+                int ty, tx;
+                pix_to_yx<TW>(pm, ty, tx);
+                hh[u] = h0 + ty; ww[u] = tx;
+                const int hc = hh[u] < H ? hh[u] : H - 1;
+                gq[u] = *reinterpret_cast<const u32x4*>(smem + pm * OROWB + c8 * 16);
+                if (hh[u] >= H) gq[u] = (u32x4){0u, 0u, 0u, 0u};
+                const bf16_t* pw = ybase + (size_t)(hc * ph) * rowf + (size_t)(2 * tx) * Cout;
+                vw[u][0] = *reinterpret_cast<const u32x4*>(pw);
+                vw[u][1] = *reinterpret_cast<const u32x4*>(pw + Cout);
+                if (ph == 2) {
+                    vw[u][2] = *reinterpret_cast<const u32x4*>(pw + rowf);
+                    vw[u][3] = *reinterpret_cast<const u32x4*>(pw + rowf + Cout);
+                } else { vw[u][2] = (u32x4){0u, 0u, 0u, 0u}; vw[u][3] = vw[u][2]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                uint64_t bits[2] = {~0ull, ~0ull};
+                if (drop) {
+                    const size_t oi = (((size_t)img * H + hh[u]) * W + ww[u]) * Cout + nb;
+                    bits[0] = tag_keep4_bits(epi.seed, (uint64_t)(oi >> 2));
+                    bits[1] = tag_keep4_bits(epi.seed, (uint64_t)(oi >> 2) + 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g = bfe(gq[u], e);
+                    if (drop) g = tag_keep4(bits[e >> 2], e & 3, keep_thr) ? g * keep_scale : 0.0f;
+                    float v[4], a[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[k] = bfe(vw[u][k], e); a[k] = fmaf(v[k], sc[e], sh[e]); }
+                    if (ph != 2) { a[2] = -INFINITY; a[3] = -INFINITY; }
+                    const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                    const float gw = g * epi.wavg, gwm = g * (epi.wavg + epi.wmax);
+                    bool found = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool eq = a[k] == mx;
+                        const bool hit = eq && !found;
+                        found = found || eq;
+                        const float dz = a[k] > 0.0f ? (hit ? gwm : gw) : 0.0f;
+                        s1[e] += dz;
+                        s2[e] = fmaf(dz, (v[k] - mu[e]) * is[e], s2[e]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                    // the next pair's loads stay behind this pair's arithmetic (registers)
+        }
+        __syncthreads();                                          // every thread is done reading the staged tile
+        float* red = reinterpret_cast<float*>(smem);              // [256][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < BN_) {
+            const int oc = tid >> 3, e = tid & 7;
+            float a = 0.0f, b = 0.0f;
+            for (int j = 0; j < 256 / PPP; ++j) { a += red[(j * PPP + oc) * 16 + e]; b += red[(j * PPP + oc) * 16 + 8 + e]; }
+            float* ps = stats + (size_t)mt * 2 * Cout;
+            ps[n0 + tid] = a;
+            ps[Cout + n0 + tid] = b;
         }
     }
     XP_MARK(7)
@@ -950,6 +1055,19 @@ void launch_x3(const TS* x, const u32x4* wp, int pro, const float* s, const floa
         hipLaunchKernelGGL((conv3x3_x3_kernel<MB, P, TW, NP, TS, 0, WM>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, \
                            BnBwdEpiX{}, B, H, W, Cin, Cout);                                                        \
     }
+    if constexpr (NP == 1 && Act<TS>::is_bf16 && TAG_X3_LDS_EPI) {
+        if (epi && epi->ph > 0) {                                 // dgrad + the pool-backward sums of the block below (EPI == 2)
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<MB, 0, TW, NP, TS, 2, WM>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv3x3_x3_kernel<MB, 0, TW, NP, TS, 2, WM>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats,
+                               *epi, B, H, W, Cin, Cout);
+            return;
+        }
+    }
     if constexpr (NP == 1 && Act<TS>::is_bf16) {
         if (epi) {                                                // dgrad + BatchNorm-backward sums (prologue 0 only)
             static bool attr_set = false;
@@ -1128,7 +1246,39 @@ extern "C" int tag_conv3x3_dgrad_bnsums_bf16(const void* dy, const void* wpack, 
         TAG_LAUNCH_CHECK();
         return 0;
     }
-    const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd};
+    const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull};
+    if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
+    else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16 twin of tag_conv3x3_dgrad_poolsums (conv.hip): partial rows P = tag_conv3x3_dgrad_poolsums_bf16_rows (one per workgroup
+// m-tile), 0 = this shape is not served (the row-streaming kernel of conv_rows.hip takes it, or the staged-tile epilogue is off):
+// the caller keeps the two-pass pool backward.
+extern "C" int tag_conv3x3_dgrad_poolsums_bf16_rows(int B, int H, int W, int Cin, int Cout) {
+    if (!(W == 8 || W == 16 || W == 32 || W == 64) || !TAG_X3_LDS_EPI) return 0;
+    if (Cin % 32 != 0 || Cout % 64 != 0 || Cin > 512) return 0;
+    if (tag_conv_rows_takes(H, W, Cin, Cout, 0)) return 0;
+    const int th = (Cout % 128 == 0 ? 128 : 64 * TAG_X3_BF16_MB64) / W;
+    return B * ((H + th - 1) / th);
+}
+extern "C" int tag_conv3x3_dgrad_poolsums_bf16(const void* dy, const void* wpack, void* dx, const void* yref,
+                                               const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                               const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
+                                               int Hf, int Wf, int ph, int pw, int pool, float drop_p, uint64_t seed, void* stream) {
+    TAG_CHECK_ARG(dy && wpack && dx && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && B > 0 && H > 0);
+    TAG_CHECK_ARG(tag_conv3x3_dgrad_poolsums_bf16_rows(B, H, W, Cin, Cout) > 0);
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 2 < (1L << 32) && (long)B * Hf * Wf < (1L << 31));
+    TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H == Hf / ph && W == Wf / pw);
+    TAG_CHECK_ARG((pool == 0 || pool == 2 || pool == 3) && drop_p >= 0.0f && drop_p < 1.0f);
+    hipStream_t st = as_stream(stream);
+    const u32x4* wp = reinterpret_cast<const u32x4*>(wpack);
+    const bf16_t* xi = static_cast<const bf16_t*>(dy);
+    bf16_t* yo = static_cast<bf16_t*>(dx);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    const BnBwdEpiX epi{static_cast<const bf16_t*>(yref), bn_scale, bn_shift, bn_mean, bn_invstd, Hf, Wf, ph, wavg, wmax, drop_p,
+                        (unsigned long long)seed};
     if (Cout % 128 == 0) launch_x3_w<4, 1, bf16_t>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
     else launch_x3_w<TAG_X3_BF16_MB64, 1, bf16_t, 2>(xi, wp, 0, nullptr, nullptr, yo, bnpart, B, H, W, Cin, Cout, st, &epi);
     TAG_LAUNCH_CHECK();

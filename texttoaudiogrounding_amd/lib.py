@@ -48,6 +48,8 @@ _SIGS = {
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_dgrad_bnsums": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_dgrad_poolsums": (c_int, [P] * 9 + [c_int] * 10 + [c_float, c_uint64, P]),
+    "tag_conv3x3_dgrad_poolsums_bf16_rows": (c_int, [c_int] * 5),
+    "tag_conv3x3_dgrad_poolsums_bf16": (c_int, [P] * 9 + [c_int] * 10 + [c_float, c_uint64, P]),
     "tag_bnrelu_pool_backward_apply": (c_int, [P] * 10 + [c_int] * 7 + [c_float, c_uint64, c_int, P]),
     "tag_bnrelu_pool_backward_apply_bf16": (c_int, [P] * 10 + [c_int] * 7 + [c_float, c_uint64, c_int, P]),
     "tag_bn_grad_from_partials_ws_bytes": (c_size_t, [c_int, c_int]),

@@ -454,14 +454,23 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
 #: the reduction half of the pool backward in the epilogue of the dgrad conv that PRODUCES the pooled gradient
 #: (tag_conv3x3_dgrad_poolsums) instead of a pass of its own over the largest tensors (pool_bwd_reduce_kernel)
 FUSE_POOL_BWD_SUMS = os.environ.get("TAG_FUSE_POOL_BWD", "1") != "0"
+#: the same for the bf16-storage kernels (tag_conv3x3_dgrad_poolsums_bf16): built and tested, OFF by default -- the bf16 convs are
+#: HBM / power-bound, the epilogue's window reads are not hidden there and the step time is level (10.62 vs 10.62-10.70 ms) while the
+#: conv family's own time grows by what the removed pass cost (docs/experiments_r05.md)
+FUSE_POOL_BWD_SUMS_BF16 = os.environ.get("TAG_FUSE_POOL_BWD_BF16", "0") != "0"
 
 
 def pool_sums_fusable(dy_in, wpack, yref, ph, pw):
     """Can the dgrad conv of (dy_in, wpack) carry the pool-backward sums of the block below (raw output yref, window ph x pw)?
     Exact-fp32 halo-tile shapes, windows 1x2 / 2x2."""
-    B, H, W, _ = dy_in.shape
-    return (FUSE_POOL_BWD_SUMS and dy_in.dtype == F32 and yref.dtype == F32 and wpack.dtype != torch.uint8
-            and W in (8, 16, 32, 64) and pw == 2 and ph in (1, 2) and H == yref.shape[1] // ph and W == yref.shape[2] // pw
+    B, H, W, Cin = dy_in.shape
+    if not (FUSE_POOL_BWD_SUMS and W in (8, 16, 32, 64) and pw == 2 and ph in (1, 2) and H == yref.shape[1] // ph
+            and W == yref.shape[2] // pw):
+        return False
+    if dy_in.dtype == BF16:       # BASELINE configs[2] mode: the one-product bf16 tile kernel with the staged output tile
+        return (FUSE_POOL_BWD_SUMS_BF16 and yref.dtype == BF16 and wpack.dtype == torch.uint8 and getattr(wpack, "products", 0) == 1
+                and query("tag_conv3x3_dgrad_poolsums_bf16_rows", B, H, W, Cin, yref.shape[3]) > 0)
+    return (dy_in.dtype == F32 and yref.dtype == F32 and wpack.dtype != torch.uint8
             and query("tag_conv3x3_stats_rows", B, H, W, yref.shape[3]) > 0)
 
 
@@ -471,6 +480,14 @@ def conv3x3_dgrad_poolsums(dy_in, wpack, yref, st: BNStat, ph, pw, drop_p=0.0, s
     -> bnrelu_pool_backward(..., partials=...)."""
     B, H, W, Cin = dy_in.shape
     _, Hf, Wf, C = yref.shape
+    if dy_in.dtype == BF16:
+        P = query("tag_conv3x3_dgrad_poolsums_bf16_rows", B, H, W, Cin, C)
+        dx = _empty(B, H, W, C, like=dy_in, dtype=BF16)
+        part = _empty(P * 2 * C, like=dy_in)
+        with _timed(("conv3x3_x3_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+            call("tag_conv3x3_dgrad_poolsums_bf16", ptr(dy_in), ptr(wpack.blob), ptr(dx), ptr(yref), ptr(st.scale), ptr(st.shift),
+                 ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C, Hf, Wf, ph, pw, int(pool), float(drop_p), seed)
+        return dx, (P, part)
     P = query("tag_conv3x3_stats_rows", B, H, W, C)
     dx = _empty(B, H, W, C, like=dy_in)
     part = _empty(P * 2 * C, like=dy_in)

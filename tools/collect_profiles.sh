@@ -3,7 +3,7 @@
 # Kernel trace of the default bench command, an isolated (single-stream) trace, and the two separate PMC passes for HBM
 # traffic -- for the fp32 contract workload and for --dtype bf16.  Summaries land in gpurun_out/prof_<round>/.
 set -u
-R=${1:-r02}
+R=${1:-r05}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp

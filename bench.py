@@ -319,6 +319,9 @@ def main():
                     help="N > 1: time ONLY the gradient buckets' all-reduces (fp32 and bf16 payload), nothing else, and print "
                          "that as the JSON line (diagnosis of a scaling run; not the contract's metric)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the ~50 ms register-resident MFMA probes behind `measured_ceiling` (profile collection: they are "
+                         "not kernels of the step)")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the `other_workloads` block (configs[3] cross-encoder / cross-attention, the strong eg_config's "
                          "CrnnEncoder, configs[4] 30 s inference at batch 256: a few seconds each, never `value`)")
@@ -496,7 +499,7 @@ def main():
                     ops.WGRAD_SIDE_STREAM = side_setting
                 alt[mode]["whole_step_mfma_frac"] = round(clips / dta / world * FLOP_PER_CLIP / 1e12 / 2500.0, 4)
                 alt[mode]["roofline"] = roofline_of(fam_a, fam_a_iso, args.steps, "bf16", "bf16", args.batch, overlap_a)
-                if alt[mode]["roofline"] is not None:
+                if alt[mode]["roofline"] is not None and not args.no_probe:
                     # what the bf16 matrix pipe sustains on THIS box right now with operands that toggle like a kernel's (the
                     # part's power limit) and with constant operands (datasheet conditions), ~50 ms each
                     alt[mode]["roofline"]["measured_ceiling"] = {"random_operands": mfma_probe("bf16_random", 50.0, local),
@@ -508,7 +511,7 @@ def main():
         ops.ACT_DTYPE = "fp32"
     loss_value = round(runner.loss_value(loss), 6)
     roof = roofline_of(fam, fam_iso, args.steps, "bf16" if args.dtype == "bf16" else "fp32", args.conv_math, args.batch, overlap)
-    if roof is not None and rank == 0:
+    if roof is not None and rank == 0 and not args.no_probe:
         kind = "bf16" if args.conv_math in ("bf16", "x3", "x9") else "f32"
         roof["measured_ceiling"] = {"random_operands": mfma_probe(f"{kind}_random", 50.0, local),
                                     "constant_operands": mfma_probe(f"{kind}_constant", 50.0, local)}

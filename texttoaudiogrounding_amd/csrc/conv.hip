@@ -587,116 +587,124 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
         // ---- EPI == 2 (the dgrad launch of the first conv of block i+1, whose output is the gradient of block i's POOLED output):
         // the reduction half of the backward of relu(bn(yref)) -> avg/max pool (ph x 2) -> dropout that this gradient flows into
         // next (models/panns.py:51-60 backward; what pool_bwd_reduce_kernel of bn_pool.hip computes in a pass of its own over the
-        // largest tensors of the step).  After the quad transpose a lane holds g = dL/d(pooled, dropped-out output) of ONE pooled
-        // pixel and 4 consecutive channels: it undoes the dropout (the forward's counter-based mask is one hash per 4 consecutive
-        // channels = exactly this lane's), loads the ph x 2 window of yref as 16-byte pieces, recomputes a = bn(yref), the ReLU mask
-        // and the arg-max (first maximum in scan order, as ATen's max_pool2d), forms dz = [a > 0] * g * (wavg + [arg-max] * wmax)
-        // and accumulates sum(dz), sum(dz * xhat) per channel.  Partial-row layout as EPI == 1 ([prow][2][Cout]);
-        // tag_bn_grad_from_partials folds the rows; pool_bwd_apply_kernel stays as the one pass that writes dy. ----
-        const int pHf = EPI == 2 ? epi.Hf : 0, pWf = EPI == 2 ? epi.Wf : 0, pph = EPI == 2 ? epi.ph : 1;
-        const bool pdrop = EPI == 2 && epi.drop_p > 0.0f;
-        const float keep_scale = pdrop ? 1.0f / (1.0f - epi.drop_p) : 1.0f;
-        const unsigned keep_thr = tag_keep4_threshold(EPI == 2 ? epi.drop_p : 0.0f);
-        const size_t rowf = (size_t)pWf * Cout;                  // one unpooled image row of yref
+        // largest tensors of the step).  Per 32-cout column block j the quad-transposed output tile (128 pixels x 64 couts of the four
+        // waves, fp32) is ALSO parked in LDS -- the patch and weight buffers are free by now --, which ends the life of the
+        // accumulators; then a thread takes (pooled pixel, channel quad) pieces of the tile -- its quad is FIXED, so 4 + 4 running sums
+        // stay in registers --, undoes the dropout (the forward's counter-based mask is one hash per 4 consecutive channels = one per
+        // piece), loads the ph x 2 window of yref as 16-byte pieces, recomputes a = bn(yref), the ReLU mask and the arg-max (first
+        // maximum in scan order, as ATen's max_pool2d), forms dz = [a > 0] * g * (wavg + [arg-max] * wmax) and accumulates sum(dz),
+        // sum(dz * xhat); the 16 threads of a quad are folded through LDS in a fixed order.  One partial row per workgroup m-tile
+        // (row 2 mt of the [P][2][Cout] layout of EPI == 1, row 2 mt + 1 zero); tag_bn_grad_from_partials folds the rows;
+        // pool_bwd_apply_kernel stays as the one pass that writes dy.  (The first form kept the sums in the store loop below, on the
+        // live accumulators: the compiler spilled 280-560 B per lane -- 1.3 GB of scratch traffic per step -- and serialised the
+        // window loads behind the spills.) ----
+        float* const Ts = smem;                                 // [128 pixels][64 couts] fp32 tile of column block j (32 KB)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nq = n0 + wn0 + j * 32 + (ml & ~3);       // first of the quad's 4 couts
-            const int nqc = nq < Cout ? nq : 0;
-            f32x4 bsc, bsh, bmu, bis;                           // BatchNorm constants of the lane's 4 channels (EPI == 2)
-            float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float* ybase = nullptr;
-            if (EPI == 2) {
-                bsc = ldg4(epi.scale + nqc); bsh = ldg4(epi.shift + nqc); bmu = ldg4(epi.mean + nqc); bis = ldg4(epi.invstd + nqc);
-                ybase = epi.yref + (size_t)img * pHf * rowf + nqc;
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int rh = 0; rh < 2; ++rh) {                // two register quads (= 2 pixels per lane) at a time
-                    f32x4 gq[2], vw[2][4];
-                    int ph_[2], pw_[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int rq = 2 * rh + u;
-                        float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
-                        // round 1: exchange with lane c4 ^ 1 (quad_perm [1,0,3,2]): even lanes send x1 / x3, odd lanes x0 / x2
-                        const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
-                        const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
-                        const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
-                        if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
-                        // round 2: exchange with lane c4 ^ 2 (quad_perm [2,3,0,1]): low lanes send x2 / x3, high lanes x0 / x1
-                        const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
-                        const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
-                        const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
-                        if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
-                        // now x_t = cout nq + t of the pixel behind register 4 rq + c4
-                        const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
-                        const int h = h0 + m / TW, w = w0 + m % TW;
-                        if (h < H && nq < Cout)
-                            *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
-                        if (EPI == 2) {
-                            gq[u] = h < H ? (f32x4){x0, x1, x2, x3} : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-                            ph_[u] = h; pw_[u] = w;
-                            const int hc = h < H ? h : H - 1;
-                            const float* p = ybase + (size_t)(hc * pph) * rowf + (size_t)(2 * w) * Cout;
-                            vw[u][0] = ldg4(p);
-                            vw[u][1] = ldg4(p + Cout);
-                            if (pph == 2) { vw[u][2] = ldg4(p + rowf); vw[u][3] = ldg4(p + rowf + Cout); }
-                            else { vw[u][2] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; vw[u][3] = vw[u][2]; }
-                        }
-                    }
-                    if (EPI == 2) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            f32x4 g = gq[u];
-                            if (pdrop) {
-                                const size_t oi = (((size_t)img * H + ph_[u]) * W + pw_[u]) * Cout + nqc;
-                                const uint64_t bits = tag_keep4_bits(epi.seed, (uint64_t)(oi >> 2));
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) g[t] = tag_keep4(bits, t, keep_thr) ? g[t] * keep_scale : 0.0f;
-                            }
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                float a[4];
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) a[k] = fmaf(vw[u][k][t], bsc[t], bsh[t]);
-                                if (pph != 2) { a[2] = -INFINITY; a[3] = -INFINITY; }
-                                const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-                                const float gw = g[t] * epi.wavg, gwm = g[t] * (epi.wavg + epi.wmax);
-                                bool found = false;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const bool eq = a[k] == mx;
-                                    const bool hit = eq && !found;
-                                    found = found || eq;
-                                    const float dz = a[k] > 0.0f ? (hit ? gwm : gw) : 0.0f;
-                                    s1[t] += dz;
-                                    s2[t] = fmaf(dz, (vw[u][k][t] - bmu[t]) * bis[t], s2[t]);
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);      // the next pair's loads stay behind this pair's arithmetic (registers)
-                    }
+                for (int rq = 0; rq < 4; ++rq) {
+                    float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
+                    // round 1: exchange with lane c4 ^ 1 (quad_perm [1,0,3,2]): even lanes send x1 / x3, odd lanes x0 / x2
+                    const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
+                    const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                    const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                    if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
+                    // round 2: exchange with lane c4 ^ 2 (quad_perm [2,3,0,1]): low lanes send x2 / x3, high lanes x0 / x1
+                    const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
+                    const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                    const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                    if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
+                    // now x_t = cout nq + t of the pixel behind register 4 rq + c4
+                    const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
+                    const int h = h0 + m / TW, w = w0 + m % TW;
+                    if (h < H && nq < Cout)
+                        *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
+                    if (EPI == 2)                                // tile column = 32 (wid & 1) + (ml & ~3): the two 32-cout blocks side by side
+                        *reinterpret_cast<f32x4*>(Ts + m * 64 + (wid & 1) * 32 + (ml & ~3)) = (f32x4){x0, x1, x2, x3};
                 }
             if (EPI == 2) {
-                // the 8 lanes that hold the same 4 channels (the quad's 4 pixels x the two lane halves) -> one partial row entry
-                f32x4 o1, o2;
+                __syncthreads();                                // the tile of column block j is complete
+                const int qd = tid & 15, sub = tid >> 4;        // channel quad of the tile (fixed per thread), first pixel
+                const int nt = n0 + (qd >> 3) * (BN_ / 2) + j * 32 + (qd & 7) * 4;        // global cout of the quad
+                const int ntc = nt < Cout ? nt : 0;
+                const f32x4 bsc = ldg4(epi.scale + ntc), bsh = ldg4(epi.shift + ntc), bmu = ldg4(epi.mean + ntc),
+                            bis = ldg4(epi.invstd + ntc);
+                const unsigned rowfb = (unsigned)epi.Wf * (unsigned)Cout * 4u, coutb = (unsigned)Cout * 4u;   // bytes: yref row, pixel
+                const char* yimg = reinterpret_cast<const char*>(epi.yref) + (size_t)img * epi.Hf * rowfb;   // wave-uniform base
+                const int pph = epi.ph;
+                const bool pdrop = epi.drop_p > 0.0f;
+                const float keep_scale = pdrop ? 1.0f / (1.0f - epi.drop_p) : 1.0f;
+                const unsigned keep_thr = tag_keep4_threshold(epi.drop_p);
+                float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+                for (int k2 = 0; k2 < 8; k2 += 2) {             // 8 pieces per thread, two at a time: 8 window loads in flight
+                    f32x4 g2[2], vw[2][4];
+                    int hh[2], ww[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float a = s1[t], b = s2[t];
-                    a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
-                    b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
-                    a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
-                    b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x4E, 0xF, 0xF, true));
-                    a += __shfl_xor(a, 32, 64);
-                    b += __shfl_xor(b, 32, 64);
-                    o1[t] = a; o2[t] = b;
+                    for (int u = 0; u < 2; ++u) {
+                        const int m = sub + 16 * (k2 + u);
+                        hh[u] = h0 + m / TW; ww[u] = w0 + m % TW;
+                        g2[u] = *reinterpret_cast<const f32x4*>(Ts + m * 64 + qd * 4);
+                        if (hh[u] >= H) g2[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                        const int hc = hh[u] < H ? hh[u] : H - 1;
+                        const unsigned off = (unsigned)(hc * pph) * rowfb + (unsigned)(2 * ww[u]) * coutb + (unsigned)ntc * 4u;
+                        vw[u][0] = *reinterpret_cast<const f32x4*>(yimg + off);
+                        vw[u][1] = *reinterpret_cast<const f32x4*>(yimg + (off + coutb));
+                        if (pph == 2) {
+                            vw[u][2] = *reinterpret_cast<const f32x4*>(yimg + (off + rowfb));
+                            vw[u][3] = *reinterpret_cast<const f32x4*>(yimg + (off + rowfb + coutb));
+                        } else { vw[u][2] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; vw[u][3] = vw[u][2]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        f32x4 g = g2[u];
+                        if (pdrop) {
+                            const uint64_t grp = ((uint64_t)((unsigned)img * (unsigned)H + (unsigned)hh[u]) * (unsigned)W + (unsigned)ww[u])
+                                                 * (unsigned)(Cout >> 2) + (unsigned)(ntc >> 2);     // flat index of the pooled element / 4
+                            const uint64_t bits = tag_keep4_bits(epi.seed, grp);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) g[t] = tag_keep4(bits, t, keep_thr) ? g[t] * keep_scale : 0.0f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float a[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) a[k] = fmaf(vw[u][k][t], bsc[t], bsh[t]);
+                            if (pph != 2) { a[2] = -INFINITY; a[3] = -INFINITY; }
+                            const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                            const float gw = g[t] * epi.wavg, gwm = g[t] * (epi.wavg + epi.wmax);
+                            bool found = false;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool eq = a[k] == mx;
+                                const bool hit = eq && !found;
+                                found = found || eq;
+                                const float dz = a[k] > 0.0f ? (hit ? gwm : gw) : 0.0f;
+                                s1[t] += dz;
+                                s2[t] = fmaf(dz, (vw[u][k][t] - bmu[t]) * bis[t], s2[t]);
+                            }
+                        }
+                    }
                 }
-                float* ps = stats + (size_t)(mt * 2 + (wid >> 1)) * 2 * Cout;
-                if (c4 == 0 && kl == 0 && nq < Cout) {
-                    *reinterpret_cast<f32x4*>(ps + nq) = o1;
-                    *reinterpret_cast<f32x4*>(ps + Cout + nq) = o2;
+                __syncthreads();                                // every thread is done reading the tile
+                *reinterpret_cast<f32x4*>(Ts + tid * 8) = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+                *reinterpret_cast<f32x4*>(Ts + tid * 8 + 4) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+                __syncthreads();
+                if (tid < 64) {                                 // tile column tid: quad tid / 4, element tid % 4; fold the 16 threads of the quad
+                    const int q = tid >> 2, e = tid & 3;
+                    float a = 0.0f, b = 0.0f;
+                    for (int r = 0; r < 16; ++r) { a += Ts[(r * 16 + q) * 8 + e]; b += Ts[(r * 16 + q) * 8 + 4 + e]; }
+                    const int n = n0 + (q >> 3) * (BN_ / 2) + j * 32 + (q & 7) * 4 + e;
+                    if (n < Cout) {
+                        float* ps = stats + (size_t)(mt * 2) * 2 * Cout;
+                        ps[n] = a; ps[Cout + n] = b;
+                        ps[2 * Cout + n] = 0.0f; ps[3 * Cout + n] = 0.0f;     // row 2 mt + 1 of the EPI == 1 layout stays empty
+                    }
                 }
+                if (j + 1 < TN) __syncthreads();                // the tile is rewritten by column block j + 1
             }
         }
     }

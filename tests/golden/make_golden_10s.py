@@ -89,5 +89,47 @@ def main():
     print("  wrote cnn8rnn_dot_eval_10s.npz", os.path.getsize(os.path.join(HERE, "cnn8rnn_dot_eval_10s.npz")), "bytes")
 
 
+def main_crnn():
+    """The same at 10 s for the variant the strong eg_config literally instantiates (row A1': CrnnEncoder(256) + EmbeddingAgg(256) +
+    ExpNegL2, hop 640: F = 501 -> 250 -> 125; models/audio_encoder.py:16-86), from the imported reference."""
+    hop = 640
+    b = O.synthetic_batch(B, S, seed=4322, ragged=False, hop=hop)
+    lens = np.array([S, S - 19 * hop * 4 - 55])
+    b["waveform"][1, lens[1]:] = 0.0
+    b["waveform_len"] = lens
+    st = O.init_crnn_state(seed=13)
+    g = torch.Generator().manual_seed(14)
+    st["text_encoder.embedding.core.weight"] = (torch.rand(5221, 256, generator=g) * 2 - 1) * 0.9
+    for k in list(st):
+        if k.endswith(".0.weight"):
+            st[k] = 0.5 + torch.rand(st[k].shape, generator=g)
+        if k.endswith(".0.bias"):
+            st[k] = 0.2 * torch.randn(st[k].shape, generator=g)
+    st = calibrate_running_stats(st, b, "crnn")
+    res = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        model = build_reference(O.state_to(st, dtype), "crnn", "expnegl2").to(dtype).eval()
+        with torch.no_grad():
+            out = model({"waveform": b["waveform"].to(dtype), "waveform_len": b["waveform_len"], "text": b["text"],
+                         "text_len": b["text_len"], "specaug": False})
+        bo = dict(b)
+        bo["waveform"] = b["waveform"].to(dtype)
+        oout = O.biencoder_forward(O.state_to(st, dtype), bo, "expnegl2", "crnn", training=False)
+        d = (oout["frame_sim"] - out["frame_sim"]).abs().max().item()
+        print(f"[crnn 10s/{tag}] frame_sim {tuple(out['frame_sim'].shape)} oracle-vs-reference {d:.3e}; length {out['length'].tolist()}")
+        assert d < (2e-5 if dtype == torch.float32 else 1e-10) and torch.equal(oout["length"], out["length"])
+        res[tag] = out
+    assert res["f32"]["frame_sim"].shape == (B, 125)
+    np.savez_compressed(
+        os.path.join(HERE, "crnn_expnegl2_eval_10s.npz"),
+        input_checksum=np.array(checksum(b["waveform"]) + checksum(b["text"].float())
+                                + checksum(st["audio_encoder.gru.weight_hh_l0"])),
+        waveform_len=np.asarray(b["waveform_len"]), frame_sim_f32=res["f32"]["frame_sim"].numpy(),
+        frame_sim_f64=res["f64"]["frame_sim"].numpy(), length=res["f32"]["length"].numpy(),
+        **{f"before/{k}": v.numpy() for k, v in st.items() if "running_" in k})
+    print("  wrote crnn_expnegl2_eval_10s.npz", os.path.getsize(os.path.join(HERE, "crnn_expnegl2_eval_10s.npz")), "bytes")
+
+
 if __name__ == "__main__":
     main()
+    main_crnn()

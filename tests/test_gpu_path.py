@@ -143,6 +143,40 @@ def test_golden_eval_at_the_benched_clip_length(dev, golden_dir, conv_math):
     assert checked >= 98
 
 
+def test_crnn_golden_eval_at_the_benched_clip_length(dev, golden_dir):
+    """CrnnEncoder (the strong eg_config's encoder) against the IMPORTED REFERENCE at 10 s clips (F = 501 -> 250 -> 125): frame_sim
+    within the north_star tolerance of the reference's fp64 twin, `length` exact."""
+    from tests.test_oracle_golden import gold_10s_crnn_inputs
+    gold = np.load(f"{golden_dir}/crnn_expnegl2_eval_10s.npz")
+    st, batch = gold_10s_crnn_inputs(gold)
+    model = build_crnn_model(st, dev).eval()
+    with torch.no_grad():
+        out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"], "text": batch["text"],
+                     "text_len": batch["text_len"], "specaug": False})
+    assert np.array_equal(out["length"].numpy(), gold["length"]) and out["frame_sim"].shape == (2, 125)
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    print(f"crnn 10 s reference fixture: frame_sim err {fs_err:.2e}")
+    assert fs_err < 1e-4
+
+
+def test_golden_eval_at_the_benched_clip_length_bf16_conv_math(dev, golden_dir, monkeypatch):
+    """The same 10 s reference fixture under the bf16 conv arithmetic (configs[2]'s): the frame probabilities stay within bf16
+    tolerance of the reference's fp64 twin and are visibly NOT the fp32 path's."""
+    from tests.test_oracle_golden import gold_10s_inputs
+    from texttoaudiogrounding_amd import ops
+    gold = np.load(f"{golden_dir}/cnn8rnn_dot_eval_10s.npz")
+    st, batch = gold_10s_inputs(gold)
+    model = build_hip_model(st, "dot", dev).eval()
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    with torch.no_grad():
+        out = model({"waveform": batch["waveform"].to(dev), "waveform_len": batch["waveform_len"], "text": batch["text"],
+                     "text_len": batch["text_len"], "specaug": False})
+    assert np.array_equal(out["length"].numpy(), gold["length"])
+    fs_err = np.abs(out["frame_sim"].cpu().numpy().astype(np.float64) - gold["frame_sim_f64"]).max()
+    print(f"10 s reference fixture, bf16 conv math: frame_sim err {fs_err:.2e}")
+    assert 1e-6 < fs_err < 3e-2
+
+
 def test_golden_eval_bf16_conv_math(dev, golden_dir):
     """BASELINE configs[2] arithmetic for the convolutions (operands rounded to bf16, fp32 accumulate, everything else
     fp32): the frame probabilities stay within bf16 tolerance of the fp64 golden values."""

@@ -237,6 +237,14 @@ int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, float* dx, c
                                const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B, int H,
                                int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool, float drop_p, uint64_t seed,
                                void* stream);
+/* Inference forward of one ConvBlock stage (models/panns.py:49-60 with BatchNorm in eval mode; models/hf_modeling_grounding.py:97-180
+ * runs the encoder that way): out (B, H/ph, W/pw, Cout) = pool(relu(conv3x3(prologue(x)) * bn_scale + bn_shift)), window ph x 2 (ph 1 | 2,
+ * floor), pool 0 avg+max | 2 avg | 3 max.  The raw conv output -- the largest tensor of the block -- is never written: the kernel
+ * pools its own output tile.  Bit-identical to tag_conv3x3_forward followed by tag_bnact_pool_forward (act 1, no dropout).
+ * Halo-tile shapes only (W 8/16/32/64), producer prologue 0 | 1. */
+int tag_conv3x3_forward_bnrelu_pool_eval(const float* x, const float* wpack, int prologue, const float* in_scale,
+                                         const float* in_shift, float* out, const float* bn_scale, const float* bn_shift, int B,
+                                         int H, int W, int Cin, int Cout, int ph, int pw, int pool, void* stream);
 /* bf16-storage twin (BASELINE configs[2] mode): the sums are taken from the bf16 values of dx the apply pass will read back; rows:
  * tag_conv3x3_dgrad_poolsums_bf16_rows (0 = shape not served: keep tag_bnrelu_pool_backward_bf16) */
 int tag_conv3x3_dgrad_poolsums_bf16_rows(int B, int H, int W, int Cin, int Cout);

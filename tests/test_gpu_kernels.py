@@ -639,6 +639,41 @@ def test_conv_dgrad_fused_pool_backward_sums_bf16(ops, dev, B, Hf, Wf, Cin, C, p
     assert bool((d <= r * 2.0 ** -7 + 1e-5 * r.max()).all())
 
 
+@pytest.mark.parametrize("B,H,W,Cin,C,ph,pro,pool", [
+    (2, 19, 16, 64, 128, 2, 1, 0), (1, 35, 32, 128, 64, 2, 0, 0), (2, 21, 16, 256, 256, 1, 1, 0), (2, 43, 64, 64, 64, 2, 1, 0),
+    (2, 250, 8, 512, 512, 1, 1, 0), (1, 3001, 64, 64, 64, 2, 1, 0), (2, 18, 8, 64, 128, 2, 0, 2), (2, 17, 32, 64, 64, 1, 1, 3)])
+def test_conv_fused_bnrelu_pool_eval(ops, dev, B, H, W, Cin, C, ph, pro, pool):
+    """Inference forward of a ConvBlock stage in ONE kernel (tag_conv3x3_forward_bnrelu_pool_eval, EPI == 3: the conv pools its own
+    output tile, the raw conv output never touches HBM) against the two kernels it replaces: BIT-identical, and against the fp64
+    chain conv -> BatchNorm(eval) -> ReLU -> avg / max pool (models/panns.py:49-60).  Odd heights (floor-dropped last row), 64-wide
+    images (two tile columns), 1x2 and 2x2 windows, with and without the producer's BatchNorm+ReLU prologue, the three pool types,
+    and the 30 s clip length of BASELINE configs[4]."""
+    pw = 2
+    g = torch.Generator().manual_seed(H * W + C + pool)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    sc_in, sh_in = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    xh = nhwc(x).to(dev)
+    wf, _ = ops.pack_conv_weight(w.to(dev), W=W)
+    st = ops.bn_stats(gamma.view(1, C).to(dev), gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), False)
+    kw = dict(prologue=1, scale=sc_in.to(dev), shift=sh_in.to(dev)) if pro else {}
+    assert ops.eval_pool_fusable(xh, wf, ph, pw, pool)
+    out = ops.conv3x3_bnrelu_pool_eval(xh, wf, C, st, ph, pw, pool=pool, **kw)
+    y = ops.conv3x3(xh, wf, C, **kw)
+    two = ops.bnact_pool(y, st, ph, pw, 1, pool, 0.0, 0)
+    assert out.shape == (B, H // ph, W // pw, C) and torch.equal(out, two)
+    if H > 1000:
+        return
+    a = x.double()
+    if pro:
+        a = F.relu(a * sc_in.double().view(1, -1, 1, 1) + sh_in.double().view(1, -1, 1, 1))
+    z = F.relu(F.batch_norm(F.conv2d(a, w.double(), None, 1, 1), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5))
+    ref = {0: F.avg_pool2d(z, (ph, pw)) + F.max_pool2d(z, (ph, pw)), 2: F.avg_pool2d(z, (ph, pw)), 3: F.max_pool2d(z, (ph, pw))}[pool]
+    assert relerr(nchw(out), ref) < 5e-6
+
+
 def test_bnrelu_backward(ops, dev):
     B, C, H, W = 2, 128, 5, 6
     g = torch.Generator().manual_seed(3)

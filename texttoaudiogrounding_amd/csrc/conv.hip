@@ -323,6 +323,7 @@ struct BnBwdEpi {
     float wavg, wmax;       // pool_type: 'avg+max' (1/(ph*2), 1) | 'avg' (1/(ph*2), 0) | 'max' (0, 1)
     float drop_p;
     unsigned long long seed;
+    int kind;               // 1 | 2 | 3 = the EPI instance to launch (host side only)
 };
 
 template <int BN_, int PRO, int TW, int EPI = 0>
@@ -620,11 +621,47 @@ __global__ __launch_bounds__(256, BN_ == 64 ? 4 : 3) void conv3x3_halo_kernel(co
                     // now x_t = cout nq + t of the pixel behind register 4 rq + c4
                     const int m = wm0 + i * 32 + halo_row_to_pix(c4 + 8 * rq + 4 * kl);
                     const int h = h0 + m / TW, w = w0 + m % TW;
-                    if (h < H && nq < Cout)
+                    if (EPI != 3 && h < H && nq < Cout)         // (EPI == 3 writes the POOLED tensor only, below)
                         *reinterpret_cast<f32x4*>(y + (((size_t)img * H + h) * W + w) * Cout + nq) = (f32x4){x0, x1, x2, x3};
-                    if (EPI == 2)                                // tile column = 32 (wid & 1) + (ml & ~3): the two 32-cout blocks side by side
+                    if (EPI == 2 || EPI == 3)                   // tile column = 32 (wid & 1) + (ml & ~3): the two 32-cout blocks side by side
                         *reinterpret_cast<f32x4*>(Ts + m * 64 + (wid & 1) * 32 + (ml & ~3)) = (f32x4){x0, x1, x2, x3};
                 }
+            // ---- EPI == 3 (inference: BatchNorm in eval mode, nothing saved for backward): relu(bn(.)) -> avg/max pool (ph x 2, floor)
+            // of models/panns.py:50-60 straight from the parked tile -- the raw conv output, the largest tensor of the block (3.15 GB per
+            // 64 clips of 30 s in block 1), is neither written nor read back by a pool pass.  Same expression and summation order as
+            // bnact_pool_fwd_kernel: the result is bit-identical to the two-pass form. ----
+            if (EPI == 3) {
+                __syncthreads();                                // the tile of column block j is complete
+                constexpr int THt = 128 / TW;
+                const int pph = epi.ph, PWt = TW / 2, npool = (THt / pph) * PWt;
+                const int qd = tid & 15;
+                const int nt = n0 + (qd >> 3) * (BN_ / 2) + j * 32 + (qd & 7) * 4;
+                const int ntc = nt < Cout ? nt : 0;
+                const f32x4 bsc = ldg4(epi.scale + ntc), bsh = ldg4(epi.shift + ntc);
+                const int Hp = H / pph, Wp = W >> 1;
+                for (int pp = tid >> 4; pp < npool; pp += 16) {
+                    const int py = pp / PWt, px = pp - py * PWt;
+                    const int hp = h0 / pph + py, wp = (w0 >> 1) + px;
+                    f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f}, mx = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int dh = 0; dh < pph; ++dh)
+#pragma unroll
+                        for (int dw = 0; dw < 2; ++dw) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(Ts + ((py * pph + dh) * TW + 2 * px + dw) * 64 + qd * 4);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float a = fmaxf(fmaf(v[t], bsc[t], bsh[t]), 0.0f);
+                                sum[t] += a;
+                                mx[t] = (dh == 0 && dw == 0) ? a : fmaxf(mx[t], a);
+                            }
+                        }
+                    f32x4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = sum[t] * epi.wavg + mx[t] * epi.wmax;
+                    if (hp < Hp && nt < Cout)
+                        *reinterpret_cast<f32x4*>(y + (((size_t)img * Hp + hp) * Wp + wp) * Cout + nt) = o;
+                }
+                if (j + 1 < TN) __syncthreads();                // the tile is rewritten by column block j + 1
+            }
             if (EPI == 2) {
                 __syncthreads();                                // the tile of column block j is complete
                 const int qd = tid & 15, sub = tid >> 4;        // channel quad of the tile (fixed per thread), first pixel
@@ -2034,29 +2071,31 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     static int lds_pad = -1;
     if (lds_pad < 0) { const char* e = getenv("TAG_HALO_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float) + (size_t)lds_pad;
-    if (epi && epi->ph > 0) {      // dgrad + the sums of the BatchNorm+ReLU+pool backward below it (EPI == 2)
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, 0, TW, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 2>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
-                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);
+#define LAUNCH_EPI(P, E)                                                                                          \
+    {                                                                                                             \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, P, TW, E>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, P, TW, E>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi, \
+                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);                        \
+    }
+    if (epi && epi->kind == 3) {   // inference forward: BatchNorm(eval) + ReLU + pool from the parked tile (producer prologue 0 | 1)
+        if (pro == 1) LAUNCH_EPI(1, 3) else LAUNCH_EPI(0, 3)
         return;
     }
-    if (epi) {          // dgrad + BatchNorm-backward sums: no producer prologue on this path
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN_, 0, TW, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, 0, TW, 1>), dim3(grid), dim3(256), lds, st, x, wp, s, t, y, stats, *epi,
-                           B, H, W, Cin, Cout, nt_mul, nt_shr, rt_mul, rt_shr, col_tiles);
+    if (epi && epi->kind == 2) {   // dgrad + the sums of the BatchNorm+ReLU+pool backward below it: no producer prologue on this path
+        LAUNCH_EPI(0, 2)
         return;
     }
-    const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull};
+    if (epi) {                     // dgrad + BatchNorm-backward sums: no producer prologue on this path
+        LAUNCH_EPI(0, 1)
+        return;
+    }
+#undef LAUNCH_EPI
+    const BnBwdEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull, 0};
 #define LAUNCH_PRO(P)                                                                                             \
     {                                                                                                             \
         static bool attr_set = false;                                                                             \
@@ -2129,7 +2168,7 @@ extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, flo
     TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
     hipStream_t st = as_stream(stream);
-    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull};
+    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0ull, 1};
     const float* x = dy;
     float* y = da;
     float* stats = bnpart;
@@ -2159,12 +2198,37 @@ extern "C" int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, f
     TAG_CHECK_ARG((pool == 0 || pool == 2 || pool == 3) && drop_p >= 0.0f && drop_p < 1.0f);
     hipStream_t st = as_stream(stream);
     const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
-    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, Hf, Wf, ph, wavg, wmax, drop_p, (unsigned long long)seed};
+    const BnBwdEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, Hf, Wf, ph, wavg, wmax, drop_p, (unsigned long long)seed, 2};
     const float* x = dy;
     float* y = dx;
     float* stats = bnpart;
     const int prologue = 0;
     const float *in_scale = nullptr, *in_shift = nullptr;
+#define EPI_PTR (&epi)
+    if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+#undef EPI_PTR
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Inference forward of a conv + the rest of its ConvBlock stage (models/panns.py:49-60 with BatchNorm in eval mode):
+// out (B, H/ph, W/pw, Cout) = pool(relu(conv(prologue(x)) * bn_scale + bn_shift)), window ph x 2 (ph 1 | 2), floor; the raw conv output
+// is never materialised (EPI == 3).  Bit-identical to tag_conv3x3_forward + tag_bnact_pool_forward(act 1, no dropout).
+extern "C" int tag_conv3x3_forward_bnrelu_pool_eval(const float* x, const float* wpack, int prologue, const float* in_scale,
+                                                    const float* in_shift, float* out, const float* bn_scale,
+                                                    const float* bn_shift, int B, int H, int W, int Cin, int Cout, int ph, int pw,
+                                                    int pool, void* stream) {
+    TAG_CHECK_ARG(x && wpack && out && bn_scale && bn_shift && B > 0 && H > 0);
+    TAG_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Cin <= 512 && (prologue == 0 || prologue == 1));
+    TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
+    TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
+    TAG_CHECK_ARG(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64));
+    TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H / ph > 0 && (pool == 0 || pool == 2 || pool == 3));
+    hipStream_t st = as_stream(stream);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    const BnBwdEpi epi{nullptr, bn_scale, bn_shift, nullptr, nullptr, 0, 0, ph, wavg, wmax, 0.0f, 0ull, 3};
+    float* y = out;
+    float* stats = nullptr;
 #define EPI_PTR (&epi)
     if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
 #undef EPI_PTR

@@ -497,6 +497,27 @@ def conv3x3_dgrad_poolsums(dy_in, wpack, yref, st: BNStat, ph, pw, drop_p=0.0, s
     return dx, (P, part)
 
 
+#: inference: conv2 of a ConvBlock writes the POOLED relu(bn(.)) straight from its output tile (tag_conv3x3_forward_bnrelu_pool_eval)
+FUSE_EVAL_POOL = os.environ.get("TAG_FUSE_EVAL_POOL", "1") != "0"
+
+
+def eval_pool_fusable(x, wpack, ph, pw, pool=0):
+    """Exact-fp32 halo-tile shapes, windows 1x2 / 2x2, the three pool types."""
+    B, H, W, _ = x.shape
+    return (FUSE_EVAL_POOL and x.dtype == F32 and wpack.dtype != torch.uint8 and W in (8, 16, 32, 64) and pw == 2 and ph in (1, 2)
+            and H // ph > 0 and pool in (0, 2, 3) and query("tag_conv3x3_stats_rows", B, H, W, 64) > 0)
+
+
+def conv3x3_bnrelu_pool_eval(x, wpack, Cout, st: BNStat, ph, pw, prologue=0, scale=None, shift=None, pool=0):
+    """pool(relu(bn_eval(conv(prologue(x))))) in ONE kernel: nothing of the (B,H,W,Cout) conv output touches HBM."""
+    B, H, W, Cin = x.shape
+    out = _empty(B, H // ph, W // pw, Cout, like=x)
+    with _timed(("conv3x3_halo_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+        call("tag_conv3x3_forward_bnrelu_pool_eval", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(out), ptr(st.scale),
+             ptr(st.shift), B, H, W, Cin, Cout, ph, pw, int(pool))
+    return out
+
+
 def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
@@ -1070,10 +1091,16 @@ class Cnn8RnnFunction(TagFunction):
             s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
                           blk.bn1.momentum, partials=part1)
             wf2, wd2 = pack_conv_weight(c2w, W=y1.shape[2])
+            ph, pw = CNN8_POOLS[i]
+            if not need_grad and not bn_train and drop[0] == 0.0 and eval_pool_fusable(y1, wf2, ph, pw):
+                # inference (models/hf_modeling_grounding.py; evaluation between epochs): bn2's affine is known before the conv
+                # runs, so conv2 pools its own output tile -- y2, the block's largest tensor, is never written or read back
+                s2 = bn_stats(g2.view(1, C), g2, b2, blk.bn2.running_mean, blk.bn2.running_var, False, blk.bn2.eps, blk.bn2.momentum)
+                x = conv3x3_bnrelu_pool_eval(y1, wf2, C, s2, ph, pw, prologue=1, scale=s1.scale, shift=s1.shift)
+                continue
             y2, part2 = conv3x3_stats(y1, wf2, C, prologue=1, scale=s1.scale, shift=s1.shift, want_stats=bn_train)
             s2 = bn_stats(y2.view(-1, C), g2, b2, blk.bn2.running_mean, blk.bn2.running_var, bn_train, blk.bn2.eps,
                           blk.bn2.momentum, partials=part2)
-            ph, pw = CNN8_POOLS[i]
             xo = bnact_pool(y2, s2, ph, pw, act=1, pool=0, drop_p=drop[0], seed=seeds[i])
             if need_grad:                      # inference: intermediates die here (30 s clips x 64 are GBs per layer)
                 acts.append((x, y1, s1, y2, s2, wd1, wd2))

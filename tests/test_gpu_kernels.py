@@ -129,7 +129,10 @@ def test_bn_stats(ops, dev, C, rows):
                                                 # the 32-wide one) walks down a strip with the input rows in a ring of four slots:
                                                 # images shorter than the ring / the tile, a split that crosses strips and images
                                                 (1, 1, 64, 64, 64, 0), (3, 2, 64, 64, 128, 1), (2, 7, 64, 128, 64, 1),
-                                                (1, 1, 32, 64, 64, 1), (5, 3, 32, 64, 128, 0), (2, 5, 32, 128, 64, 3)])
+                                                (1, 1, 32, 64, 64, 1), (5, 3, 32, 64, 128, 0), (2, 5, 32, 128, 64, 3),
+                                                # round 5: 4-wide images (the last two CrnnEncoder layers, 125 x 4) on the halo-tile
+                                                # kernel as 32 x 4 tiles: a tile taller than the image, a partial last tile, prologues 2 / 3
+                                                (2, 125, 4, 128, 128, 2), (3, 125, 4, 128, 128, 3), (1, 33, 4, 64, 128, 0), (2, 31, 4, 128, 64, 1)])
 def test_conv3x3_forward_dgrad_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, Cin, H, W, generator=g)

@@ -2120,7 +2120,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 // 0 = this shape is served by a kernel without the fused statistics
 extern "C" int tag_conv3x3_stats_rows(int B, int H, int W, int Cout) {
     (void)Cout;
-    if (!(conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64))) return 0;
+    if (!(conv_impl() == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || W == 64))) return 0;
     const int tw = W == 64 ? 32 : W, th = 128 / tw;             // 64-wide images: two 4 x 32 tile columns
     return B * ((H + th - 1) / th) * (W / tw) * 2;
 }
@@ -2133,14 +2133,16 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3);
     TAG_CHECK_ARG(prologue == 0 || (in_scale && in_shift));
     hipStream_t st = as_stream(stream);
-    const bool halo = conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64);
+    // (W == 4: the last two layers of CrnnEncoder, 125 x 4 images as 32 x 4 tiles -- round 5; the epilogue entry points below keep W >= 8)
+    const bool halo = conv_impl() == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || W == 64);
     // 32-bit byte offsets: inside ONE image for the halo-tile kernel (64-bit image base), over the whole batch for the fallback
     TAG_CHECK_ARG((long)B * H * W < (1L << 31) && (long)H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(halo || (long)B * H * W * Cin * 4 < (1L << 32));
     TAG_CHECK_ARG(stats == nullptr || halo);
 #define EPI_PTR nullptr
 #define HALO_BY_W(BN_)                                                                                          \
-    if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);        \
+    if (W == 4) launch_halo<BN_, 4>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);        \
+    else if (W == 8) launch_halo<BN_, 8>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);   \
     else if (W == 16) launch_halo<BN_, 16>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
     else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
     else launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);   /* W == 64: two tile columns */

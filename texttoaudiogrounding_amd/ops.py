@@ -381,7 +381,7 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
             call("tag_conv3x3_forward_x3", ptr(x), ptr(wpack.blob), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H, W,
                  Cin, Cout, wpack.products)
     else:
-        kname = "conv3x3_halo_kernel" if W in (8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
+        kname = "conv3x3_halo_kernel" if W in (4, 8, 16, 32, 64) else "conv3x3_fwd_kernel"   # dispatch rule of the C side
         with _timed((kname, B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
             call("tag_conv3x3_forward", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(y), sp, B, H, W, Cin,
                  Cout)

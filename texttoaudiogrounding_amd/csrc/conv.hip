@@ -2239,7 +2239,7 @@ extern "C" int tag_conv3x3_forward_bnrelu_pool_eval(const float* x, const float*
     return 0;
 }
 
-static bool wgrad_alltaps_ok(int W) { return conv_impl() == 0 && (W == 8 || W == 16 || W == 32 || W == 64); }
+static bool wgrad_alltaps_ok(int W) { return conv_impl() == 0 && (W == 4 || W == 8 || W == 16 || W == 32 || W == 64); }
 // all-taps kernel: K slices (in chunks of 32 pixels) so that ~512 workgroups (ONE round of 2 per CU) are launched: against
 // two rounds the fp32 kernels are level (16.00 -> 15.88 ms per step), the bf16 kernels gain 6 % (2.55 -> 2.41 ms) and the
 // fp32 partials every layer writes and the reduction re-reads halve (151 -> 75 MB per layer, 2.1 -> 1.05 GB per step)
@@ -2360,7 +2360,8 @@ extern "C" int tag_conv3x3_wgrad(const float* x, int prologue, const float* in_s
     if (wgrad_alltaps_ok(W)) {
         int cps;
         const int sp = alltaps_splits(B, H, W, Cin, Cout, &cps);
-        if (W == 8) launch_wgrad_alltaps<8>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        if (W == 4) launch_wgrad_alltaps<4>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
+        else if (W == 8) launch_wgrad_alltaps<8>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         else if (W == 16) launch_wgrad_alltaps<16>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         else if (W == 32) launch_wgrad_alltaps<32>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);
         else launch_wgrad_alltaps<64>(x, prologue, in_scale, in_shift, dy, partial, B, H, W, Cin, Cout, sp, cps, st);

@@ -555,7 +555,10 @@ def test_bnrelu_pool_fwd_bwd(ops, dev, H, W, C, ph, pw, train, p):
 @pytest.mark.parametrize("B,Hf,Wf,Cin,C,ph,train,p", [
     (2, 18, 16, 64, 128, 2, True, 0.2), (1, 35, 32, 128, 64, 2, True, 0.0), (2, 21, 16, 256, 128, 1, True, 0.2),
     (2, 43, 64, 128, 64, 2, True, 0.2), (2, 13, 128, 64, 64, 2, False, 0.2), (3, 250, 16, 512, 256, 1, True, 0.2),
-    (2, 1001, 64, 128, 64, 2, True, 0.2)])
+    (2, 1001, 64, 128, 64, 2, True, 0.2),
+    # a 32-channel tensor (half of a 64-cout tile is empty: the BatchNorm / pool passes take C | 256 or multiples of 256), one clip,
+    # a single pooled row, fewer rows than a tile
+    (1, 5, 16, 32, 32, 2, False, 0.2), (3, 2, 32, 64, 32, 1, True, 0.0), (1, 9, 16, 64, 256, 2, True, 0.2)])
 def test_conv_dgrad_fused_pool_backward_sums(ops, dev, B, Hf, Wf, Cin, C, ph, train, p):
     """One-read pool backward: tag_conv3x3_dgrad_poolsums (the dgrad conv of the NEXT block's first conv, with the sums of the
     BatchNorm+ReLU+pool backward below it in the epilogue) + tag_bn_grad_from_partials + tag_bnrelu_pool_backward_apply, against
@@ -644,7 +647,9 @@ def test_conv_dgrad_fused_pool_backward_sums_bf16(ops, dev, B, Hf, Wf, Cin, C, p
 
 @pytest.mark.parametrize("B,H,W,Cin,C,ph,pro,pool", [
     (2, 19, 16, 64, 128, 2, 1, 0), (1, 35, 32, 128, 64, 2, 0, 0), (2, 21, 16, 256, 256, 1, 1, 0), (2, 43, 64, 64, 64, 2, 1, 0),
-    (2, 250, 8, 512, 512, 1, 1, 0), (1, 3001, 64, 64, 64, 2, 1, 0), (2, 18, 8, 64, 128, 2, 0, 2), (2, 17, 32, 64, 64, 1, 1, 3)])
+    (2, 250, 8, 512, 512, 1, 1, 0), (1, 3001, 64, 64, 64, 2, 1, 0), (2, 18, 8, 64, 128, 2, 0, 2), (2, 17, 32, 64, 64, 1, 1, 3),
+    # half-empty n-tile (32 channels), fewer rows than a tile, one row
+    (1, 9, 16, 64, 32, 2, 1, 0), (3, 2, 32, 64, 256, 1, 0, 0), (2, 1, 8, 32, 32, 1, 1, 0)])
 def test_conv_fused_bnrelu_pool_eval(ops, dev, B, H, W, Cin, C, ph, pro, pool):
     """Inference forward of a ConvBlock stage in ONE kernel (tag_conv3x3_forward_bnrelu_pool_eval, EPI == 3: the conv pools its own
     output tile, the raw conv output never touches HBM) against the two kernels it replaces: BIT-identical, and against the fp64

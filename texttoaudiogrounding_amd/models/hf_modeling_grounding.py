@@ -203,7 +203,9 @@ class Cnn8RnnLaionClapGroundingModel(_ModelBase):
         self.max_clips_per_pass = max_clips_per_pass
         self.text_tokenizer = self._local_tokenizer(config.text_encoder_name)
         if _HAVE_TRANSFORMERS:
+            self._tag_constructing = True       # post_init() must not redo the sub-modules' own initialisation (see _init_weights)
             self.post_init()
+            self._tag_constructing = False
 
     @staticmethod
     def _local_tokenizer(name):
@@ -216,8 +218,14 @@ class Cnn8RnnLaionClapGroundingModel(_ModelBase):
         except Exception:                       # noqa: BLE001 - not cached / no such directory: the caller injects one
             return None
 
-    def _init_weights(self, module):            # weights come from the sub-modules' own constructors (reference: same)
-        return
+    def _init_weights(self, module):
+        """Called by ``from_pretrained`` for modules whose weights are MISSING from the checkpoint (the constructors' own
+        initialisation is skipped when the model is materialised from a checkpoint): PyTorch's default for the standard layer types,
+        so that a partial checkpoint never leaves uninitialised memory behind.  The reference defines no ``_init_weights`` either."""
+        if getattr(self, "_tag_constructing", False):
+            return                              # fresh construction: the constructors' initialisation stands, as in the reference
+        if isinstance(module, (nn.Linear, nn.Embedding, nn.LayerNorm, nn.BatchNorm2d, nn.GRU, nn.Conv2d)):
+            module.reset_parameters()
 
     if not _HAVE_TRANSFORMERS:
         @property

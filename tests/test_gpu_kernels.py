@@ -1126,3 +1126,19 @@ def test_adam_clip_vs_torch(ops, dev):
         assert abs(gsq.item() - float((gr.double() ** 2).sum())) / float((gr.double() ** 2).sum()) < 1e-10
         ops.adam_step(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, i + 1, gsq, 1.0, 1.0)
     assert (p.cpu().double() - pr.detach()).abs().max().item() < 1e-6
+
+
+def test_halo_256_cout_tiles_forced_everywhere(dev):
+    """TAG_HALO_BN256=2 puts EVERY halo launch with W <= 16 and Cout % 256 == 0 on the 256-cout workgroups -- also the launches the
+    default keeps on 128-cout tiles (plain forward / dgrad without statistics, the inference epilogue EPI == 3).  The switch is read once
+    per process, so the affected kernel tests run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAG_HALO_BN256="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "fused_bnrelu_pool_eval or forward_dgrad_wgrad or fused_bn_stats or fused_pool_backward_sums and not bf16 "
+                        "and not forced_everywhere"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -2118,11 +2118,13 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 
 // 256-cout workgroups (2 per CU, 252 VGPRs) for the narrow deep layers (W <= 16, Cout a multiple of 256): the same rate as the
 // 128-cout tile at 3 per CU (tools/conv_bench.py: 135.1 vs 135.0, 135.7 vs 135.9 TFLOP/s) with HALF the patch re-reads and weight
-// passes through L2 -- TAG_HALO_BN256=0 keeps the 128-cout tiles everywhere (A/B).
-static bool halo_bn256(int W, int Cout) {
+// passes through L2 -- in the TRAINING step, where the time is level (53.22 / 53.32 vs 53.27 / 53.34 ms).  The forward-only 30 s
+// inference pass is 1.3 % slower with them (216 vs 213 ms per 256 clips), so launches that neither write BatchNorm statistics nor carry
+// a backward epilogue keep the 128-cout tiles.  TAG_HALO_BN256=0: 128-cout tiles everywhere, =2: 256-cout tiles everywhere (A/B).
+static bool halo_bn256(int W, int Cout, bool training_launch) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("TAG_HALO_BN256"); on = e ? atoi(e) : 1; }
-    return on && W <= 16 && Cout % 256 == 0;
+    return (on == 2 || (on == 1 && training_launch)) && W <= 16 && Cout % 256 == 0;
 }
 
 // rows of BatchNorm partial statistics the forward kernel writes when asked to (one per 64-pixel wave tile);
@@ -2156,7 +2158,7 @@ extern "C" int tag_conv3x3_forward(const float* x, const float* wpack, int prolo
     else if (W == 32) launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st); \
     else launch_halo<BN_, 32>(x, wpack, prologue, in_scale, in_shift, y, stats, EPI_PTR, B, H, W, Cin, Cout, st);   /* W == 64: two tile columns */
     if (halo) {
-        if (halo_bn256(W, Cout)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+        if (halo_bn256(W, Cout, stats != nullptr)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
     } else if (Cout >= 128) {
         launch_fwd<128>(x, wpack, prologue, in_scale, in_shift, y, B, H, W, Cin, Cout, st);
     } else {
@@ -2186,7 +2188,7 @@ extern "C" int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, flo
     const int prologue = 0;
     const float *in_scale = nullptr, *in_shift = nullptr;
 #define EPI_PTR (&epi)
-    if (halo_bn256(W, Cout)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+    if (halo_bn256(W, Cout, true)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
 #undef EPI_PTR
     TAG_LAUNCH_CHECK();
     return 0;
@@ -2216,7 +2218,7 @@ extern "C" int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, f
     const int prologue = 0;
     const float *in_scale = nullptr, *in_shift = nullptr;
 #define EPI_PTR (&epi)
-    if (halo_bn256(W, Cout)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+    if (halo_bn256(W, Cout, true)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
 #undef EPI_PTR
     TAG_LAUNCH_CHECK();
     return 0;
@@ -2241,7 +2243,7 @@ extern "C" int tag_conv3x3_forward_bnrelu_pool_eval(const float* x, const float*
     float* y = out;
     float* stats = nullptr;
 #define EPI_PTR (&epi)
-    if (halo_bn256(W, Cout)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
+    if (halo_bn256(W, Cout, false)) { HALO_BY_W(256) } else if (Cout >= 128) { HALO_BY_W(128) } else { HALO_BY_W(64) }
 #undef EPI_PTR
 #undef HALO_BY_W
     TAG_LAUNCH_CHECK();

@@ -226,13 +226,13 @@ int tag_bnrelu_pool_backward(const float* y, const float* scale, const float* sh
                              const float* dout, float* dy, float* dgamma, float* dbeta, int B, int H,
                              int W, int C, int ph, int pw, int pool /* 0 avg+max | 2 avg | 3 max */, float drop_p,
                              uint64_t seed, int bn_train, void* ws, void* stream);
-/* One-read pool backward (round 5; models/panns.py:46-62 backward).  The dgrad convolution of the NEXT block's first conv produces
- * dout = dL/d(pooled, dropped-out output) -- tag_conv3x3_dgrad_poolsums writes it as tag_conv3x3_forward would AND, in its
- * epilogue, the partial sums over every 64-pixel wave tile of dz and dz * xhat, where dz is the gradient at the BatchNorm output
- * of yref (B,Hf,Wf,Cout) (dropout undone with the forward's counter-based mask, ReLU mask and first-maximum arg-max recomputed from
- * the ph x 2 window of yref): bnpart [P][2][Cout], P = tag_conv3x3_stats_rows(B,H,W,Cout), H = Hf / ph, W = Wf / pw; windows ph x 2
- * with ph 1 or 2.  tag_bn_grad_from_partials folds the rows into dgamma / dbeta; tag_bnrelu_pool_backward_apply is the apply pass
- * of tag_bnrelu_pool_backward alone -- the separate reduction pass over yref and dout is gone. */
+/* Pool backward without its own reduction pass (round 5; models/panns.py:46-62 backward).  The dgrad convolution of the NEXT block's first
+ * conv produces dout = dL/d(pooled, dropped-out output) -- tag_conv3x3_dgrad_poolsums writes it as tag_conv3x3_forward would AND, from its
+ * output tile (parked in LDS at the end of the kernel), the partial sums over the tile of dz and dz * xhat, where dz is the gradient at the
+ * BatchNorm output of yref (B,Hf,Wf,Cout): dropout undone with the forward's counter-based mask, ReLU mask and first-maximum arg-max
+ * recomputed from the ph x 2 window of yref.  bnpart [P][2][Cout], P = tag_conv3x3_stats_rows(B,H,W,Cout) (row 2t carries m-tile t,
+ * row 2t + 1 is zero), H = Hf / ph, W = Wf / pw; windows ph x 2 with ph 1 or 2.  tag_bn_grad_from_partials folds the rows into
+ * dgamma / dbeta; tag_bnrelu_pool_backward_apply is the apply pass of tag_bnrelu_pool_backward alone. */
 int tag_conv3x3_dgrad_poolsums(const float* dy, const float* wpack, float* dx, const float* yref, const float* bn_scale,
                                const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B, int H,
                                int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool, float drop_p, uint64_t seed,

@@ -158,6 +158,14 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
                                       "ms_per_step": round(v["ms"] / steps, 3)} for k, v in fam_iso.items()}}
 
 
+def mem_record(device):
+    """Peak device memory since the last reset: what the caching allocator handed out (allocated) and what it holds (reserved).
+    Reserved far above allocated in a leg = the allocator could not reuse freed blocks (a host that ran ahead of events recorded on
+    a second stream) -- the symptom of the round-4 side-stream stall (ops._SideWgrad)."""
+    return {"max_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+            "max_reserved_GB": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)}
+
+
 def run_steps(runner, batch, k, sync):
     """k training steps; returns (wall seconds incl. the closing sync, host seconds spent INSIDE train_step = the time one core
     needs to enqueue a step: ctypes launches + autograd bookkeeping, no synchronisation), and the last loss."""
@@ -426,8 +434,10 @@ def main():
     from texttoaudiogrounding_amd.utils.telemetry import BoardSampler, mfma_probe
     sampler = BoardSampler(local)              # hwmon power + shader clock every 25 ms while a leg runs (a sysfs read: no GPU work)
     sampler.start()
+    torch.cuda.reset_peak_memory_stats(device)
     dt, host_s, loss = run_steps(runner, batch, args.steps, sync)
     board = sampler.stop()
+    mem_main = mem_record(device)
     log(f"timed {args.steps} steps in {dt:.3f} s (host enqueue {host_s / args.steps * 1e3:.2f} ms/step)")
     prof, ops.PROFILE = ops.PROFILE, None
     comm_timing = None
@@ -475,8 +485,10 @@ def main():
             sync()
             ops.PROFILE = {} if mode == "bf16" else None          # the bf16 mode gets its own roofline (events as in the main leg)
             sampler.start()
+            torch.cuda.reset_peak_memory_stats(device)
             dta, host_a, _ = run_steps(runner, batch, args.steps, sync)
             board_a = sampler.stop()
+            mem_a = mem_record(device)
             prof_a, ops.PROFILE = ops.PROFILE, None
             if world > 1:
                 t = torch.tensor([dta], device=device, dtype=torch.float64)
@@ -484,7 +496,8 @@ def main():
                 dta = t.item()
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3),
-                         "host_enqueue_ms_per_step": round(host_a / args.steps * 1e3, 3), "board": board_a}
+                         "host_enqueue_ms_per_step": round(host_a / args.steps * 1e3, 3), "board": board_a,
+                         "device_memory": mem_a}
             alt[mode]["wgrad_side_stream"] = bool(ops.side_stream_enabled())
             if mode == "bf16":
                 fam_a = fam_a_iso = families(prof_a)
@@ -544,7 +557,9 @@ def main():
                                              (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4),
                "roofline": roof,
                # socket power and shader clock sampled (hwmon, every 25 ms) while the timed region ran
-               "board": board}
+               "board": board,
+               # peak device memory over the timed region (allocated by tensors / held by the caching allocator)
+               "device_memory": mem_main}
         if alt:
             out["alt_conv_math"] = alt
         if others:

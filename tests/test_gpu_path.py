@@ -1133,6 +1133,47 @@ def test_fp32_step_with_the_wgrad_side_stream_switched_on(dev, monkeypatch, cu_s
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
 
 
+def test_side_stream_steps_without_a_host_sync_do_not_grow_the_allocator(dev, monkeypatch):
+    """K training steps enqueued WITHOUT a host synchronisation (what bench.py times, what a loop that reads the loss every N steps
+    does) with the weight-gradient convs on the side stream: the caching allocator's reserve must stay at the level of one step.
+    Round 4 marked the side stream's operands with Tensor.record_stream, which defers a block's reuse until the HOST sees the side
+    stream's event complete -- a host running ahead of the GPU saw none complete and took new memory every step (53-75 GB after
+    30-60 steps of the benched size, then a drain-the-device stall once hipMalloc failed).  The operands are now kept alive until
+    join(); the old rule (TAG_SIDE_RECORD_STREAM=1) stays switchable and must give bit-identical gradients."""
+    from texttoaudiogrounding_amd import ops
+    from texttoaudiogrounding_amd.runner import StrongRunner
+    st = O.init_state(seed=3, logit_gain=40.0)
+    batch = O.synthetic_batch(16, 320000, seed=8, ragged=True)    # large enough that the GPU step outlasts the host's enqueue
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}     # resident, as in bench.py: no blocking copies
+    monkeypatch.setattr(ops, "WGRAD_SIDE_STREAM", True)
+    grads = {}
+    for record_stream in (False, True):
+        monkeypatch.setattr(ops, "SIDE_RECORD_STREAM", record_stream)
+        torch.manual_seed(123)
+        model = build_hip_model(st, "dot", dev).train()
+        runner = StrongRunner(model, device=str(dev))
+        fresh = lambda: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        runner.forward_backward(fresh())
+        torch.cuda.synchronize()
+        grads[record_stream] = runner.flat.grad.clone()
+        if record_stream:
+            continue
+        for _ in range(2):                                    # the allocator's steady state of a synchronised loop
+            runner.train_step(fresh())
+            torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_reserved(dev)
+        for _ in range(16):
+            runner.train_step(fresh())                        # no synchronisation: the host runs ahead
+        torch.cuda.synchronize()
+        grown = torch.cuda.max_memory_reserved(dev) - base
+        one_step = torch.cuda.max_memory_allocated(dev)
+        assert grown <= 0.5 * one_step, (f"allocator reserve grew by {grown / 2 ** 20:.0f} MiB over 16 unsynchronised steps "
+                                         f"(one step's peak: {one_step / 2 ** 20:.0f} MiB)")
+        del runner, model
+    assert torch.equal(grads[False], grads[True])
+
+
 def test_bf16_mode_pool_sum_fusion_switch(dev, monkeypatch):
     """TAG_FUSE_POOL_BWD_BF16=1 (off by default: measured level in step time, docs/experiments_r05.md) through a whole bf16-mode
     training step: the forward is untouched (loss identical) and every gradient tensor agrees with the two-pass pool backward up to

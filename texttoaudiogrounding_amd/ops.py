@@ -1001,14 +1001,30 @@ WGRAD_LAG = _os.environ.get("TAG_WGRAD_LAG", "0") != "0"     # measured: 57.7 ms
 SIDE_PARAM_GRADS = _env_int("TAG_SIDE_PARAM_GRADS", 1)
 
 
+#: TAG_SIDE_RECORD_STREAM=1 restores round 4's lifetime rule for the side stream's operands (Tensor.record_stream instead of keeping
+#: them alive until join()) -- kept for the A/B that shows the allocator growth it causes under an unsynchronised host.
+SIDE_RECORD_STREAM = _env_int("TAG_SIDE_RECORD_STREAM", 0) != 0
+
+
 class _SideWgrad:
-    """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them."""
+    """Runs conv3x3_wgrad calls on the side stream; join() makes the main stream wait for all of them.
+
+    Lifetime of the tensors the side stream reads or writes: they are allocated on the MAIN stream, and the caching allocator
+    would hand their memory to the main stream's next allocation the moment Python drops them.  They are therefore kept alive in
+    ``self.keep`` until join() has made the main stream wait for the side stream -- from then on a release on the main stream is
+    ordered after every side-stream access.  (Round 4 used ``Tensor.record_stream`` instead.  That defers the reuse of a block
+    until the HOST sees the side stream's event complete; a host that enqueues K unsynchronised steps runs far ahead of the
+    GPU, sees none complete and takes NEW memory for every step -- ~10 GB per fp32-storage step -- until hipMalloc fails and
+    the allocator drains the device and frees its cache: a 2 s stall in the middle of `bench.py --conv-math x3 --steps 30`,
+    in every process that started while the previous one's 250 GB were still being returned, found with
+    tools/step_timeline.py / a per-thread CPU sampler: kernels at their normal durations, the main thread asleep.)"""
 
     def __init__(self, device):
         self.on = side_stream_enabled()
         self.main = torch.cuda.current_stream(device)
         self.side = _side_stream(device) if self.on else None
         self.pending = []
+        self.keep = []
 
     def wgrad(self, x, dy, prologue=0, scale=None, shift=None, out=None):
         if not self.on:
@@ -1021,7 +1037,7 @@ class _SideWgrad:
 
     def run(self, fn, tensors=()):
         """``fn()`` on the side stream, ordered after everything enqueued on the main stream so far (inline when the side
-        stream is off).  ``tensors``: main-stream allocations fn reads (kept alive for the side stream)."""
+        stream is off).  ``tensors``: main-stream allocations fn reads (kept alive until join())."""
         if not self.on:
             fn()
             return
@@ -1029,9 +1045,7 @@ class _SideWgrad:
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
             fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.side)
+        self._hold(tensors)
 
     def release(self):
         """Launch the queued wgrads on the side stream, ordered after everything enqueued on the main stream so far."""
@@ -1041,16 +1055,23 @@ class _SideWgrad:
         with torch.cuda.stream(self.side):
             for x, dy, prologue, scale, shift, dw in self.pending:
                 conv3x3_wgrad(x, dy, prologue, scale, shift, out=dw)
-        for x, dy, prologue, scale, shift, dw in self.pending:
-            for t in (x, dy, scale, shift, dw):
-                if t is not None:
-                    t.record_stream(self.side)           # the caching allocator must not recycle them early
+        for item in self.pending:
+            self._hold(item)
         self.pending = []
+
+    def _hold(self, tensors):
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                if SIDE_RECORD_STREAM:
+                    t.record_stream(self.side)
+                else:
+                    self.keep.append(t)
 
     def join(self):
         if self.on:
             self.release()
             self.main.wait_stream(self.side)
+            self.keep = []                               # released on the main stream, ordered after the wait
 
 
 class Cnn8RnnFunction(TagFunction):

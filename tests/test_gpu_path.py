@@ -1032,6 +1032,31 @@ def test_edge_shapes_train_step(dev, B, S):
         assert (p.grad.cpu().double() - g).abs().max().item() / (g.abs().max().item() + 1e-30) < 1e-3, name
 
 
+_TRAJECTORY_REF = {}
+
+
+def _oracle_trajectory(st, batch, names):
+    """The fp64 oracle's ten optimiser steps on the trajectory test's fixed batch: the same for every arithmetic mode of the HIP
+    path, so it is computed once per session (20 s of CPU work on a shared host) and shared by the four parametrisations."""
+    key = tuple(names)
+    if key not in _TRAJECTORY_REF:
+        s64 = O.state_to(st, torch.float64, requires_grad=True)
+        b64 = dict(batch)
+        b64["waveform"], b64["label"] = batch["waveform"].double(), batch["label"].double()
+        params = [s64[n] for n in names]
+        opt = torch.optim.Adam(params, lr=2e-4)
+        ref = []
+        for _ in range(10):
+            opt.zero_grad()
+            loss, _ = O.train_step_loss(s64, b64, "dot", "cnn8rnn", True, (0.0, 0.0))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            ref.append(loss.item())
+        _TRAJECTORY_REF[key] = ref
+    return list(_TRAJECTORY_REF[key])
+
+
 @pytest.mark.parametrize("math_", ["fp32", "x3", "x9", "bf16mode"])
 def test_training_trajectory_matches_oracle(dev, math_):
     """Ten optimiser steps (forward, backward, clip_grad_norm_(1.0), Adam) on a fixed batch, dropout off: the loss
@@ -1053,20 +1078,7 @@ def test_training_trajectory_matches_oracle(dev, math_):
             hip.append(runner.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}).item())
     finally:
         ops.CONV_MATH, ops.ACT_DTYPE = old
-    s64 = O.state_to(st, torch.float64, requires_grad=True)
-    b64 = dict(batch)
-    b64["waveform"], b64["label"] = batch["waveform"].double(), batch["label"].double()
-    names = [n for n, _ in model.named_parameters()]
-    params = [s64[n] for n in names]
-    opt = torch.optim.Adam(params, lr=2e-4)
-    ref = []
-    for _ in range(10):
-        opt.zero_grad()
-        loss, _ = O.train_step_loss(s64, b64, "dot", "cnn8rnn", True, (0.0, 0.0))
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-        ref.append(loss.item())
+    ref = _oracle_trajectory(st, batch, [n for n, _ in model.named_parameters()])
     print(f"trajectory [{math_}]: hip {['%.5f' % v for v in hip]}")
     print(f"                 oracle {['%.5f' % v for v in ref]}")
     assert ref[-1] < ref[0] - 0.005                                  # the oracle actually learns on this batch

@@ -7,7 +7,9 @@ long-lived workgroups, what the chip does during those waits.
     rocprofv3 --kernel-trace --output-format csv -d D -o k -- python bench.py --dtype bf16 --steps 4 --warmup 2 --no-...
     python tools/step_timeline.py D/k_kernel_trace.csv [step_index_from_end=2] [--rows]
 
-A step = the dispatches between two consecutive `adam_kernel` launches.
+A step = the dispatches between two consecutive `adam_kernel` launches.  (rocprofv3 of this image segfaults at EXIT after the trace
+files are written: the CSV is complete.  The traced host enqueues ~3 x slower than an untraced one, so gaps in the traces of the
+5-10 ms steps are partly the tracer's; the kernel durations and the cross-queue overlaps are the measurement.)
 """
 import csv
 import sys

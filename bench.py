@@ -166,18 +166,32 @@ def mem_record(device):
             "max_reserved_GB": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)}
 
 
-def run_steps(runner, batch, k, sync):
+def run_steps(runner, batch, k, sync, spread=None):
     """k training steps; returns (wall seconds incl. the closing sync, host seconds spent INSIDE train_step = the time one core
-    needs to enqueue a step: ctypes launches + autograd bookkeeping, no synchronisation), and the last loss."""
+    needs to enqueue a step: ctypes launches + autograd bookkeeping, no synchronisation), and the last loss.
+    spread: a dict that receives {"min", "median", "max"} of the k steps' own GPU durations (one HIP event per step boundary on the
+    compute stream -- a marker packet, no synchronisation): a stall inside the timed region (round 5: the allocator draining the
+    device in the middle of an unsynchronised run) shows as max >> median instead of hiding in the mean."""
     host = 0.0
     loss = None
+    marks = None
+    if spread is not None and torch.cuda.is_available():
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(k):
+    for i in range(k):
         th = time.perf_counter()
         loss = runner.train_step(dict(batch))
         host += time.perf_counter() - th
+        if marks is not None:
+            marks[i + 1].record()
     sync()
-    return time.perf_counter() - t0, host, loss
+    dt = time.perf_counter() - t0
+    if marks is not None:
+        d = [marks[i].elapsed_time(marks[i + 1]) for i in range(k)]
+        first, d = d[0], sorted(d)
+        spread.update({"min": round(d[0], 3), "median": round(d[len(d) // 2], 3), "max": round(d[-1], 3), "first": round(first, 3)})
+    return dt, host, loss
 
 
 def build_workload(name, device):
@@ -421,21 +435,22 @@ def main():
                               "comm_only": res}))
         dist.destroy_process_group()
         return
+    from texttoaudiogrounding_amd.utils.telemetry import BoardSampler, mfma_probe
+    sampler = BoardSampler(local)              # hwmon power + shader clock every 25 ms while a leg runs (a sysfs read: no GPU work)
     log(f"model on {device}, batch {args.batch}/GPU; warm-up {args.warmup} step(s)")
     for i in range(args.warmup):
         tw = time.perf_counter()
         runner.train_step(dict(batch))
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {time.perf_counter() - tw:.3f} s")
-    sync()
     ops.PROFILE = {}
     if runner.buckets is not None:
         runner.buckets.record = True          # per-bucket events on the communication stream + the exposed wait
-    from texttoaudiogrounding_amd.utils.telemetry import BoardSampler, mfma_probe
-    sampler = BoardSampler(local)              # hwmon power + shader clock every 25 ms while a leg runs (a sysfs read: no GPU work)
     sampler.start()
     torch.cuda.reset_peak_memory_stats(device)
-    dt, host_s, loss = run_steps(runner, batch, args.steps, sync)
+    step_spread = {}
+    sync()                                     # barrier + synchronize, then NOTHING between it and the first timed enqueue (an idle
+    dt, host_s, loss = run_steps(runner, batch, args.steps, sync, step_spread)     # gap of some ms lets the shader clock fall)
     board = sampler.stop()
     mem_main = mem_record(device)
     log(f"timed {args.steps} steps in {dt:.3f} s (host enqueue {host_s / args.steps * 1e3:.2f} ms/step)")
@@ -482,11 +497,12 @@ def main():
             ops.CONV_MATH = mode
             ops.ACT_DTYPE = "bf16" if mode == "bf16" else "fp32"
             runner.train_step(dict(batch))
-            sync()
             ops.PROFILE = {} if mode == "bf16" else None          # the bf16 mode gets its own roofline (events as in the main leg)
             sampler.start()
             torch.cuda.reset_peak_memory_stats(device)
-            dta, host_a, _ = run_steps(runner, batch, args.steps, sync)
+            spread_a = {}
+            sync()
+            dta, host_a, _ = run_steps(runner, batch, args.steps, sync, spread_a)
             board_a = sampler.stop()
             mem_a = mem_record(device)
             prof_a, ops.PROFILE = ops.PROFILE, None
@@ -497,7 +513,7 @@ def main():
             alt[mode] = {"conv_math": desc[mode], "value": round(clips / dta, 2), "unit": "clips/s",
                          "ms_per_step": round(dta / args.steps * 1e3, 3),
                          "host_enqueue_ms_per_step": round(host_a / args.steps * 1e3, 3), "board": board_a,
-                         "device_memory": mem_a}
+                         "device_memory": mem_a, "step_ms": spread_a}
             alt[mode]["wgrad_side_stream"] = bool(ops.side_stream_enabled())
             if mode == "bf16":
                 fam_a = fam_a_iso = families(prof_a)
@@ -559,7 +575,9 @@ def main():
                # socket power and shader clock sampled (hwmon, every 25 ms) while the timed region ran
                "board": board,
                # peak device memory over the timed region (allocated by tensors / held by the caching allocator)
-               "device_memory": mem_main}
+               "device_memory": mem_main,
+               # the timed steps' own GPU durations (events at the step boundaries): a stall would show as max >> median
+               "step_ms": step_spread}
         if alt:
             out["alt_conv_math"] = alt
         if others:

@@ -1014,10 +1014,10 @@ class _SideWgrad:
     ``self.keep`` until join() has made the main stream wait for the side stream -- from then on a release on the main stream is
     ordered after every side-stream access.  (Round 4 used ``Tensor.record_stream`` instead.  That defers the reuse of a block
     until the HOST sees the side stream's event complete; a host that enqueues K unsynchronised steps runs far ahead of the
-    GPU, sees none complete and takes NEW memory for every step -- ~10 GB per fp32-storage step -- until hipMalloc fails and
-    the allocator drains the device and frees its cache: a 2 s stall in the middle of `bench.py --conv-math x3 --steps 30`,
-    in every process that started while the previous one's 250 GB were still being returned, found with
-    tools/step_timeline.py / a per-thread CPU sampler: kernels at their normal durations, the main thread asleep.)"""
+    GPU, sees none complete and takes NEW memory for every step (measured: 53-75 GB of reserve for 3-6 GB of tensors after 30-60
+    steps, 22-26 ms of host time per step inside hipMalloc), and once an allocation fails the allocator drains the device and frees
+    its cache: a 2 s stall in the middle of `bench.py --conv-math x3 --steps 30` in every second of a row of processes -- kernels
+    at their normal durations, the main thread asleep (docs/experiments_r05.md).)"""
 
     def __init__(self, device):
         self.on = side_stream_enabled()

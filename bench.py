@@ -162,8 +162,12 @@ def mem_record(device):
     """Peak device memory since the last reset: what the caching allocator handed out (allocated) and what it holds (reserved).
     Reserved far above allocated in a leg = the allocator could not reuse freed blocks (a host that ran ahead of events recorded on
     a second stream) -- the symptom of the round-4 side-stream stall (ops._SideWgrad)."""
+    st = torch.cuda.memory_stats(device)
     return {"max_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-            "max_reserved_GB": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)}
+            "max_reserved_GB": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2),
+            # since process start: hipMalloc calls the allocator had to make, and allocations that failed first (the allocator then
+            # synchronises the device and frees its cache before retrying: a stall)
+            "device_mallocs": int(st.get("num_device_alloc", 0)), "alloc_retries": int(st.get("num_alloc_retries", 0))}
 
 
 def run_steps(runner, batch, k, sync, spread=None):

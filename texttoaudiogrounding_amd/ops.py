@@ -1015,9 +1015,9 @@ class _SideWgrad:
     ordered after every side-stream access.  (Round 4 used ``Tensor.record_stream`` instead.  That defers the reuse of a block
     until the HOST sees the side stream's event complete; a host that enqueues K unsynchronised steps runs far ahead of the
     GPU, sees none complete and takes NEW memory for every step (measured: 53-75 GB of reserve for 3-6 GB of tensors after 30-60
-    steps, 22-26 ms of host time per step inside hipMalloc), and once an allocation fails the allocator drains the device and frees
-    its cache: a 2 s stall in the middle of `bench.py --conv-math x3 --steps 30` in every second of a row of processes -- kernels
-    at their normal durations, the main thread asleep (docs/experiments_r05.md).)"""
+    steps -- 100-150 GB on a fast box --, 22-26 ms of host time per step inside hipMalloc), and in every second of a row of
+    `bench.py --conv-math x3 --steps 30` processes ONE such hipMalloc blocked for 0.7-2.6 s (the driver still reclaiming the
+    previous process's reserve): kernels at their normal durations, the main thread asleep (docs/experiments_r05.md).)"""
 
     def __init__(self, device):
         self.on = side_stream_enabled()

@@ -161,7 +161,7 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
 def mem_record(device):
     """Peak device memory since the last reset: what the caching allocator handed out (allocated) and what it holds (reserved).
     Reserved far above allocated in a leg = the allocator could not reuse freed blocks (a host that ran ahead of events recorded on
-    a second stream) -- the symptom of the round-4 side-stream stall (ops._SideWgrad)."""
+    a second stream) -- the symptom of the round-4 side-stream growth (ops._SideWgrad)."""
     st = torch.cuda.memory_stats(device)
     return {"max_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "max_reserved_GB": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2),
@@ -174,8 +174,8 @@ def run_steps(runner, batch, k, sync, spread=None):
     """k training steps; returns (wall seconds incl. the closing sync, host seconds spent INSIDE train_step = the time one core
     needs to enqueue a step: ctypes launches + autograd bookkeeping, no synchronisation), and the last loss.
     spread: a dict that receives {"min", "median", "max"} of the k steps' own GPU durations (one HIP event per step boundary on the
-    compute stream -- a marker packet, no synchronisation): a stall inside the timed region (round 5: the allocator draining the
-    device in the middle of an unsynchronised run) shows as max >> median instead of hiding in the mean."""
+    compute stream -- a marker packet, no synchronisation): a stall inside the timed region (round 5: one hipMalloc blocking for
+    seconds in the middle of an unsynchronised run) shows as max >> median instead of hiding in the mean."""
     host = 0.0
     loss = None
     marks = None

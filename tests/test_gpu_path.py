@@ -1150,7 +1150,7 @@ def test_side_stream_steps_without_a_host_sync_do_not_grow_the_allocator(dev, mo
     does) with the weight-gradient convs on the side stream: the caching allocator's reserve must stay at the level of one step.
     Round 4 marked the side stream's operands with Tensor.record_stream, which defers a block's reuse until the HOST sees the side
     stream's event complete -- a host running ahead of the GPU saw none complete and took new memory every step (53-75 GB after
-    30-60 steps of the benched size, then a drain-the-device stall once hipMalloc failed).  The operands are now kept alive until
+    30-60 steps of the benched size, with single hipMalloc calls blocking for 0.7-2.6 s in every second process of a row).  The operands are now kept alive until
     join(); the old rule (TAG_SIDE_RECORD_STREAM=1) stays switchable and must give bit-identical gradients."""
     from texttoaudiogrounding_amd import ops
     from texttoaudiogrounding_amd.runner import StrongRunner

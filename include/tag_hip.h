@@ -167,6 +167,26 @@ int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, float* da, con
                              const float* bn_scale, const float* bn_shift, const float* bn_mean,
                              const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
                              void* stream);
+/* Winograd F(2x2,3x3) form of the same convolution (csrc/conv_wino.hip), all fp32: the A1 ConvBlock convs of
+ * models/panns.py:29-38,49-50 as input transform (producer BatchNorm+ReLU prologue and zero padding applied on load) ->
+ * 16 dense products (T x Cin).(Cin x Cout) on the exact-fp32 MFMA in one batched launch (T = B*ceil(H/2)*ceil(W/2) tiles,
+ * 2.25 x fewer MFMA FLOP than tag_conv3x3_forward) -> output transform, which also writes EITHER the BatchNorm partial
+ * statistics of y (rows [K | r | q][Cout] + counts, folded by tag_bn_stats_from_partials) OR, for the dgrad form, the sums
+ * [sum g | sum g*xhat][Cout] of the BatchNorm+ReLU backward the gradient flows into (folded by tag_bn_grad_from_partials):
+ * drop-in for tag_conv3x3_forward(stats) / tag_conv3x3_dgrad_bnsums on the deep layers.  Error vs an fp64 convolution:
+ * ~2.3 x the direct fp32 kernel's (same rounding class).
+ *   ufwd [16][Cin][Cout] / udgrad [16][Cout][Cin]: G g G^T of the filter / of the tap-flipped, channel-swapped filter;
+ *   ws: tag_conv3x3_wino_ws_bytes (transformed input + product planes); P = tag_conv3x3_wino_stats_rows;
+ *   tag_conv3x3_wino_ok: 1 when the shape is served (channel counts 32..1024 whose quarter divides 256, Cin % 32 == 0). */
+int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout);
+int tag_pack_conv_weight_wino(const float* w /*(Cout,Cin,3,3)*/, float* ufwd, float* udgrad, int Cin, int Cout, void* stream);
+size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout);
+int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
+                             float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
+int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* udgrad, float* da, const float* yref, const float* bn_scale,
+                                  const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B,
+                                  int H, int W, int Cin, int Cout, void* ws, void* stream);
 size_t tag_bn_grad_from_partials_ws_bytes(int P, int C);
 int tag_bn_grad_from_partials(const float* bnpart, int P, int C, float* dgamma, float* dbeta, void* ws, void* stream);
 int tag_bnrelu_backward_apply(const float* y, const float* scale, const float* shift, const float* mean,

@@ -721,13 +721,16 @@ def test_conv_dgrad_fused_bnrelu_backward(ops, dev, B, H, W, Cin, C):
     e = (relerr(nchw(dy), yd.grad), relerr(dg, gd.grad), relerr(db, bd.grad))
     print(f"fused dgrad+BN backward: dy {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
     assert max(e) < 1e-5
-    # and equal (to rounding) to the unfused kernels
-    old = ops.FUSE_BN_BWD_SUMS
-    ops.FUSE_BN_BWD_SUMS = False
+    # and equal (to rounding) to the unfused kernels: like with like -- the direct conv both times (a launch large enough for the
+    # Winograd form, tests/test_gpu_wino.py, would differ from the direct conv by both kernels' rounding)
+    old, oldw = ops.FUSE_BN_BWD_SUMS, ops.CONV_WINOGRAD
+    ops.CONV_WINOGRAD = False
     try:
+        dy, dg, db = ops.conv3x3_dgrad_bnrelu_backward(nhwc(du).to(dev), wd, yh, st, gamma.to(dev))
+        ops.FUSE_BN_BWD_SUMS = False
         dy2, dg2, db2 = ops.conv3x3_dgrad_bnrelu_backward(nhwc(du).to(dev), wd, yh, st, gamma.to(dev))
     finally:
-        ops.FUSE_BN_BWD_SUMS = old
+        ops.FUSE_BN_BWD_SUMS, ops.CONV_WINOGRAD = old, oldw
     assert relerr(dy, dy2) < 2e-6 and relerr(dg, dg2) < 2e-6 and relerr(db, db2) < 2e-6
 
 

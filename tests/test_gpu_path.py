@@ -664,7 +664,7 @@ def test_full_length_train_step_vs_oracle(dev):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name
 
 
-@pytest.mark.parametrize("math_", ["fp32", "x9"])
+@pytest.mark.parametrize("math_", ["fp32", "fp32-direct", "x9"])
 def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_):
     """Parity AT THE BENCHED SIZE (BASELINE configs[1]: B = 64, 10 s clips, train-mode BatchNorm, dropout ON) -- the grids
     where the XCD remap, 3-workgroup/CU residency, split-K counts and the 128-workgroup persistent GRU actually live.
@@ -682,11 +682,18 @@ def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_)
     seeds = iter(int(v) for v in gold["dropout_seeds"])
     monkeypatch.setattr(ops, "new_seed", lambda: next(seeds))
     # "x9" (round 4): the all-nine-products split arithmetic is held to the SAME bounds as the exact-fp32 MFMA kernels
-    monkeypatch.setattr(ops, "CONV_MATH", math_)
+    # "fp32" (the default path, round 5): blocks 3 and 4 run their forward and conv2-dgrad launches as Winograd F(2x2,3x3)
+    # (csrc/conv_wino.hip) at this size; "fp32-direct" = the direct halo-tile kernels everywhere (TAG_CONV_WINOGRAD=0) -- same bounds
+    monkeypatch.setattr(ops, "CONV_MATH", "fp32" if math_ == "fp32-direct" else math_)
+    monkeypatch.setattr(ops, "CONV_WINOGRAD", math_ == "fp32")
+    wino0 = ops.WINO_LAUNCHES
     model = build_hip_model(st, "dot", dev).train()
     runner = StrongRunner(model, device=str(dev))
     loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
     lv = runner.loss_value(loss)                       # also raises if the GRU exchange timed out at this grid
+    # 3 forward launches (256->256 of block 3, 256->512 and 512->512 of block 4) + 2 dgrad launches carrying BatchNorm-backward
+    # sums (the conv2 of blocks 3 and 4)
+    assert ops.WINO_LAUNCHES - wino0 == (5 if math_ == "fp32" else 0), ops.WINO_LAUNCHES - wino0
     info = model.audio_encoder._last_dropout
     assert info["seeds"] == [int(v) for v in gold["dropout_seeds"]]
     # the masks the kernels drew are the masks the oracle replayed (CPU restatement of the generator, checked by count)

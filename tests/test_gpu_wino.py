@@ -1,0 +1,162 @@
+"""Winograd F(2x2,3x3) form of the deep-layer convolutions (csrc/conv_wino.hip; models/panns.py:29-38,49-50) against an fp64
+convolution: forward with every producer prologue and the fused BatchNorm batch statistics, dgrad with the fused
+BatchNorm+ReLU-backward sums, odd heights / widths (tiles that hang over the image), tile counts that do and do not fill the
+GEMM tiles, and the dispatch rule of ops.py (which launches take this path).  Tolerances: 5e-6 of the output range -- the
+direct fp32 kernel's own bound in tests/test_gpu_kernels.py (measured: 1e-6, against 2e-6 ... 4e-6 of the direct kernel at 512
+input channels: 16 chains of Cin products round less than one chain of 9 Cin)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from texttoaudiogrounding_amd import ops as _ops
+    return _ops
+
+
+def wino_pack(ops, w):
+    Cout, Cin = w.shape[:2]
+    uf = torch.empty(16, Cin, Cout, device=w.device)
+    ud = torch.empty(16, Cout, Cin, device=w.device)
+    ops.call("tag_pack_conv_weight_wino", ops.ptr(w), ops.ptr(uf), ops.ptr(ud), Cin, Cout)
+    return uf, ud
+
+
+def prologue64(x, mode, s, t):
+    if mode == 1:
+        return torch.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1))
+    if mode == 2:
+        return F.leaky_relu(x, 0.1) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    if mode == 3:
+        return x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    return x
+
+
+SHAPES = [(2, 10, 8, 64, 128, 1),      # whole tiles, 40-tile launch: ragged GEMM tiles
+          (3, 9, 7, 128, 64, 0),       # odd height AND width: the last tile row / column hangs over the image
+          (1, 1, 2, 32, 32, 3),        # a single tile row of one-pixel height
+          (2, 37, 16, 256, 256, 2),    # the 1.5 s fixture's block-3 geometry
+          (8, 64, 8, 512, 256, 1)]     # 1024 tiles = whole 128-row GEMM tiles (the loader without tail handling)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES)
+def test_wino_forward_and_statistics(ops, dev, B, H, W, Cin, Cout, pro):
+    """tag_conv3x3_wino_forward: y = conv(prologue(x)) and the partial statistics rows folded by tag_bn_stats_from_partials."""
+    g = torch.Generator().manual_seed(B * H + W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g) * (1.0 + torch.arange(Cin).view(1, Cin, 1, 1) % 3)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    s, t = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    ref = F.conv2d(prologue64(x.double(), pro, s.double(), t.double()), w.double(), padding=1)
+    assert ops.query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout) == 1
+    xh, wh, sd, td = nhwc(x).to(dev), w.to(dev), s.to(dev), t.to(dev)     # (kept alive: the calls below take raw pointers)
+    uf, _ = wino_pack(ops, wh)
+    P = ops.query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
+    y = torch.full((B, H, W, Cout), float("nan"), device=dev)
+    part = torch.full((P * (3 * Cout + 1),), float("nan"), device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout) // 4, device=dev)
+    ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y),
+             ops.ptr(part), B, H, W, Cin, Cout, ops.ptr(ws))
+    e = relerr(nchw(y), ref)
+    assert e < 5e-6, e
+    # statistics: every pixel counted exactly once, mean / invstd of the kernel's OWN output
+    assert int(part[P * 3 * Cout:].sum().item()) == B * H * W
+    gam, bet = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    st = ops.bn_stats(y.view(-1, Cout), gam, bet, None, None, True, partials=(P, part))
+    y64 = y.double().view(-1, Cout)
+    m64, v64 = y64.mean(0), y64.var(0, unbiased=False)
+    assert (st.mean.double() - m64).abs().max().item() < 2e-6 * (m64.abs().max().item() + v64.sqrt().max().item())
+    assert ((st.invstd.double() * torch.sqrt(v64 + 1e-5)) - 1.0).abs().max().item() < 5e-6
+    # without a statistics buffer the same output, bit for bit
+    y2 = torch.empty_like(y)
+    ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y2), None,
+             B, H, W, Cin, Cout, ops.ptr(ws))
+    assert torch.equal(y, y2)
+    print(f"wino forward {B}x{H}x{W} {Cin}->{Cout} prologue {pro}: err {e:.2e}, P {P}")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES)
+def test_wino_dgrad_and_bn_backward_sums(ops, dev, B, H, W, Cin, Cout, pro):
+    """tag_conv3x3_wino_dgrad_bnsums: da = conv_transpose(dy, w) and sum g / sum g xhat of the BatchNorm+ReLU backward it flows into."""
+    g = torch.Generator().manual_seed(B * H + W + Cout + 1)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cout)
+    yref = torch.randn(B, Cin, H, W, generator=g) * 2.0 + 0.2
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    mean, invstd = 0.1 * torch.randn(Cin, generator=g), torch.rand(Cin, generator=g) + 0.5
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    wh = w.to(dev)
+    _, ud = wino_pack(ops, wh)
+    P = ops.query("tag_conv3x3_wino_stats_rows", B, H, W, Cin)
+    da = torch.full((B, H, W, Cin), float("nan"), device=dev)
+    part = torch.full((P * 2 * Cin,), float("nan"), device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, Cout, Cin) // 4, device=dev)
+    yh, dyh = nhwc(yref).to(dev), nhwc(dy).to(dev)
+    scd, shd, md, isd = sc.to(dev), sh.to(dev), mean.to(dev), invstd.to(dev)      # (kept alive: raw pointers below)
+    ops.call("tag_conv3x3_wino_dgrad_bnsums", ops.ptr(dyh), ops.ptr(ud), ops.ptr(da), ops.ptr(yh), ops.ptr(scd),
+             ops.ptr(shd), ops.ptr(md), ops.ptr(isd), ops.ptr(part), B, H, W, Cout, Cin, ops.ptr(ws))
+    e = relerr(nchw(da), ref)
+    assert e < 5e-6, e
+    dg, db = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
+    wsb = ops._ws(ops.query("tag_bn_grad_from_partials_ws_bytes", P, Cin), da)
+    ops.call("tag_bn_grad_from_partials", ops.ptr(part), P, Cin, ops.ptr(dg), ops.ptr(db), ops.ptr(wsb))
+    # against fp64 sums over the kernel's own da with the mask the kernel's arithmetic gives (fmaf(y, scale, shift) > 0)
+    # (a single-rounding fmaf keeps the sign of the exact y * scale + shift, which fp64 holds exactly)
+    mask = (nhwc(yref).double() * sc.double() + sh.double()) > 0
+    gg = da.double().cpu() * mask
+    db64 = gg.sum(dim=(0, 1, 2))
+    dg64 = (gg * (nhwc(yref).double() - mean.double()) * invstd.double()).sum(dim=(0, 1, 2))
+    scale = max(db64.abs().max().item(), dg64.abs().max().item())
+    assert (db.cpu().double() - db64).abs().max().item() < 5e-6 * scale
+    assert (dg.cpu().double() - dg64).abs().max().item() < 5e-6 * scale
+    print(f"wino dgrad {B}x{H}x{W} {Cout}->{Cin}: err {e:.2e}")
+
+
+def test_wino_dispatch_rule(ops, dev, monkeypatch):
+    """ops.conv3x3_stats / conv3x3_dgrad_bnrelu_backward take the Winograd form exactly for fp32 training launches on 8- / 16-wide
+    images with both channel counts >= WINO_MIN_C and at least WINO_MIN_TILES tiles; everything else keeps the direct kernel; the
+    two forms agree to both kernels' rounding, and a run is bit-reproducible."""
+    B, H, W, C = 4, 64, 16, 256                   # 1024 tiles
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, C, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
+    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1024)
+    wf, wd = ops.pack_conv_weight(w, W=W)
+    assert hasattr(wf, "wino_u") and hasattr(wd, "wino_u")
+    n0 = ops.WINO_LAUNCHES
+    y_w, part_w = ops.conv3x3_stats(x, wf, C)
+    y_w2, _ = ops.conv3x3_stats(x, wf, C)
+    assert ops.WINO_LAUNCHES == n0 + 2 and torch.equal(y_w, y_w2)
+    y_e = ops.conv3x3(x, wf, C)                   # no statistics wanted (inference): direct
+    assert ops.WINO_LAUNCHES == n0 + 2
+    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1025)
+    y_d, part_d = ops.conv3x3_stats(x, wf, C)
+    assert ops.WINO_LAUNCHES == n0 + 2 and torch.equal(y_d, y_e)
+    assert relerr(y_w, y_d) < 5e-6
+    assert part_w[0] == ops.query("tag_conv3x3_wino_stats_rows", B, H, W, C) and part_d[0] == ops.query("tag_conv3x3_stats_rows", B, H, W, C)
+    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "CONV_WINOGRAD", False)
+    ops.conv3x3_stats(x, wf, C)
+    assert ops.WINO_LAUNCHES == n0 + 2
+    monkeypatch.setattr(ops, "CONV_WINOGRAD", True)
+    wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 channels: below WINO_MIN_C, no Winograd weights made
+    assert not hasattr(wf64, "wino_u")
+    wf32, _ = ops.pack_conv_weight(w, W=32)                              # 32-wide image: direct
+    assert not hasattr(wf32, "wino_u")

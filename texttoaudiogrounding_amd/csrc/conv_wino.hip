@@ -1,0 +1,316 @@
+// Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / padding 1 convolutions of the DEEP ConvBlocks (models/panns.py:29-38,
+// 49-50: conv1 / conv2 of blocks 3 and 4 of Cnn8Rnn, models/audio_encoder.py:134-138), forward and dgrad, all fp32.
+//
+//   y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2 x 2 output tile, 4 x 4 input tile d and filter g (Lavin & Gray 2015)
+//
+// 16 multiplies per 2 x 2 outputs and channel pair instead of 36: the contraction over the input channels becomes 16
+// independent dense products  M_xi (T x Cout) = V_xi (T x Cin) . U_xi (Cin x Cout),  T = B * ceil(H/2) * ceil(W/2) tiles,
+// with 2.25 x fewer MFMA FLOP than the direct kernel (csrc/conv.hip) spends -- the direct kernel runs at 0.86-0.88 of the
+// fp32 MFMA peak, so on the layers whose channel count makes the products long enough this is the only lever left that is
+// worth more than a per cent.  Every operation is fp32 (transforms on the VALU, products on v_mfma_f32_32x32x2_f32 through
+// the dense GEMM kernel of gemm.hip, one batched launch); the transform constants are 0, +-1 and 1/2, the measured error
+// against an fp64 convolution is 2.3 x the direct fp32 kernel's (1.1e-7 against 4.6e-8 of the output range, rms, at 512
+// input channels) -- the same rounding class.  Three kernels per convolution:
+//   wino_input_kernel    x (B,H,W,Cin) -> V [16][T][Cin]: producer BatchNorm + ReLU prologue and zero padding applied on load
+//                        (the same prologue modes as conv3x3_halo_kernel), B^T d B on 4 channels per thread, 16-byte accesses;
+//   gemm_kernel (gemm.hip, tag_launch_gemm_batched)  M [16][T][Cout] = V . U, 128 x 128 tiles;
+//   wino_output_kernel   M -> y (B,H,W,Cout) = A^T m A, and in the same pass EITHER the BatchNorm batch statistics of y
+//                        (pivoted partial rows [K | r | q] + counts, the layout tag_bn_stats_from_partials folds) OR the
+//                        sums of the BatchNorm+ReLU backward the gradient flows into (rows [sum g | sum g xhat] for
+//                        tag_bn_grad_from_partials) -- the EPI == 0 / EPI == 1 epilogues of the direct kernel.
+// The two transform passes are HBM-bound (V and M are 4 x the activation each); they cost ~0.5 ms of the ~1.5 ms the
+// 512 -> 512 layer gains per launch at B = 64.  Fixed summation order everywhere, no atomics: bit-reproducible.
+#include "tag_common.h"
+
+int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,
+                            int N, int K, int batch, hipStream_t st);
+
+namespace {
+
+__device__ __forceinline__ f32x4 wino_prologue(f32x4 v, int mode, f32x4 s, f32x4 t) {      // = apply_prologue of conv.hip
+    if (mode == 1) {
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.0f); v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.0f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.0f); v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.0f);
+    } else if (mode == 2) {
+        v.x = fmaf(v.x > 0 ? v.x : 0.1f * v.x, s.x, t.x); v.y = fmaf(v.y > 0 ? v.y : 0.1f * v.y, s.y, t.y);
+        v.z = fmaf(v.z > 0 ? v.z : 0.1f * v.z, s.z, t.z); v.w = fmaf(v.w > 0 ? v.w : 0.1f * v.w, s.w, t.w);
+    } else if (mode == 3) {
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+    }
+    return v;
+}
+
+// U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: Uf[xi][ci][co] from w[co][ci][ky][kx] (forward), and
+// Ud[xi][co][ci] from the tap-flipped filter w[co][ci][2-ky][2-kx] (dgrad: the transposed convolution as a convolution
+// from the Cout-channel gradient to the Cin-channel gradient).  One thread per (ci, co) pair.
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ Uf,
+                                                        float* __restrict__ Ud, int Cin, int Cout) {
+    const long n = (long)Cin * Cout;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int co = (int)(e / Cin), ci = (int)(e % Cin);
+        float g[3][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = w[e * 9 + k];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            float* U = dir == 0 ? Uf : Ud;
+            if (!U) continue;
+            float p[4][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g0 = dir == 0 ? g[0][c] : g[2][2 - c], g1 = dir == 0 ? g[1][c] : g[1][2 - c],
+                            g2 = dir == 0 ? g[2][c] : g[0][2 - c];
+                p[0][c] = g0;
+                p[1][c] = 0.5f * (g0 + g1 + g2);
+                p[2][c] = 0.5f * (g0 - g1 + g2);
+                p[3][c] = g2;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = p[r][0], u1 = 0.5f * (p[r][0] + p[r][1] + p[r][2]), u2 = 0.5f * (p[r][0] - p[r][1] + p[r][2]),
+                            u3 = p[r][2];
+                const size_t base = dir == 0 ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
+                U[(size_t)(4 * r + 0) * n + base] = u0;
+                U[(size_t)(4 * r + 1) * n + base] = u1;
+                U[(size_t)(4 * r + 2) * n + base] = u2;
+                U[(size_t)(4 * r + 3) * n + base] = u3;
+            }
+        }
+    }
+}
+
+// V[xi = 4 r + s][t][c] = (B^T d B)[r][s],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]],  d = the 4 x 4 input window of
+// tile t = (b, i, j): rows 2 i - 1 .. 2 i + 2, columns 2 j - 1 .. 2 j + 2 (zero outside the image, AFTER the prologue).
+// A thread owns 4 consecutive channels of one tile; the C / 4 threads of a tile are neighbours (16-byte coalesced both ways).
+template <int PRO>
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift, float* __restrict__ V, int B, int H,
+                                                         int W, int C, int th, int tw, long T) {
+    const int cq = C >> 2;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t = item / cq;
+    const int q = (int)(item - t * cq);
+    if (t >= T) return;
+    const int j = (int)(t % tw);
+    const long bi = t / tw;
+    const int i = (int)(bi % th), b = (int)(bi / th);
+    f32x4 rs = {1.0f, 1.0f, 1.0f, 1.0f}, rt = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRO != 0) {
+        rs = *reinterpret_cast<const f32x4*>(in_scale + 4 * q);
+        rt = *reinterpret_cast<const f32x4*>(in_shift + 4 * q);
+    }
+    const float* xb = x + (size_t)b * H * W * C + 4 * q;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = 2 * i - 1 + r;
+        const bool okh = (unsigned)h < (unsigned)H;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int w = 2 * j - 1 + s;
+            const bool ok = okh && (unsigned)w < (unsigned)W;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ok) v = wino_prologue(*reinterpret_cast<const f32x4*>(xb + ((size_t)h * W + w) * C), PRO, rs, rt);
+            d[r][s] = v;
+        }
+    }
+    f32x4 tt[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        tt[0][s] = d[0][s] - d[2][s];
+        tt[1][s] = d[1][s] + d[2][s];
+        tt[2][s] = d[2][s] - d[1][s];
+        tt[3][s] = d[1][s] - d[3][s];
+    }
+    const size_t plane = (size_t)T * C;
+    float* vp = V + (size_t)t * C + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * r + 0) * plane) = tt[r][0] - tt[r][2];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * r + 1) * plane) = tt[r][1] + tt[r][2];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * r + 2) * plane) = tt[r][2] - tt[r][1];
+        *reinterpret_cast<f32x4*>(vp + (size_t)(4 * r + 3) * plane) = tt[r][1] - tt[r][3];
+    }
+}
+
+struct WinoEpi {
+    const float* yref;      // EPI == 1: (B,H,W,C) raw conv output saved by the forward pass (= BatchNorm input)
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+};
+
+// y (2 x 2 pixels of tile t) = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]],  m[r][s] = M[4 r + s][t][c].  A workgroup holds
+// G = 256 / (C / 4) tile slots and walks ITERS tiles per slot (tile = (blockIdx.x * ITERS + it) * G + slot); every slot
+// writes ONE partial row (row = blockIdx.x * G + slot) of
+//   EPI == 0: [K | r | q][C] + count -- pivot K = the thread's first output, r = sum(y - K), q = sum((y - K)^2) over the
+//             slot's pixels (tag_bn_stats_from_partials; the layout of the direct kernel's EPI == 0 and of conv_c1_fwd_rows);
+//   EPI == 1: [sum g | sum g xhat][C], g = y where bn(yref) > 0 (tag_bn_grad_from_partials; the direct kernel's EPI == 1).
+constexpr int WINO_ITERS = 8;
+template <int EPI>
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, float* __restrict__ y,
+                                                          float* __restrict__ stats, WinoEpi epi, int B, int H, int W, int C,
+                                                          int th, int tw, long T, int P) {
+    const int cq = C >> 2, G = 256 / cq;
+    const int slot = threadIdx.x / cq, q = threadIdx.x - slot * cq;
+    const size_t plane = (size_t)T * C;
+    float sk[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float cnt = 0.0f;
+    bool have_pivot = false;
+    f32x4 bsc = {0, 0, 0, 0}, bsh = {0, 0, 0, 0}, bmu = {0, 0, 0, 0}, bis = {0, 0, 0, 0};
+    if (EPI == 1) {
+        bsc = *reinterpret_cast<const f32x4*>(epi.scale + 4 * q); bsh = *reinterpret_cast<const f32x4*>(epi.shift + 4 * q);
+        bmu = *reinterpret_cast<const f32x4*>(epi.mean + 4 * q); bis = *reinterpret_cast<const f32x4*>(epi.invstd + 4 * q);
+    }
+    for (int it = 0; it < WINO_ITERS; ++it) {
+        const long t = ((long)blockIdx.x * WINO_ITERS + it) * G + slot;
+        if (t >= T) break;
+        const int j = (int)(t % tw);
+        const long bi = t / tw;
+        const int i = (int)(bi % th), b = (int)(bi / th);
+        const float* mp = M + (size_t)t * C + 4 * q;
+        f32x4 m[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) m[r][s] = *reinterpret_cast<const f32x4*>(mp + (size_t)(4 * r + s) * plane);
+        f32x4 u[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u[0][s] = m[0][s] + m[1][s] + m[2][s];
+            u[1][s] = m[1][s] - m[2][s] - m[3][s];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int h = 2 * i + a;
+            if (h >= H) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int w = 2 * j + e;
+                if (w >= W) continue;
+                const f32x4 o = e == 0 ? u[a][0] + u[a][1] + u[a][2] : u[a][1] - u[a][2] - u[a][3];
+                const size_t off = (((size_t)b * H + h) * W + w) * C + 4 * q;
+                *reinterpret_cast<f32x4*>(y + off) = o;
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                if (EPI == 0 && stats) {
+                    if (!have_pivot) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sk[k] = ov[k];
+                        have_pivot = true;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float dv = ov[k] - sk[k]; s1[k] += dv; s2[k] = fmaf(dv, dv, s2[k]); }
+                    cnt += 1.0f;
+                }
+                if (EPI == 1) {
+                    const f32x4 yr = *reinterpret_cast<const f32x4*>(epi.yref + off);
+                    const float yv[4] = {yr.x, yr.y, yr.z, yr.w};
+                    const float sc[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sh[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+                    const float mu[4] = {bmu.x, bmu.y, bmu.z, bmu.w}, is[4] = {bis.x, bis.y, bis.z, bis.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float g = fmaf(yv[k], sc[k], sh[k]) > 0.0f ? ov[k] : 0.0f;
+                        s1[k] += g;
+                        s2[k] = fmaf(g, (yv[k] - mu[k]) * is[k], s2[k]);
+                    }
+                }
+            }
+        }
+    }
+    const int prow = blockIdx.x * G + slot;
+    if (slot >= G || prow >= P) return;
+    if (EPI == 0 && stats) {
+        float* ps = stats + (size_t)prow * 3 * C + 4 * q;
+        *reinterpret_cast<f32x4*>(ps) = (f32x4){sk[0], sk[1], sk[2], sk[3]};
+        *reinterpret_cast<f32x4*>(ps + C) = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4*>(ps + 2 * C) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+        if (q == 0) stats[(size_t)P * 3 * C + prow] = cnt;
+    }
+    if (EPI == 1) {
+        float* ps = stats + (size_t)prow * 2 * C + 4 * q;
+        *reinterpret_cast<f32x4*>(ps) = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4*>(ps + C) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+    }
+}
+
+struct WinoGeom { int th, tw; long T; int G, P; };
+inline WinoGeom wino_geom(int B, int H, int W, int Cout) {
+    WinoGeom g;
+    g.th = (H + 1) / 2; g.tw = (W + 1) / 2;
+    g.T = (long)B * g.th * g.tw;
+    g.G = 256 / (Cout / 4);
+    const long per_wg = (long)g.G * WINO_ITERS;
+    g.P = (int)((g.T + per_wg - 1) / per_wg) * g.G;
+    return g;
+}
+// channel counts the transform kernels take: C / 4 threads per tile must divide a 256-thread workgroup
+inline bool wino_channels_ok(int C) { return C >= 32 && C <= 1024 && C % 4 == 0 && 256 % (C / 4) == 0; }
+
+int wino_run(const float* x, const float* U, int pro, const float* s, const float* t, float* y, float* stats, const WinoEpi* epi,
+             int B, int H, int W, int Cin, int Cout, float* ws, hipStream_t st) {
+    const WinoGeom g = wino_geom(B, H, W, Cout);
+    float* V = ws;
+    float* Mb = ws + (size_t)16 * g.T * Cin;
+    const long items = g.T * (Cin / 4);
+    const int gin = (int)((items + 255) / 256);
+    switch (pro) {
+        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
+        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
+        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
+        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
+    }
+    tag_launch_gemm_batched(V, Cin, g.T * Cin, U, Cout, (long)Cin * Cout, Mb, Cout, g.T * Cout, (int)g.T, Cout, Cin, 16, st);
+    const int gout = g.P / g.G;
+    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (epi)
+        hipLaunchKernelGGL(wino_output_kernel<1>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
+    else
+        hipLaunchKernelGGL(wino_output_kernel<0>, dim3(gout), dim3(256), 0, st, Mb, y, stats, none, B, H, W, Cout, g.th, g.tw, g.T, g.P);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout) {
+    if (!(B > 0 && H > 0 && W > 0 && wino_channels_ok(Cin) && wino_channels_ok(Cout) && Cin % 32 == 0)) return 0;
+    const WinoGeom g = wino_geom(B, H, W, Cout);
+    return g.T < (1L << 31) / 16 && (long)B * H * W < (1L << 31);
+}
+
+extern "C" int tag_pack_conv_weight_wino(const float* w, float* ufwd, float* udgrad, int Cin, int Cout, void* stream) {
+    TAG_CHECK_ARG(w && (ufwd || udgrad) && Cin > 0 && Cout > 0);
+    const long n = (long)Cin * Cout;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, ufwd,
+                       udgrad, Cin, Cout);
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    const WinoGeom g = wino_geom(B, H, W, Cout);
+    return (size_t)16 * g.T * ((size_t)Cin + Cout) * sizeof(float);
+}
+
+extern "C" int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout) {
+    if (!wino_channels_ok(Cout)) return 0;
+    return wino_geom(B, H, W, Cout).P;
+}
+
+extern "C" int tag_conv3x3_wino_forward(const float* x, const float* u, int prologue, const float* in_scale,
+                                        const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
+                                        void* ws, void* stream) {
+    TAG_CHECK_ARG(x && u && y && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+    TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
+    wino_run(x, u, prologue, in_scale, in_shift, y, stats, nullptr, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* u, float* da, const float* yref, const float* bn_scale,
+                                             const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart,
+                                             int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
+    TAG_CHECK_ARG(dy && u && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && ws);
+    TAG_CHECK_ARG(tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd};
+    wino_run(dy, u, 0, nullptr, nullptr, da, bnpart, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}

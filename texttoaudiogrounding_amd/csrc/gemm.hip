@@ -30,11 +30,12 @@ __device__ __forceinline__ float4 load4(const float* p, int n, bool aligned) {
 
 // KC = operand is k-contiguous in memory (element (r,k) at base[r*ld + k]); else mn-contiguous
 // (element (r,k) at base[k*ld + r]).  LDS image: S[r][LD] (KC) or S[k][LD] (else).  T = tile edge (64 or 128).
-template <bool KC, int T>
+template <bool KC, int T, int GKT = GK>
 struct Stage {
-    static constexpr int LD = KC ? GK + 4 : T;
-    static constexpr int SZ = KC ? T * (GK + 4) : GK * T;     // floats per buffer
-    static constexpr int NL = T / 32;       // float4 per thread per chunk
+    static constexpr int LD = KC ? GKT + 4 : T;
+    static constexpr int SZ = KC ? T * (GKT + 4) : GKT * T;     // floats per buffer
+    static constexpr int NL = T * GKT / 1024;       // float4 per thread per chunk
+    static constexpr int RQ = GKT / 4;              // float4 per row of a k-contiguous operand
     f32x4 reg[NL];
     // FAST: every tile and K chunk is whole and 16-byte aligned (checked by the launcher) -> plain float4 loads, no tail tests
     template <bool FAST>
@@ -44,7 +45,7 @@ struct Stage {
             const int idx = threadIdx.x + 256 * i;
             float4 v;
             if (KC) {
-                const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+                const int r = r0 + idx / RQ, k = k0 + (idx % RQ) * 4;
                 if constexpr (FAST) v = *reinterpret_cast<const float4*>(base + (size_t)r * ld + k);
                 else v = (r < rmax) ? load4(base + (size_t)r * ld + k, kmax - k, al) : make_float4(0, 0, 0, 0);
             } else {
@@ -60,7 +61,7 @@ struct Stage {
         for (int i = 0; i < NL; ++i) {
             const int idx = threadIdx.x + 256 * i;
             if (KC) {
-                const int r = idx >> 3, k = (idx & 7) * 4;
+                const int r = idx / RQ, k = (idx % RQ) * 4;
                 *reinterpret_cast<f32x4*>(s + r * LD + k) = reg[i];
             } else {
                 const int k = idx / (T / 4), r = (idx % (T / 4)) * 4;
@@ -152,16 +153,21 @@ typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
 // BF = false: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  BF = true (BASELINE configs[2] mode, tag_gemm_bf16): the same fp32
 // tensors and the same LDS image, but the fragments are rounded to bf16 (nearest-even) on their way from LDS to the registers
 // and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what autocast does to nn.Linear / the GRU projections.
-template <bool AKC, bool BKC, int T, bool BF = false, bool FAST = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+// GKT = K chunk per barrier of the fp32 form: 32 (default), or 16 for the batched Winograd-domain products -- half the LDS
+// (36.8 KB at 128 x 128: THREE workgroups per CU) and a barrier per 32 MFMAs, the configuration of conv3x3_halo_kernel's
+// half-tap weight stages, which is what keeps the matrix pipe fed there.
+template <bool AKC, bool BKC, int T, bool BF = false, bool FAST = false, int GKT = GK>
+__global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                    Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
-                                                   float* __restrict__ partial) {
-    constexpr int LDSA = Stage<AKC, T>::LD, LDSB = Stage<BKC, T>::LD;
-    constexpr int KCH = BF ? GKB : GK;     // K chunk per barrier
+                                                   float* __restrict__ partial, long sA = 0, long sB = 0, long sC = 0) {
+    // batched launches (tag_gemm_batched: the 16 Winograd-domain products of conv_wino.hip): blockIdx.y = batch entry
+    if (gridDim.y > 1) { A += (size_t)blockIdx.y * sA; B += (size_t)blockIdx.y * sB; C += (size_t)blockIdx.y * sC; }
+    constexpr int LDSA = Stage<AKC, T, GKT>::LD, LDSB = Stage<BKC, T, GKT>::LD;
+    constexpr int KCH = BF ? GKB : GKT;    // K chunk per barrier
     constexpr int TT = T / 64;             // 32x32 MFMA tiles per wave per dimension (waves 2 x 2)
-    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T>::SZ;                        // floats per buffer (16-byte aligned)
-    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T>::SZ;
+    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T, GKT>::SZ;                   // floats per buffer (16-byte aligned)
+    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T, GKT>::SZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                      // [2][ASZ]
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     // tools/gemm_bench.py): PD = 3 (64-tiles) / 2 (128-tiles) is 0-17 % SLOWER than PD = 1 -- the loop is bound by its
     // per-chunk instruction and barrier overhead (TAG_GEMM_ABL), not by the latency of the loads -- so one chunk ahead stays.
     constexpr int PD = 1;
-    typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T>>::type sa[PD];
-    typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T>>::type sb[PD];
+    typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T, GKT>>::type sa[PD];
+    typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T, GKT>>::type sb[PD];
     f32x16 acc[TT][TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         frag_b(0, bf[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < GK / 8; ++g) {
-            if (g + 1 < GK / 8) { frag_a(g + 1, af[(g + 1) & 1]); frag_b(g + 1, bf[(g + 1) & 1]); }
+        for (int g = 0; g < GKT / 8; ++g) {
+            if (g + 1 < GKT / 8) { frag_a(g + 1, af[(g + 1) & 1]); frag_b(g + 1, bf[(g + 1) & 1]); }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -344,20 +350,21 @@ int gemm_splits(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
-template <bool AKC, bool BKC, int T, bool BF = false>
+template <bool AKC, bool BKC, int T, bool BF = false, int GKT = GK>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                   Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st) {
-    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T>::SZ;
-    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T>::SZ;
+                   Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st, int batch = 1, long sA = 0,
+                   long sB = 0, long sC = 0) {
+    constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T, GKT>::SZ;
+    constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T, GKT>::SZ;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF, false, GKT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = ((M + T - 1) / T) * ((N + T - 1) / T) * splits;
-    constexpr int KCH = BF ? GKB : GK;
+    constexpr int KCH = BF ? GKB : GKT;
     int kchunk = (K + splits - 1) / splits;
     kchunk = (kchunk + KCH - 1) / KCH * KCH;
     // whole tiles, whole K chunks, no empty K slice, 16-byte aligned rows: the loader without tail handling
@@ -365,15 +372,15 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
     if (fast) {
         static bool fast_attr_set = false;
         if (!fast_attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC, T, BF, true, GKT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             fast_attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, true>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N,
-                           K, ep, a_al, b_al, splits, kchunk, partial);
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, true, GKT>), dim3(grid, batch), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M,
+                           N, K, ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC);
     } else {
-        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF>), dim3(grid), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K, ep,
-                           a_al, b_al, splits, kchunk, partial);
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, false, GKT>), dim3(grid, batch), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K,
+                           ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC);
     }
     if (splits > 1) {
         long nb = ((long)M * N + 255) / 256;
@@ -524,6 +531,24 @@ extern "C" int tag_gemm_bf16(const float* A, int lda, int transA, const float* B
     Epilogue ep{bias, act, accumulate, 1.0f, 0, 1, 1, 1};
     launch_gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, ep, static_cast<float*>(ws), as_stream(stream), true);
     TAG_LAUNCH_CHECK();
+    return 0;
+}
+
+// `batch` independent products C_b = A_b x B_b of one shape in ONE launch (blockIdx.y = b): A_b (M,K) row-major, B_b (K,N)
+// row-major, C_b (M,N); strides in floats.  128 x 128 tiles when M, N allow it (the launch as a whole makes many residency
+// rounds), no split-K, no epilogue.  Serves the Winograd-domain products of conv_wino.hip.
+int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,
+                            int N, int K, int batch, hipStream_t st) {
+    Epilogue ep{nullptr, 0, 0, 1.0f, 0, 1, 1, 1};
+    const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
+    const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
+    static const int gkt = getenv("TAG_WINO_GK") ? atoi(getenv("TAG_WINO_GK")) : 16;        // A/B: 32 = the dense GEMM's chunk
+    if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)
+        launch_gemm_t<true, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+    else if (M >= 128 && N >= 128)
+        launch_gemm_t<true, false, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+    else
+        launch_gemm_t<true, false, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
     return 0;
 }
 

@@ -343,10 +343,47 @@ def pack_conv_weight(w, want_dgrad=True, W=None):
         call("tag_pack_conv_weight", ptr(w), ptr(pf), ptr(pd), Cin, Cout)
         wf = pf if wf is None else wf
         wd = pd if wd is None else wd
+        if W is not None and _wino_shape(W, Cin, Cout) and wf is pf and (not want_dgrad or wd is pd):
+            # the direct packs stay what they are (inference, pool-sum epilogues, fallbacks); the Winograd-domain weights ride along
+            uf = _empty(16, Cin, Cout, like=w)
+            ud = _empty(16, Cout, Cin, like=w) if want_dgrad else None
+            call("tag_pack_conv_weight_wino", ptr(w), ptr(uf), ptr(ud), Cin, Cout)
+            pf.wino_u = uf
+            if want_dgrad:
+                pd.wino_u = ud
     return wf, (wd if want_dgrad else None)
 
 
 FUSE_BN_STATS = os.environ.get("TAG_FUSE_BN_STATS", "1") != "0"
+
+#: Winograd F(2x2,3x3) form (csrc/conv_wino.hip, all fp32) of the TRAINING forward (with fused BatchNorm statistics) and of the
+#: dgrad + BatchNorm-backward-sums launches of the deep layers: 2.25 x fewer MFMA FLOP than the direct halo-tile kernel, which
+#: runs at 0.86-0.88 of the fp32 MFMA peak.  Used where it was measured faster at B = 64 (tools/wino_bench.py): both channel
+#: counts >= WINO_MIN_C on the 8- / 16-wide images (Cnn8Rnn blocks 3 and 4: x1.13 ... x1.50 per launch).  "0" = direct kernels only.
+CONV_WINOGRAD = os.environ.get("TAG_CONV_WINOGRAD", "1") != "0"
+WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "256"))
+#: ... and only on launches with at least this many 2 x 2 output tiles (B * ceil(H/2) * ceil(W/2); 8192 = batch 17 of 10 s clips in
+#: block 4): below that the 16 products are too short to fill the chip and the direct kernel keeps the launch
+WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
+#: launches that took the Winograd path since import (tests assert that the benched-size step really runs through it)
+WINO_LAUNCHES = 0
+
+
+def _wino_shape(W, Cin, Cout) -> bool:
+    return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16) and min(Cin, Cout) >= WINO_MIN_C)
+
+
+def _wino_u(wpack, x, Cout):
+    """The Winograd-domain weights riding on a direct pack (pack_conv_weight) when this launch may use them, else None."""
+    u = getattr(wpack, "wino_u", None)
+    if u is None or not CONV_WINOGRAD or CONV_MATH != "fp32" or x.dtype != F32:
+        return None
+    B, H, W, Cin = x.shape
+    if B * ((H + 1) // 2) * ((W + 1) // 2) < WINO_MIN_TILES or not query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout):
+        return None
+    global WINO_LAUNCHES
+    WINO_LAUNCHES += 1
+    return u
 
 
 def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
@@ -361,6 +398,15 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     y = _empty(B, H, W, Cout, like=x, dtype=x.dtype)
     x3 = wpack.dtype == torch.uint8
     part = None
+    u = _wino_u(wpack, x, Cout) if (want_stats and FUSE_BN_STATS and not x3) else None
+    if u is not None:
+        P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
+        part = (P, _empty(P * (3 * Cout + 1), like=x))
+        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout), x)
+        with _timed(("conv3x3_wino", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
+            call("tag_conv3x3_wino_forward", ptr(x), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y), ptr(part[1]), B, H, W, Cin,
+                 Cout, ptr(ws))
+        return y, part
     if want_stats and FUSE_BN_STATS:
         if x3 and x.dtype == BF16:
             P = query("tag_conv3x3_x3_bf16_stats_rows", B, H, W, Cin, Cout, prologue)
@@ -431,12 +477,21 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
             after_conv()
         res = bnrelu_backward(yref, st, gamma, da, dg_out=dg_out, db_out=db_out)
         return (*res, True) if defer_apply else res
-    P = query("tag_conv3x3_stats_rows", B, H, W, C)
+    u = _wino_u(wpack, dy_in, C)
     da = _empty(B, H, W, C, like=dy_in)
-    part = _empty(P * 2 * C, like=dy_in)
-    with _timed(("conv3x3_halo_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
-        call("tag_conv3x3_dgrad_bnsums", ptr(dy_in), ptr(wpack), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
-             ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C)
+    if u is not None:
+        P = query("tag_conv3x3_wino_stats_rows", B, H, W, C)
+        part = _empty(P * 2 * C, like=dy_in)
+        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, C), dy_in)
+        with _timed(("conv3x3_wino", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+            call("tag_conv3x3_wino_dgrad_bnsums", ptr(dy_in), ptr(u), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
+                 ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C, ptr(ws))
+    else:
+        P = query("tag_conv3x3_stats_rows", B, H, W, C)
+        part = _empty(P * 2 * C, like=dy_in)
+        with _timed(("conv3x3_halo_kernel", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+            call("tag_conv3x3_dgrad_bnsums", ptr(dy_in), ptr(wpack), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
+                 ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C)
     if after_conv is not None:
         after_conv()
     dg = dg_out if dg_out is not None else _empty(C, like=da)

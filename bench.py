@@ -486,6 +486,21 @@ def main():
         sync()
         fam_iso, ops.PROFILE = families(ops.PROFILE), None
         ops.WGRAD_SIDE_STREAM = side_setting
+    # ---- the same K steps with the direct halo-tile kernels everywhere (TAG_CONV_WINOGRAD=0): what the Winograd form of the deep
+    # layers is worth on this box, in the driver-timed record
+    alt_algo = None
+    if args.conv_math == "fp32" and ops.CONV_WINOGRAD and not args.no_alt:
+        ops.CONV_WINOGRAD = False
+        runner.train_step(dict(batch))
+        sync()
+        dtd, host_d, _ = run_steps(runner, batch, args.steps, sync, None)
+        ops.CONV_WINOGRAD = True
+        if world > 1:
+            t = torch.tensor([dtd], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtd = t.item()
+        alt_algo = {"direct": {"conv_algo": "direct MFMA convolution in every layer (TAG_CONV_WINOGRAD=0)",
+                               "value": round(clips / dtd, 2), "unit": "clips/s", "ms_per_step": round(dtd / args.steps * 1e3, 3)}}
     # ---- the same K steps with the opt-in conv arithmetic (reported beside the contract's number, never as `value`)
     alt = None
     if args.conv_math == "fp32" and not args.no_alt:
@@ -571,10 +586,16 @@ def main():
                "data": "synthetic",
                "config": {"workload": workload_name(args), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
-                          "conv_math": args.conv_math},
+                          "conv_math": args.conv_math,
+                          "conv_algo": ("fp32 Winograd F(2x2,3x3) for the forward and dgrad convs of blocks 3-4 (both channel counts "
+                                        ">= 256; csrc/conv_wino.hip), direct MFMA convolution elsewhere"
+                                        if (args.conv_math == "fp32" and ops.CONV_WINOGRAD) else "direct MFMA convolution")},
                "loss": loss_value,
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /
                                              (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4),
+               # counts the ALGORITHMIC (direct-convolution) FLOP of the step, 101.7 GFLOP per clip; with the Winograd form of the deep
+               # layers the matrix pipe executes fewer (2.25 x fewer in those launches), so this is an effective rate, not pipe utilisation
+               "whole_step_mfma_frac_counts": "algorithmic direct-convolution FLOP (effective rate)",
                "roofline": roof,
                # socket power and shader clock sampled (hwmon, every 25 ms) while the timed region ran
                "board": board,
@@ -582,6 +603,8 @@ def main():
                "device_memory": mem_main,
                # the timed steps' own GPU durations (events at the step boundaries): a stall would show as max >> median
                "step_ms": step_spread}
+        if alt_algo:
+            out["alt_conv_algo"] = alt_algo
         if alt:
             out["alt_conv_math"] = alt
         if others:

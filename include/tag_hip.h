@@ -182,6 +182,12 @@ int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout);
 int tag_pack_conv_weight_wino(const float* w /*(Cout,Cin,3,3)*/, float* ufwd, float* udgrad, int Cin, int Cout, void* stream);
 size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout);
+/* weight gradient in the Winograd domain: dw (Cout,Cin,3,3) = G^T [ sum over tiles (A dY A^T) (.) (B^T prologue(x) B) ] G -- the
+ * adjoint of the forward form; 16 x S products (Cout x kc).(kc x Cin) over K slices of the tile axis in one batched launch,
+ * folded in a fixed order.  Drop-in for tag_conv3x3_wgrad on the shapes tag_conv3x3_wino_ok accepts. */
+size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift, const float* dy,
+                           float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
 int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
                              float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
 int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* udgrad, float* da, const float* yref, const float* bn_scale,

@@ -129,6 +129,30 @@ def test_wino_dgrad_and_bn_backward_sums(ops, dev, B, H, W, Cin, Cout, pro):
     print(f"wino dgrad {B}x{H}x{W} {Cout}->{Cin}: err {e:.2e}")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES + [(16, 64, 8, 256, 256, 1)])      # the last: 2048 tiles, 2 K slices
+def test_wino_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
+    """tag_conv3x3_wino_wgrad: dw = d/dw sum(conv(prologue(x), w) * dy) against fp64 autograd -- the bound of the direct
+    weight-gradient kernel's own test (1e-5 of the largest entry)."""
+    g = torch.Generator().manual_seed(B * H + W + Cin + 2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    s, t = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    w64 = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(prologue64(x.double(), pro, s.double(), t.double()), w64, padding=1).backward(dy.double())
+    xh, dyh, sd, td = nhwc(x).to(dev), nhwc(dy).to(dev), s.to(dev), t.to(dev)
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout) // 4, device=dev)
+    ops.call("tag_conv3x3_wino_wgrad", ops.ptr(xh), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(dyh), ops.ptr(dw), B, H, W, Cin, Cout,
+             ops.ptr(ws))
+    e = relerr(dw, w64.grad)
+    dw2 = torch.empty_like(dw)
+    ops.call("tag_conv3x3_wino_wgrad", ops.ptr(xh), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(dyh), ops.ptr(dw2), B, H, W, Cin, Cout,
+             ops.ptr(ws))
+    print(f"wino wgrad {B}x{H}x{W} {Cin}->{Cout} prologue {pro}: err {e:.2e}")
+    assert e < 1e-5, e
+    assert torch.equal(dw, dw2)                   # fixed summation order: bit-reproducible
+
+
 def test_wino_dispatch_rule(ops, dev, monkeypatch):
     """ops.conv3x3_stats / conv3x3_dgrad_bnrelu_backward take the Winograd form exactly for fp32 training launches on 8- / 16-wide
     images with both channel counts >= WINO_MIN_C and at least WINO_MIN_TILES tiles; everything else keeps the direct kernel; the
@@ -151,10 +175,16 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     assert ops.WINO_LAUNCHES == n0 + 2 and torch.equal(y_d, y_e)
     assert relerr(y_w, y_d) < 5e-6
     assert part_w[0] == ops.query("tag_conv3x3_wino_stats_rows", B, H, W, C) and part_d[0] == ops.query("tag_conv3x3_stats_rows", B, H, W, C)
+    dyv = torch.randn(B, H, W, C, generator=g).to(dev)
+    dw_d = ops.conv3x3_wgrad(x, dyv)
+    assert ops.WINO_LAUNCHES == n0 + 2
     monkeypatch.setattr(ops, "WINO_MIN_TILES", 1)
+    dw_w = ops.conv3x3_wgrad(x, dyv)
+    assert ops.WINO_LAUNCHES == n0 + 3 and relerr(dw_w, dw_d) < 1e-5
     monkeypatch.setattr(ops, "CONV_WINOGRAD", False)
     ops.conv3x3_stats(x, wf, C)
-    assert ops.WINO_LAUNCHES == n0 + 2
+    ops.conv3x3_wgrad(x, dyv)
+    assert ops.WINO_LAUNCHES == n0 + 3
     monkeypatch.setattr(ops, "CONV_WINOGRAD", True)
     wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 channels: below WINO_MIN_C, no Winograd weights made
     assert not hasattr(wf64, "wino_u")

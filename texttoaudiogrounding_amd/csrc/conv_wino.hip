@@ -23,7 +23,7 @@
 #include "tag_common.h"
 
 int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,
-                            int N, int K, int batch, hipStream_t st);
+                            int N, int K, int batch, hipStream_t st, int transA);
 
 namespace {
 
@@ -85,12 +85,19 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 template <int PRO>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift, float* __restrict__ V, int B, int H,
-                                                         int W, int C, int th, int tw, long T) {
+                                                         int W, int C, int th, int tw, long T, long Tpad) {
     const int cq = C >> 2;
     const long item = (long)blockIdx.x * 256 + threadIdx.x;
     const long t = item / cq;
     const int q = (int)(item - t * cq);
-    if (t >= T) return;
+    if (t >= Tpad) return;
+    const size_t plane = (size_t)Tpad * C;
+    if (t >= T) {                              // rows that only pad the K slices of the weight-gradient products: zero
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+            *reinterpret_cast<f32x4*>(V + (size_t)xi * plane + (size_t)t * C + 4 * q) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
     const int j = (int)(t % tw);
     const long bi = t / tw;
     const int i = (int)(bi % th), b = (int)(bi / th);
@@ -122,7 +129,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         tt[2][s] = d[2][s] - d[1][s];
         tt[3][s] = d[1][s] - d[3][s];
     }
-    const size_t plane = (size_t)T * C;
     float* vp = V + (size_t)t * C + 4 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -231,6 +237,102 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// Weight gradient in the Winograd domain: dw = G^T [ sum_t (A dY_t A^T) (.) (B^T d_t B) ] G  (the adjoint of the forward form),
+// A = [[1,0],[1,1],[1,-1],[0,-1]].  D[xi][t][c] = (A dY A^T)[r][s] of the 2 x 2 output-gradient tile t (zero outside the image;
+// rows t >= T pad the K slices with zeros).  Same thread layout as wino_input_kernel.
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ D, int B, int H, int W,
+                                                      int C, int th, int tw, long T, long Tpad) {
+    const int cq = C >> 2;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t = item / cq;
+    const int q = (int)(item - t * cq);
+    if (t >= Tpad) return;
+    const size_t plane = (size_t)Tpad * C;
+    float* dp = D + (size_t)t * C + 4 * q;
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (t >= T) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(dp + (size_t)xi * plane) = z;
+        return;
+    }
+    const int j = (int)(t % tw);
+    const long bi = t / tw;
+    const int i = (int)(bi % th), b = (int)(bi / th);
+    f32x4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int h = 2 * i + a, w = 2 * j + e;
+            g[a][e] = (h < H && w < W) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)b * H + h) * W + w) * C + 4 * q) : z;
+        }
+    f32x4 r[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        r[0][e] = g[0][e];
+        r[1][e] = g[0][e] + g[1][e];
+        r[2][e] = g[0][e] - g[1][e];
+        r[3][e] = z - g[1][e];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<f32x4*>(dp + (size_t)(4 * k + 0) * plane) = r[k][0];
+        *reinterpret_cast<f32x4*>(dp + (size_t)(4 * k + 1) * plane) = r[k][0] + r[k][1];
+        *reinterpret_cast<f32x4*>(dp + (size_t)(4 * k + 2) * plane) = r[k][0] - r[k][1];
+        *reinterpret_cast<f32x4*>(dp + (size_t)(4 * k + 3) * plane) = z - r[k][1];
+    }
+}
+
+// dw (Cout,Cin,3,3) = G^T (sum over the S K-slices of Pp[xi][s][co][ci]) G, fixed summation order; one thread per (co, ci)
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ Pp, int S, int Cin, int Cout,
+                                                                float* __restrict__ dw) {
+    const long n = (long)Cin * Cout;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        float u[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            float a = 0.0f;
+            for (int s = 0; s < S; ++s) a += Pp[((size_t)xi * S + s) * n + e];
+            u[xi >> 2][xi & 3] = a;
+        }
+        float q[3][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float hs = 0.5f * (u[1][s] + u[2][s]), hd = 0.5f * (u[1][s] - u[2][s]);
+            q[0][s] = u[0][s] + hs;
+            q[1][s] = hd;
+            q[2][s] = hs + u[3][s];
+        }
+        float* o = dw + e * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float hs = 0.5f * (q[a][1] + q[a][2]), hd = 0.5f * (q[a][1] - q[a][2]);
+            o[3 * a + 0] = q[a][0] + hs;
+            o[3 * a + 1] = hd;
+            o[3 * a + 2] = hs + q[a][3];
+        }
+    }
+}
+
+// K slices of the weight-gradient products: (xi, slice) pairs are the batch entries of ONE launch, so a slice must be a whole
+// number of 16-row K chunks and the planes are padded to S * kc rows
+struct WinoWgGeom { int th, tw; long T, Tpad; int S, kc; };
+inline WinoWgGeom wino_wg_geom(int B, int H, int W, int Cin, int Cout) {
+    WinoWgGeom g;
+    g.th = (H + 1) / 2; g.tw = (W + 1) / 2;
+    g.T = (long)B * g.th * g.tw;
+    const long tiles = (long)((Cin + 127) / 128) * ((Cout + 127) / 128) * 16;
+    long S = (1024 + tiles - 1) / tiles;                       // ~1024 workgroups: one residency round of 4 per CU
+    if (S > g.T / 512) S = g.T / 512;
+    if (S < 1) S = 1;
+    long kc = (g.T + S - 1) / S;
+    kc = (kc + 15) / 16 * 16;
+    g.S = (int)((g.T + kc - 1) / kc);
+    g.kc = (int)kc;
+    g.Tpad = (long)g.S * kc;
+    return g;
+}
+
 struct WinoGeom { int th, tw; long T; int G, P; };
 inline WinoGeom wino_geom(int B, int H, int W, int Cout) {
     WinoGeom g;
@@ -252,12 +354,12 @@ int wino_run(const float* x, const float* U, int pro, const float* s, const floa
     const long items = g.T * (Cin / 4);
     const int gin = (int)((items + 255) / 256);
     switch (pro) {
-        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
-        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
-        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
-        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T); break;
+        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T, g.T); break;
+        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T, g.T); break;
+        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T, g.T); break;
+        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, s, t, V, B, H, W, Cin, g.th, g.tw, g.T, g.T); break;
     }
-    tag_launch_gemm_batched(V, Cin, g.T * Cin, U, Cout, (long)Cin * Cout, Mb, Cout, g.T * Cout, (int)g.T, Cout, Cin, 16, st);
+    tag_launch_gemm_batched(V, Cin, g.T * Cin, U, Cout, (long)Cin * Cout, Mb, Cout, g.T * Cout, (int)g.T, Cout, Cin, 16, st, 0);
     const int gout = g.P / g.G;
     const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (epi)
@@ -292,6 +394,39 @@ extern "C" size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Co
 extern "C" int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout) {
     if (!wino_channels_ok(Cout)) return 0;
     return wino_geom(B, H, W, Cout).P;
+}
+
+extern "C" size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
+    return ((size_t)16 * g.Tpad * ((size_t)Cin + Cout) + (size_t)16 * g.S * Cin * Cout) * sizeof(float);
+}
+
+extern "C" int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift, const float* dy,
+                                      float* dw, int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && dy && dw && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+    TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
+    hipStream_t st = as_stream(stream);
+    const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
+    float* V = static_cast<float*>(ws);
+    float* D = V + (size_t)16 * g.Tpad * Cin;
+    float* Pp = D + (size_t)16 * g.Tpad * Cout;
+    const int gin = (int)((g.Tpad * (Cin / 4) + 255) / 256), gdy = (int)((g.Tpad * (Cout / 4) + 255) / 256);
+    switch (prologue) {
+        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+    }
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(gdy), dim3(256), 0, st, dy, D, B, H, W, Cout, g.th, g.tw, g.T, g.Tpad);
+    // batch entry (xi, s): Pp[xi][s] (Cout x Cin) = D[xi][s kc .. (s+1) kc)^T . V[xi][the same rows]; the planes are contiguous, so
+    // consecutive entries are kc rows apart in both operands
+    tag_launch_gemm_batched(D, Cout, (long)g.kc * Cout, V, Cin, (long)g.kc * Cin, Pp, Cin, (long)Cin * Cout, Cout, Cin, g.kc,
+                            16 * g.S, st, 1);
+    const long n = (long)Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256)), dim3(256), 0, st, Pp, g.S, Cin, Cout,
+                       dw);
+    TAG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int tag_conv3x3_wino_forward(const float* x, const float* u, int prologue, const float* in_scale,

@@ -537,12 +537,22 @@ extern "C" int tag_gemm_bf16(const float* A, int lda, int transA, const float* B
 // `batch` independent products C_b = A_b x B_b of one shape in ONE launch (blockIdx.y = b): A_b (M,K) row-major, B_b (K,N)
 // row-major, C_b (M,N); strides in floats.  128 x 128 tiles when M, N allow it (the launch as a whole makes many residency
 // rounds), no split-K, no epilogue.  Serves the Winograd-domain products of conv_wino.hip.
+// transA: A_b stored (K,M) (m-contiguous) -- the weight-gradient products of conv_wino.hip, whose K runs over the tiles.
 int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,
-                            int N, int K, int batch, hipStream_t st) {
+                            int N, int K, int batch, hipStream_t st, int transA) {
     Epilogue ep{nullptr, 0, 0, 1.0f, 0, 1, 1, 1};
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
     static const int gkt = getenv("TAG_WINO_GK") ? atoi(getenv("TAG_WINO_GK")) : 16;        // A/B: 32 = the dense GEMM's chunk
+    if (transA) {
+        if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)
+            launch_gemm_t<false, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+        else if (M >= 128 && N >= 128)
+            launch_gemm_t<false, false, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+        else
+            launch_gemm_t<false, false, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+        return 0;
+    }
     if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)
         launch_gemm_t<true, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
     else if (M >= 128 && N >= 128)

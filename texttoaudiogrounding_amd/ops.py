@@ -373,7 +373,13 @@ def _wino_shape(W, Cin, Cout) -> bool:
     return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16) and min(Cin, Cout) >= WINO_MIN_C)
 
 
-def _wino_u(wpack, x, Cout):
+def _wino_flop(B, H, W, Cin, Cout) -> float:
+    """FLOP a Winograd launch EXECUTES on the matrix pipe (16 products of T x Cin x Cout; bench.py's roofline counts these, not the
+    2.25 x larger direct-convolution figure)."""
+    return 2.0 * 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin * Cout
+
+
+def _wino_u(wpack, x, Cout, count=True):
     """The Winograd-domain weights riding on a direct pack (pack_conv_weight) when this launch may use them, else None."""
     u = getattr(wpack, "wino_u", None)
     if u is None or not CONV_WINOGRAD or CONV_MATH != "fp32" or x.dtype != F32:
@@ -381,31 +387,33 @@ def _wino_u(wpack, x, Cout):
     B, H, W, Cin = x.shape
     if B * ((H + 1) // 2) * ((W + 1) // 2) < WINO_MIN_TILES or not query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout):
         return None
-    global WINO_LAUNCHES
-    WINO_LAUNCHES += 1
+    if count:
+        global WINO_LAUNCHES
+        WINO_LAUNCHES += 1
     return u
 
 
-def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None):
-    """y = conv(prologue(x))."""
-    return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False)[0]
+def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None, training_launch=False):
+    """y = conv(prologue(x)).  training_launch: a launch of the training step (a dgrad conv): may take the Winograd form."""
+    return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False, training_launch=training_launch)[0]
 
 
-def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats=True):
+def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats=True, training_launch=False):
     """(y, partials): y = conv(prologue(x)) and, when want_stats, the BatchNorm partial statistics of y that the kernel
     writes in its epilogue ((P, buffer), or None when this shape has no fused statistics) -> bn_stats(..., partials=...)."""
     B, H, W, Cin = x.shape
     y = _empty(B, H, W, Cout, like=x, dtype=x.dtype)
     x3 = wpack.dtype == torch.uint8
     part = None
-    u = _wino_u(wpack, x, Cout) if (want_stats and FUSE_BN_STATS and not x3) else None
+    u = _wino_u(wpack, x, Cout) if (((want_stats and FUSE_BN_STATS) or training_launch) and not x3) else None
     if u is not None:
-        P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
-        part = (P, _empty(P * (3 * Cout + 1), like=x))
+        if want_stats and FUSE_BN_STATS:
+            P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
+            part = (P, _empty(P * (3 * Cout + 1), like=x))
         ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout), x)
-        with _timed(("conv3x3_wino", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
-            call("tag_conv3x3_wino_forward", ptr(x), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y), ptr(part[1]), B, H, W, Cin,
-                 Cout, ptr(ws))
+        with _timed(("conv3x3_wino", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
+            call("tag_conv3x3_wino_forward", ptr(x), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y), ptr(part[1]) if part else None,
+                 B, H, W, Cin, Cout, ptr(ws))
         return y, part
     if want_stats and FUSE_BN_STATS:
         if x3 and x.dtype == BF16:
@@ -483,7 +491,7 @@ def conv3x3_dgrad_bnrelu_backward(dy_in, wpack, yref, st: BNStat, gamma, dg_out=
         P = query("tag_conv3x3_wino_stats_rows", B, H, W, C)
         part = _empty(P * 2 * C, like=dy_in)
         ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, C), dy_in)
-        with _timed(("conv3x3_wino", B, H, W, Cin, C), 2.0 * B * H * W * 9 * Cin * C):
+        with _timed(("conv3x3_wino", B, H, W, Cin, C), _wino_flop(B, H, W, Cin, C)):
             call("tag_conv3x3_wino_dgrad_bnsums", ptr(dy_in), ptr(u), ptr(da), ptr(yref), ptr(st.scale), ptr(st.shift),
                  ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C, ptr(ws))
     else:
@@ -590,6 +598,14 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
         with _timed(("conv3x3_wgrad_x3_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
             call("tag_conv3x3_wgrad_x3", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
                  _X3_PRODUCTS[CONV_MATH], ptr(ws))
+        return dw
+    if (x.dtype == F32 and dy.dtype == F32 and _wino_shape(W, Cin, Cout) and B * ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_TILES
+            and query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout)):
+        global WINO_LAUNCHES
+        WINO_LAUNCHES += 1
+        ws = _ws(query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+        with _timed(("conv3x3_wino_wgrad", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
+            call("tag_conv3x3_wino_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout, ptr(ws))
         return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     # profile family: the all-taps decomposition (conv3x3_wgrad_alltaps_kernel at W = 8 / 16, its row-ring form
@@ -1263,7 +1279,11 @@ class Cnn8RnnFunction(TagFunction):
             if i > 0:
                 _deliver(grads, sk, o, sw.wgrad(x_in, dy1, out=sk[o]))
                 below = sv["acts"][i - 1]          # (x, y1, s1, y2, s2, ...) of the block whose pooled output x_in is
-                if pool_sums_fusable(dy1, wd1, below[3], *CNN8_POOLS[i - 1]):
+                if _wino_u(wd1, dy1, x_in.shape[3], count=False) is not None:
+                    # Winograd dgrad (block 4's first conv at the benched size: 2.24 -> 1.67 ms); the pool-backward sums of the
+                    # block below keep their own pass (pool_bwd_reduce, 0.1 ms there)
+                    dx = conv3x3(dy1, wd1, x_in.shape[3], training_launch=True)
+                elif pool_sums_fusable(dy1, wd1, below[3], *CNN8_POOLS[i - 1]):
                     dx, poolpart = conv3x3_dgrad_poolsums(dy1, wd1, below[3], below[4], *CNN8_POOLS[i - 1], drop[0], seeds[i - 1])
                 else:
                     dx = conv3x3(dy1, wd1, x_in.shape[3])

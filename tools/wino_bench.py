@@ -112,4 +112,14 @@ for (H, W, Cin, Cout) in shapes:
     print(f"dgrad {H}x{W} {Cout}->{Cin}: direct {td:.3f} ms  wino {tw:.3f} ms  x{td / tw:.2f} | err/range max direct {ed:.2e} wino {ew:.2e} | "
           f"sums vs fp64 of wino's own da: dbeta {(outs[1][1].double() - db64).abs().max().item() / sc:.1e} dgamma "
           f"{(outs[1][0].double() - dg64).abs().max().item() / sc:.1e}; direct-vs-wino dbeta {(outs[0][1] - outs[1][1]).abs().max().item() / sc:.1e}")
+    # ---- weight gradient
+    dwd = torch.empty(Cout, Cin, 3, 3, device=dev)
+    dww = torch.empty(Cout, Cin, 3, 3, device=dev)
+    wsd = ops._ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+    wsw = ops._ws(query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+    w_d = lambda: call("tag_conv3x3_wgrad", ptr(x), 1, ptr(scale), ptr(shift), ptr(dy), ptr(dwd), B, H, W, Cin, Cout, ptr(wsd))
+    w_w = lambda: call("tag_conv3x3_wino_wgrad", ptr(x), 1, ptr(scale), ptr(shift), ptr(dy), ptr(dww), B, H, W, Cin, Cout, ptr(wsw))
+    td, tw = timeit(w_d), timeit(w_w)
+    print(f"wgrad {H}x{W} {Cin}->{Cout}: direct {td:.3f} ms  wino {tw:.3f} ms  x{td / tw:.2f} | direct-vs-wino "
+          f"{(dwd - dww).abs().max().item() / dwd.abs().max().item():.2e}")
 ops.check_async_errors()

@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
     // PD register sets = PD K chunks requested ahead of the one being multiplied.  Measured at the step's shapes (B = 64,
     // tools/gemm_bench.py): PD = 3 (64-tiles) / 2 (128-tiles) is 0-17 % SLOWER than PD = 1 -- the loop is bound by its
     // per-chunk instruction and barrier overhead (TAG_GEMM_ABL), not by the latency of the loads -- so one chunk ahead stays.
-    constexpr int PD = 1;
+    // The 16-wide chunk of the batched Winograd-domain products (4 workgroups per CU, 106 VGPRs): with a k-contiguous A operand TWO
+    // chunks ahead is 5 % faster (2.99 -> 2.84 ms for the 16 products of the 512 -> 512 layer), with the m-contiguous A of the
+    // weight-gradient products it is 17 % slower (2.77 -> 3.25 ms): one chunk there.
+    constexpr int PD = (GKT == 16 && !BF && AKC) ? 2 : 1;
     typename std::conditional<BF, StageBF<AKC, T>, Stage<AKC, T, GKT>>::type sa[PD];
     typename std::conditional<BF, StageBF<BKC, T>, Stage<BKC, T, GKT>>::type sb[PD];
     f32x16 acc[TT][TT];
@@ -292,6 +295,37 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
         __syncthreads();
 #endif
         }
+    }
+    if constexpr (FAST && GKT == 16 && !BF) {
+        // The batched Winograd-domain products (whole tiles, no bias / activation / split-K): 16-byte stores after a 4 x 4 transpose
+        // inside each lane quad (two DPP exchange rounds, as conv3x3_halo_kernel's epilogue) -- a global_store_dword is one of the
+        // instruction forms that wait for gaps in the co-resident waves' MFMA streams (tools/coissue_probe.hip), and a 128-tile has
+        // 64 of them per lane: the ablation without stores says they cost 10 % of this kernel (2.25 -> 2.03 ms for the 16 products
+        // of the 512 -> 512 layer).
+        const int c4 = lane & 3;
+        const bool odd = c4 & 1, hi = c4 & 2;
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const int nq = n0 + wn0 + j * 32 + (ml & ~3);
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float x0 = acc[i][j][4 * rq], x1 = acc[i][j][4 * rq + 1], x2 = acc[i][j][4 * rq + 2], x3 = acc[i][j][4 * rq + 3];
+                    const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
+                    const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+                    const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+                    if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
+                    const float s02 = hi ? x0 : x2, s13 = hi ? x1 : x3;
+                    const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+                    const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+                    if (hi) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
+                    // x_t = column nq + t of row (register 4 rq + c4) = c4 + 8 rq + 4 kl of the 32-row tile
+                    const int m = m0 + wm0 + i * 32 + c4 + 8 * rq + 4 * kl;
+                    *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + nq) = (f32x4){x0, x1, x2, x3};
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i)

@@ -190,6 +190,12 @@ int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, 
                            float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
 int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
                              float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
+/* inference twin of tag_conv3x3_forward_bnrelu_pool_eval: the output transform pools its own 2 x 2 tile (one 2 x 2 window or two
+ * 1 x 2 windows) after BatchNorm(eval) + ReLU; the raw conv output is never written. */
+int tag_conv3x3_wino_forward_bnrelu_pool_eval(const float* x, const float* ufwd, int prologue, const float* in_scale,
+                                              const float* in_shift, float* out, const float* bn_scale, const float* bn_shift,
+                                              int B, int H, int W, int Cin, int Cout, int ph, int pw, int pool, void* ws,
+                                              void* stream);
 int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* udgrad, float* da, const float* yref, const float* bn_scale,
                                   const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B,
                                   int H, int W, int Cin, int Cout, void* ws, void* stream);

@@ -153,6 +153,41 @@ def test_wino_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert torch.equal(dw, dw2)                   # fixed summation order: bit-reproducible
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES[1:] + [(2, 11, 8, 64, 64, 1)])
+@pytest.mark.parametrize("ph,pool", [(2, 0), (1, 0), (2, 2), (1, 3)])
+def test_wino_forward_bnrelu_pool_eval(ops, dev, B, H, W, Cin, Cout, pro, ph, pool):
+    """tag_conv3x3_wino_forward_bnrelu_pool_eval (inference: the output transform pools its own tile) against the fp64 chain
+    pool(relu(conv(prologue(x)) * scale + shift)), windows 2x2 / 1x2 (floor), pool types avg+max / avg / max."""
+    if H // ph == 0 or W < 2:
+        pytest.skip("no whole pool window")
+    g = torch.Generator().manual_seed(B * H + W + Cin + 7 * ph + pool)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    s, t = torch.rand(Cin, generator=g) + 0.5, 0.3 * torch.randn(Cin, generator=g)
+    bs, bt = torch.rand(Cout, generator=g) + 0.5, 0.3 * torch.randn(Cout, generator=g)
+    yy = F.conv2d(prologue64(x.double(), pro, s.double(), t.double()), w.double(), padding=1)
+    a = torch.relu(yy * bs.double().view(1, -1, 1, 1) + bt.double().view(1, -1, 1, 1))
+    avg, mx = F.avg_pool2d(a, (ph, 2)), F.max_pool2d(a, (ph, 2))
+    ref = avg + mx if pool == 0 else (avg if pool == 2 else mx)
+    xh, wh, sd, td, bsd, btd = nhwc(x).to(dev), w.to(dev), s.to(dev), t.to(dev), bs.to(dev), bt.to(dev)
+    uf, _ = wino_pack(ops, wh)
+    out = torch.full((B, H // ph, W // 2, Cout), float("nan"), device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout) // 4, device=dev)
+    ops.call("tag_conv3x3_wino_forward_bnrelu_pool_eval", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(out),
+             ops.ptr(bsd), ops.ptr(btd), B, H, W, Cin, Cout, ph, 2, pool, ops.ptr(ws))
+    assert torch.isfinite(out).all()
+    e = relerr(nchw(out), ref)
+    assert e < 5e-6, e
+    # = the unfused Winograd forward followed by the pool pass of bn_pool.hip, bit for bit (same expression, same order)
+    y = torch.empty(B, H, W, Cout, device=dev)
+    ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y), None, B, H, W, Cin,
+             Cout, ops.ptr(ws))
+    st = ops.BNStat()
+    st.scale, st.shift, st.train = bsd, btd, False
+    two = ops.bnact_pool(y, st, ph, 2, act=1, pool=pool)
+    assert torch.equal(out, two)
+
+
 def test_wino_dispatch_rule(ops, dev, monkeypatch):
     """ops.conv3x3_stats / conv3x3_dgrad_bnrelu_backward take the Winograd form exactly for fp32 training launches on 8- / 16-wide
     images with both channel counts >= WINO_MIN_C and at least WINO_MIN_TILES tiles; everything else keeps the direct kernel; the

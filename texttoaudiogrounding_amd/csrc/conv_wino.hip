@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 struct WinoEpi {
     const float* yref;      // EPI == 1: (B,H,W,C) raw conv output saved by the forward pass (= BatchNorm input)
     const float* scale; const float* shift; const float* mean; const float* invstd;
+    int ph; float wavg, wmax;   // EPI == 3: pool window ph x 2 and the weights of its average / maximum (conv.hip's EPI == 3)
 };
 
 // y (2 x 2 pixels of tile t) = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]],  m[r][s] = M[4 r + s][t][c].  A workgroup holds
@@ -150,6 +151,9 @@ struct WinoEpi {
 //   EPI == 0: [K | r | q][C] + count -- pivot K = the thread's first output, r = sum(y - K), q = sum((y - K)^2) over the
 //             slot's pixels (tag_bn_stats_from_partials; the layout of the direct kernel's EPI == 0 and of conv_c1_fwd_rows);
 //   EPI == 1: [sum g | sum g xhat][C], g = y where bn(yref) > 0 (tag_bn_grad_from_partials; the direct kernel's EPI == 1).
+//   EPI == 3 (inference, BatchNorm in eval mode): no rows; the tile's 2 x 2 outputs ARE the pool windows (one 2 x 2 window, or two
+//             1 x 2 windows), so out (B, H/ph, W/2, C) = avg/max pool(relu(y * scale + shift)) leaves directly -- the raw conv output
+//             is never written (the expression and summation order of bnact_pool_fwd_kernel / the direct kernel's EPI == 3).
 constexpr int WINO_ITERS = 8;
 template <int EPI>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, float* __restrict__ y,
@@ -162,8 +166,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     float cnt = 0.0f;
     bool have_pivot = false;
     f32x4 bsc = {0, 0, 0, 0}, bsh = {0, 0, 0, 0}, bmu = {0, 0, 0, 0}, bis = {0, 0, 0, 0};
-    if (EPI == 1) {
+    if (EPI == 1 || EPI == 3) {
         bsc = *reinterpret_cast<const f32x4*>(epi.scale + 4 * q); bsh = *reinterpret_cast<const f32x4*>(epi.shift + 4 * q);
+    }
+    if (EPI == 1) {
         bmu = *reinterpret_cast<const f32x4*>(epi.mean + 4 * q); bis = *reinterpret_cast<const f32x4*>(epi.invstd + 4 * q);
     }
     for (int it = 0; it < WINO_ITERS; ++it) {
@@ -183,6 +189,45 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         for (int s = 0; s < 4; ++s) {
             u[0][s] = m[0][s] + m[1][s] + m[2][s];
             u[1][s] = m[1][s] - m[2][s] - m[3][s];
+        }
+        if (EPI == 3) {
+            const int Hp = H / epi.ph, Wp = W >> 1;
+            f32x4 a[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x4 o0 = u[r][0] + u[r][1] + u[r][2], o1 = u[r][1] - u[r][2] - u[r][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[r][0][k] = fmaxf(fmaf(o0[k], bsc[k], bsh[k]), 0.0f);
+                    a[r][1][k] = fmaxf(fmaf(o1[k], bsc[k], bsh[k]), 0.0f);
+                }
+            }
+            if (j < Wp) {
+                if (epi.ph == 2) {
+                    if (i < Hp) {
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sum = ((a[0][0][k] + a[0][1][k]) + a[1][0][k]) + a[1][1][k];
+                            const float mx = fmaxf(fmaxf(fmaxf(a[0][0][k], a[0][1][k]), a[1][0][k]), a[1][1][k]);
+                            o[k] = sum * epi.wavg + mx * epi.wmax;
+                        }
+                        *reinterpret_cast<f32x4*>(y + (((size_t)b * Hp + i) * Wp + j) * C + 4 * q) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int hp = 2 * i + r;
+                        if (hp >= Hp) continue;
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            o[k] = (a[r][0][k] + a[r][1][k]) * epi.wavg + fmaxf(a[r][0][k], a[r][1][k]) * epi.wmax;
+                        *reinterpret_cast<f32x4*>(y + (((size_t)b * Hp + hp) * Wp + j) * C + 4 * q) = o;
+                    }
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -221,6 +266,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             }
         }
     }
+    if (EPI == 3) return;
     const int prow = blockIdx.x * G + slot;
     if (slot >= G || prow >= P) return;
     if (EPI == 0 && stats) {
@@ -361,8 +407,10 @@ int wino_run(const float* x, const float* U, int pro, const float* s, const floa
     }
     tag_launch_gemm_batched(V, Cin, g.T * Cin, U, Cout, (long)Cin * Cout, Mb, Cout, g.T * Cout, (int)g.T, Cout, Cin, 16, st, 0);
     const int gout = g.P / g.G;
-    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (epi)
+    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f};
+    if (epi && epi->ph > 0)
+        hipLaunchKernelGGL(wino_output_kernel<3>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
+    else if (epi)
         hipLaunchKernelGGL(wino_output_kernel<1>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
     else
         hipLaunchKernelGGL(wino_output_kernel<0>, dim3(gout), dim3(256), 0, st, Mb, y, stats, none, B, H, W, Cout, g.th, g.tw, g.T, g.P);
@@ -439,12 +487,28 @@ extern "C" int tag_conv3x3_wino_forward(const float* x, const float* u, int prol
     return 0;
 }
 
+// Inference forward of a conv + the rest of its ConvBlock stage with BatchNorm in eval mode (models/panns.py:49-60): the Winograd
+// twin of tag_conv3x3_forward_bnrelu_pool_eval -- out (B, H/ph, W/2, Cout) = pool(relu(conv(prologue(x)) * bn_scale + bn_shift)).
+extern "C" int tag_conv3x3_wino_forward_bnrelu_pool_eval(const float* x, const float* u, int prologue, const float* in_scale,
+                                                         const float* in_shift, float* out, const float* bn_scale,
+                                                         const float* bn_shift, int B, int H, int W, int Cin, int Cout, int ph, int pw,
+                                                         int pool, void* ws, void* stream) {
+    TAG_CHECK_ARG(x && u && out && bn_scale && bn_shift && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+    TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
+    TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H / ph > 0 && W >= 2 && (pool == 0 || pool == 2 || pool == 3));
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    const WinoEpi epi{nullptr, bn_scale, bn_shift, nullptr, nullptr, ph, wavg, wmax};
+    wino_run(x, u, prologue, in_scale, in_shift, out, nullptr, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* u, float* da, const float* yref, const float* bn_scale,
                                              const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart,
                                              int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
     TAG_CHECK_ARG(dy && u && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && ws);
     TAG_CHECK_ARG(tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
-    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd};
+    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0.0f, 0.0f};
     wino_run(dy, u, 0, nullptr, nullptr, da, bnpart, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();
     return 0;

@@ -365,6 +365,11 @@ WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "256"))
 #: ... and only on launches with at least this many 2 x 2 output tiles (B * ceil(H/2) * ceil(W/2); 8192 = batch 17 of 10 s clips in
 #: block 4): below that the 16 products are too short to fill the chip and the direct kernel keeps the launch
 WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
+#: the inference forward (BatchNorm in eval mode, nothing saved) of the same layers as Winograd too, at EVERY launch size: the choice
+#: must not depend on the batch, or the same clip would score differently in a 4-clip and in a 64-clip pass (the forward is
+#: batch-invariant, tests/test_gpu_infer.py); batches are cut so that the transform planes stay under WINO_WS_MAX bytes
+CONV_WINOGRAD_EVAL = os.environ.get("TAG_CONV_WINOGRAD_EVAL", "1") != "0"
+WINO_WS_MAX = int(os.environ.get("TAG_WINO_WS_MAX", str(3 << 30)))
 #: launches that took the Winograd path since import (tests assert that the benched-size step really runs through it)
 WINO_LAUNCHES = 0
 
@@ -379,13 +384,17 @@ def _wino_flop(B, H, W, Cin, Cout) -> float:
     return 2.0 * 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin * Cout
 
 
-def _wino_u(wpack, x, Cout, count=True):
-    """The Winograd-domain weights riding on a direct pack (pack_conv_weight) when this launch may use them, else None."""
+def _wino_u(wpack, x, Cout, count=True, any_size=False):
+    """The Winograd-domain weights riding on a direct pack (pack_conv_weight) when this launch may use them, else None.
+    any_size: the inference forward -- no tile threshold (see CONV_WINOGRAD_EVAL)."""
     u = getattr(wpack, "wino_u", None)
     if u is None or not CONV_WINOGRAD or CONV_MATH != "fp32" or x.dtype != F32:
         return None
     B, H, W, Cin = x.shape
-    if B * ((H + 1) // 2) * ((W + 1) // 2) < WINO_MIN_TILES or not query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout):
+    if any_size and not CONV_WINOGRAD_EVAL:
+        return None
+    if ((not any_size and B * ((H + 1) // 2) * ((W + 1) // 2) < WINO_MIN_TILES)
+            or not query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout)):
         return None
     if count:
         global WINO_LAUNCHES
@@ -398,14 +407,32 @@ def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None, training_launch=
     return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False, training_launch=training_launch)[0]
 
 
-def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats=True, training_launch=False):
+def _batch_chunks(B, bytes_per_clip):
+    """Batch slices [b0, b1) whose Winograd transform planes stay under WINO_WS_MAX (any cut gives the same rows: every tile is
+    transformed and multiplied independently of the others)."""
+    nb = max(1, min(B, WINO_WS_MAX // max(1, bytes_per_clip)))
+    return [(b0, min(B, b0 + nb)) for b0 in range(0, B, nb)]
+
+
+def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats=True, training_launch=False, inference=False):
     """(y, partials): y = conv(prologue(x)) and, when want_stats, the BatchNorm partial statistics of y that the kernel
     writes in its epilogue ((P, buffer), or None when this shape has no fused statistics) -> bn_stats(..., partials=...)."""
     B, H, W, Cin = x.shape
     y = _empty(B, H, W, Cout, like=x, dtype=x.dtype)
     x3 = wpack.dtype == torch.uint8
     part = None
-    u = _wino_u(wpack, x, Cout) if (((want_stats and FUSE_BN_STATS) or training_launch) and not x3) else None
+    u = None
+    if not x3 and inference and not want_stats:
+        u = _wino_u(wpack, x, Cout, any_size=True)
+        if u is not None:                      # inference forward: batch cuts bound the workspace (30 s x 256 clips: 25 GB uncut)
+            for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout)):
+                ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
+                with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
+                    call("tag_conv3x3_wino_forward", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y[b0:b1]), None,
+                         b1 - b0, H, W, Cin, Cout, ptr(ws))
+            return y, None
+    elif ((want_stats and FUSE_BN_STATS) or training_launch) and not x3:
+        u = _wino_u(wpack, x, Cout)
     if u is not None:
         if want_stats and FUSE_BN_STATS:
             P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
@@ -575,6 +602,14 @@ def conv3x3_bnrelu_pool_eval(x, wpack, Cout, st: BNStat, ph, pw, prologue=0, sca
     """pool(relu(bn_eval(conv(prologue(x))))) in ONE kernel: nothing of the (B,H,W,Cout) conv output touches HBM."""
     B, H, W, Cin = x.shape
     out = _empty(B, H // ph, W // pw, Cout, like=x)
+    u = _wino_u(wpack, x, Cout, any_size=True)
+    if u is not None:
+        for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout)):
+            ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
+            with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
+                call("tag_conv3x3_wino_forward_bnrelu_pool_eval", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift),
+                     ptr(out[b0:b1]), ptr(st.scale), ptr(st.shift), b1 - b0, H, W, Cin, Cout, ph, pw, int(pool), ptr(ws))
+        return out
     with _timed(("conv3x3_halo_kernel", B, H, W, Cin, Cout), 2.0 * B * H * W * 9 * Cin * Cout):
         call("tag_conv3x3_forward_bnrelu_pool_eval", ptr(x), ptr(wpack), prologue, ptr(scale), ptr(shift), ptr(out), ptr(st.scale),
              ptr(st.shift), B, H, W, Cin, Cout, ph, pw, int(pool))
@@ -1178,7 +1213,8 @@ class Cnn8RnnFunction(TagFunction):
                 wf1 = wd1 = None
             else:
                 wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
-                y1, part1 = conv3x3_stats(x, wf1, c1w.shape[0], want_stats=bn_train)
+                y1, part1 = conv3x3_stats(x, wf1, c1w.shape[0], want_stats=bn_train,
+                                          inference=not need_grad and not bn_train and drop[0] == 0.0)
             Bx, H, W, C = y1.shape
             s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
                           blk.bn1.momentum, partials=part1)

@@ -289,6 +289,8 @@ def other_workloads(args, device, log, budget_s=5.0):
                              "estimator": "one_block_after_one_warm_up_pass", "host_enqueue_ms_per_step": round(host / k * 1e3, 3),
                              # forward of a 30 s clip = 3 x 33.90 GFLOP (T' = 750) -- numerically FLOP_PER_CLIP
                              "whole_forward_mfma_frac": round(B * k / dt * 3 * 33.90e9 / 1e12 / PEAK_FP32_MFMA, 4),
+                             "whole_forward_mfma_frac_counts": "algorithmic direct-convolution FLOP (effective rate: blocks 3-4 run as "
+                                                               "Winograd F(2x2,3x3) and execute 2.25 x fewer)",
                              "text_tower_ms_per_batch": round(dtt / k * 1e3, 2)}
     log(f"other workload infer_30s_b256: {res['infer_30s_b256']['value']} clips/s")
     return res

@@ -186,10 +186,17 @@ int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout);
  * adjoint of the forward form; 16 x S products (Cout x kc).(kc x Cin) over K slices of the tile axis in one batched launch,
  * folded in a fixed order.  Drop-in for tag_conv3x3_wgrad on the shapes tag_conv3x3_wino_ok accepts. */
 size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+/* v_saved (optional): the transformed input the forward launch of the same convolution left in its
+ * v_keep buffer -- the input transform is then not repeated (x may be NULL); allowed when tag_conv3x3_wino_wgrad_can_reuse_v. */
+int tag_conv3x3_wino_wgrad_can_reuse_v(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift, const float* dy,
-                           float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
+                           float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout, void* ws, const float* v_saved,
+                           void* stream);
+/* v_keep (optional): 16 * T * Cin floats that receive the transformed input instead of ws (which then
+ * needs the product planes only: 16 * T * Cout floats) -- kept by the caller for tag_conv3x3_wino_wgrad(v_saved). */
 int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
-                             float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, void* stream);
+                             float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, float* v_keep,
+                             void* stream);
 /* inference twin of tag_conv3x3_forward_bnrelu_pool_eval: the output transform pools its own 2 x 2 tile (one 2 x 2 window or two
  * 1 x 2 windows) after BatchNorm(eval) + ReLU; the raw conv output is never written. */
 int tag_conv3x3_wino_forward_bnrelu_pool_eval(const float* x, const float* ufwd, int prologue, const float* in_scale,

@@ -73,7 +73,7 @@ def test_wino_forward_and_statistics(ops, dev, B, H, W, Cin, Cout, pro):
     part = torch.full((P * (3 * Cout + 1),), float("nan"), device=dev)
     ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout) // 4, device=dev)
     ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y),
-             ops.ptr(part), B, H, W, Cin, Cout, ops.ptr(ws))
+             ops.ptr(part), B, H, W, Cin, Cout, ops.ptr(ws), None)
     e = relerr(nchw(y), ref)
     assert e < 5e-6, e
     # statistics: every pixel counted exactly once, mean / invstd of the kernel's OWN output
@@ -87,7 +87,7 @@ def test_wino_forward_and_statistics(ops, dev, B, H, W, Cin, Cout, pro):
     # without a statistics buffer the same output, bit for bit
     y2 = torch.empty_like(y)
     ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y2), None,
-             B, H, W, Cin, Cout, ops.ptr(ws))
+             B, H, W, Cin, Cout, ops.ptr(ws), None)
     assert torch.equal(y, y2)
     print(f"wino forward {B}x{H}x{W} {Cin}->{Cout} prologue {pro}: err {e:.2e}, P {P}")
 
@@ -143,11 +143,11 @@ def test_wino_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev)
     ws = torch.empty(ops.query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout) // 4, device=dev)
     ops.call("tag_conv3x3_wino_wgrad", ops.ptr(xh), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(dyh), ops.ptr(dw), B, H, W, Cin, Cout,
-             ops.ptr(ws))
+             ops.ptr(ws), None)
     e = relerr(dw, w64.grad)
     dw2 = torch.empty_like(dw)
     ops.call("tag_conv3x3_wino_wgrad", ops.ptr(xh), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(dyh), ops.ptr(dw2), B, H, W, Cin, Cout,
-             ops.ptr(ws))
+             ops.ptr(ws), None)
     print(f"wino wgrad {B}x{H}x{W} {Cin}->{Cout} prologue {pro}: err {e:.2e}")
     assert e < 1e-5, e
     assert torch.equal(dw, dw2)                   # fixed summation order: bit-reproducible
@@ -181,11 +181,39 @@ def test_wino_forward_bnrelu_pool_eval(ops, dev, B, H, W, Cin, Cout, pro, ph, po
     # = the unfused Winograd forward followed by the pool pass of bn_pool.hip, bit for bit (same expression, same order)
     y = torch.empty(B, H, W, Cout, device=dev)
     ops.call("tag_conv3x3_wino_forward", ops.ptr(xh), ops.ptr(uf), pro, ops.ptr(sd), ops.ptr(td), ops.ptr(y), None, B, H, W, Cin,
-             Cout, ops.ptr(ws))
+             Cout, ops.ptr(ws), None)
     st = ops.BNStat()
     st.scale, st.shift, st.train = bsd, btd, False
     two = ops.bnact_pool(y, st, ph, 2, act=1, pool=pool)
     assert torch.equal(out, two)
+
+
+def test_wino_wgrad_reuses_the_forward_planes(ops, dev, monkeypatch):
+    """A training forward launch leaves its transformed input on the input tensor (ops.WINO_KEEP_V); the weight gradient of the same
+    convolution multiplies those planes instead of transforming x again: bit-identical dw, the planes released after one use, and
+    a different prologue / different BatchNorm tensors do NOT take them."""
+    B, H, W, C = 8, 64, 8, 256                    # 1024 tiles, 2 K slices of 512: no padding rows
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, C, generator=g).to(dev)
+    dy = torch.randn(B, H, W, C, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
+    s, t = (torch.rand(C, generator=g) + 0.5).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1024)
+    assert ops.query("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, C, C) == 1
+    wf, _ = ops.pack_conv_weight(w, W=W)
+    monkeypatch.setattr(ops, "WINO_KEEP_V", False)
+    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
+    assert not hasattr(x, "_wino_v")
+    dw_plain = ops.conv3x3_wgrad(x, dy, prologue=1, scale=s, shift=t)
+    monkeypatch.setattr(ops, "WINO_KEEP_V", True)
+    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
+    assert hasattr(x, "_wino_v")
+    dw_other = ops.conv3x3_wgrad(x, dy, prologue=0)              # another prologue: the planes do not apply (and are dropped)
+    assert not hasattr(x, "_wino_v")
+    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
+    dw_kept = ops.conv3x3_wgrad(x, dy, prologue=1, scale=s, shift=t)
+    assert not hasattr(x, "_wino_v")
+    assert torch.equal(dw_kept, dw_plain) and not torch.equal(dw_other, dw_plain)
 
 
 def test_wino_dispatch_rule(ops, dev, monkeypatch):

@@ -393,10 +393,12 @@ inline WinoGeom wino_geom(int B, int H, int W, int Cout) {
 inline bool wino_channels_ok(int C) { return C >= 32 && C <= 1024 && C % 4 == 0 && 256 % (C / 4) == 0; }
 
 int wino_run(const float* x, const float* U, int pro, const float* s, const float* t, float* y, float* stats, const WinoEpi* epi,
-             int B, int H, int W, int Cin, int Cout, float* ws, hipStream_t st) {
+             int B, int H, int W, int Cin, int Cout, float* ws, hipStream_t st, float* v_keep = nullptr) {
     const WinoGeom g = wino_geom(B, H, W, Cout);
-    float* V = ws;
-    float* Mb = ws + (size_t)16 * g.T * Cin;
+    // v_keep: the transformed input goes to a buffer of the caller's (16 T Cin floats) that outlives the call -- the weight
+    // gradient of the same convolution multiplies the same planes (tag_conv3x3_wino_wgrad, v_saved); ws then holds the products only
+    float* V = v_keep ? v_keep : ws;
+    float* Mb = v_keep ? ws : ws + (size_t)16 * g.T * Cin;
     const long items = g.T * (Cin / 4);
     const int gin = (int)((items + 255) / 256);
     switch (pro) {
@@ -449,21 +451,31 @@ extern "C" size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, 
     return ((size_t)16 * g.Tpad * ((size_t)Cin + Cout) + (size_t)16 * g.S * Cin * Cout) * sizeof(float);
 }
 
+extern "C" int tag_conv3x3_wino_wgrad_can_reuse_v(int B, int H, int W, int Cin, int Cout) {
+    const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
+    return g.Tpad == g.T;                      // the K slices need no zero rows: the forward's planes are the operand as they are
+}
+
 extern "C" int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift, const float* dy,
-                                      float* dw, int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
-    TAG_CHECK_ARG(x && dy && dw && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+                                      float* dw, int B, int H, int W, int Cin, int Cout, void* ws, const float* v_saved,
+                                      void* stream) {
+    TAG_CHECK_ARG((x || v_saved) && dy && dw && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
+    TAG_CHECK_ARG(v_saved == nullptr || tag_conv3x3_wino_wgrad_can_reuse_v(B, H, W, Cin, Cout));
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
     hipStream_t st = as_stream(stream);
     const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
-    float* V = static_cast<float*>(ws);
-    float* D = V + (size_t)16 * g.Tpad * Cin;
+    // v_saved: B^T prologue(x) B as the forward launch of this convolution left it (tag_conv3x3_wino_forward, v_keep): the input
+    // transform (0.12-0.27 ms per layer at B = 64) is not repeated; ws then starts with the gradient planes
+    float* D = v_saved ? static_cast<float*>(ws) : static_cast<float*>(ws) + (size_t)16 * g.Tpad * Cin;
+    const float* V = v_saved ? v_saved : static_cast<const float*>(ws);
+    float* Vw = static_cast<float*>(ws);
     float* Pp = D + (size_t)16 * g.Tpad * Cout;
     const int gin = (int)((g.Tpad * (Cin / 4) + 255) / 256), gdy = (int)((g.Tpad * (Cout / 4) + 255) / 256);
-    switch (prologue) {
-        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
-        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
-        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
-        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, V, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+    if (!v_saved) switch (prologue) {
+        case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, Vw, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, Vw, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, Vw, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
+        default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gin), dim3(256), 0, st, x, in_scale, in_shift, Vw, B, H, W, Cin, g.th, g.tw, g.T, g.Tpad); break;
     }
     hipLaunchKernelGGL(wino_dy_kernel, dim3(gdy), dim3(256), 0, st, dy, D, B, H, W, Cout, g.th, g.tw, g.T, g.Tpad);
     // batch entry (xi, s): Pp[xi][s] (Cout x Cin) = D[xi][s kc .. (s+1) kc)^T . V[xi][the same rows]; the planes are contiguous, so
@@ -479,10 +491,11 @@ extern "C" int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float*
 
 extern "C" int tag_conv3x3_wino_forward(const float* x, const float* u, int prologue, const float* in_scale,
                                         const float* in_shift, float* y, float* stats, int B, int H, int W, int Cin, int Cout,
-                                        void* ws, void* stream) {
+                                        void* ws, float* v_keep, void* stream) {
     TAG_CHECK_ARG(x && u && y && ws && tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
-    wino_run(x, u, prologue, in_scale, in_shift, y, stats, nullptr, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
+    wino_run(x, u, prologue, in_scale, in_shift, y, stats, nullptr, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream),
+             v_keep);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -52,8 +52,9 @@ _SIGS = {
     "tag_conv3x3_wino_ws_bytes": (c_size_t, [c_int] * 5),
     "tag_conv3x3_wino_stats_rows": (c_int, [c_int] * 4),
     "tag_conv3x3_wino_wgrad_ws_bytes": (c_size_t, [c_int] * 5),
-    "tag_conv3x3_wino_wgrad": (c_int, [P, c_int, P, P, P, P] + [c_int] * 5 + [P, P]),
-    "tag_conv3x3_wino_forward": (c_int, [P, P, c_int, P, P, P, P] + [c_int] * 5 + [P, P]),
+    "tag_conv3x3_wino_wgrad_can_reuse_v": (c_int, [c_int] * 5),
+    "tag_conv3x3_wino_wgrad": (c_int, [P, c_int, P, P, P, P] + [c_int] * 5 + [P, P, P]),
+    "tag_conv3x3_wino_forward": (c_int, [P, P, c_int, P, P, P, P] + [c_int] * 5 + [P, P, P]),
     "tag_conv3x3_wino_forward_bnrelu_pool_eval": (c_int, [P, P, c_int, P, P, P, P, P] + [c_int] * 8 + [P, P]),
     "tag_conv3x3_wino_dgrad_bnsums": (c_int, [P] * 9 + [c_int] * 5 + [P, P]),
     "tag_conv3x3_forward_bnrelu_pool_eval": (c_int, [P, P, c_int, P, P, P, P, P] + [c_int] * 8 + [P]),

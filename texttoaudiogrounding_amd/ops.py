@@ -370,6 +370,9 @@ WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
 #: batch-invariant, tests/test_gpu_infer.py); batches are cut so that the transform planes stay under WINO_WS_MAX bytes
 CONV_WINOGRAD_EVAL = os.environ.get("TAG_CONV_WINOGRAD_EVAL", "1") != "0"
 WINO_WS_MAX = int(os.environ.get("TAG_WINO_WS_MAX", str(3 << 30)))
+#: a training forward launch keeps its transformed input (16 T Cin floats) on the input tensor for the weight gradient of the same
+#: convolution: three input transforms per step less (0.67 ms at B = 64) for 2.6 GB more live memory
+WINO_KEEP_V = os.environ.get("TAG_WINO_KEEP_V", "1") != "0"
 #: launches that took the Winograd path since import (tests assert that the benched-size step really runs through it)
 WINO_LAUNCHES = 0
 
@@ -429,7 +432,7 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
                 ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
                 with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
                     call("tag_conv3x3_wino_forward", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y[b0:b1]), None,
-                         b1 - b0, H, W, Cin, Cout, ptr(ws))
+                         b1 - b0, H, W, Cin, Cout, ptr(ws), None)
             return y, None
     elif ((want_stats and FUSE_BN_STATS) or training_launch) and not x3:
         u = _wino_u(wpack, x, Cout)
@@ -437,10 +440,16 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
         if want_stats and FUSE_BN_STATS:
             P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
             part = (P, _empty(P * (3 * Cout + 1), like=x))
-        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout), x)
+        # a training forward keeps its transformed input for the weight gradient of the same convolution (conv3x3_wgrad finds it
+        # on the input tensor: same x, same prologue) -- 0.5-1 GB per layer at B = 64 instead of a second input transform
+        vkeep = None
+        if want_stats and WINO_KEEP_V and query("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, Cin, Cout):
+            vkeep = _empty(16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin, like=x)
+            x._wino_v = (vkeep, prologue, scale, shift)
+        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, 0 if vkeep is not None else Cin, Cout), x)
         with _timed(("conv3x3_wino", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
             call("tag_conv3x3_wino_forward", ptr(x), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y), ptr(part[1]) if part else None,
-                 B, H, W, Cin, Cout, ptr(ws))
+                 B, H, W, Cin, Cout, ptr(ws), ptr(vkeep))
         return y, part
     if want_stats and FUSE_BN_STATS:
         if x3 and x.dtype == BF16:
@@ -639,8 +648,14 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
         global WINO_LAUNCHES
         WINO_LAUNCHES += 1
         ws = _ws(query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
+        kept = getattr(x, "_wino_v", None)        # (planes, prologue, scale, shift) left by this convolution's forward launch
+        v = kept[0] if (kept is not None and kept[1] == prologue and kept[2] is scale and kept[3] is shift
+                        and kept[0].numel() == 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin) else None
         with _timed(("conv3x3_wino_wgrad", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
-            call("tag_conv3x3_wino_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout, ptr(ws))
+            call("tag_conv3x3_wino_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout, ptr(ws),
+                 ptr(v))
+        if kept is not None:
+            del x._wino_v                         # one use: the planes are released with this launch
         return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     # profile family: the all-taps decomposition (conv3x3_wgrad_alltaps_kernel at W = 8 / 16, its row-ring form

@@ -62,7 +62,7 @@ for (H, W, Cin, Cout) in shapes:
     sw = torch.zeros(Pw * (3 * Cout + 1), device=dev)
     f_d = lambda: call("tag_conv3x3_forward", ptr(x), ptr(pf), 1, ptr(scale), ptr(shift), ptr(yd), ptr(sd), B, H, W, Cin, Cout)
     f_w = lambda: call("tag_conv3x3_wino_forward", ptr(x), ptr(uf), 1, ptr(scale), ptr(shift), ptr(yw), ptr(sw), B, H, W, Cin, Cout,
-                       ptr(ws))
+                       ptr(ws), None)
     td, tw = timeit(f_d), timeit(f_w)
     r = ref64(x, w, scale, shift)
     rng = r.abs().max().item()
@@ -118,7 +118,7 @@ for (H, W, Cin, Cout) in shapes:
     wsd = ops._ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     wsw = ops._ws(query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     w_d = lambda: call("tag_conv3x3_wgrad", ptr(x), 1, ptr(scale), ptr(shift), ptr(dy), ptr(dwd), B, H, W, Cin, Cout, ptr(wsd))
-    w_w = lambda: call("tag_conv3x3_wino_wgrad", ptr(x), 1, ptr(scale), ptr(shift), ptr(dy), ptr(dww), B, H, W, Cin, Cout, ptr(wsw))
+    w_w = lambda: call("tag_conv3x3_wino_wgrad", ptr(x), 1, ptr(scale), ptr(shift), ptr(dy), ptr(dww), B, H, W, Cin, Cout, ptr(wsw), None)
     td, tw = timeit(w_d), timeit(w_w)
     print(f"wgrad {H}x{W} {Cin}->{Cout}: direct {td:.3f} ms  wino {tw:.3f} ms  x{td / tw:.2f} | direct-vs-wino "
           f"{(dwd - dww).abs().max().item() / dwd.abs().max().item():.2e}")

@@ -650,12 +650,14 @@ def test_conv_dgrad_fused_pool_backward_sums_bf16(ops, dev, B, Hf, Wf, Cin, C, p
     (2, 250, 8, 512, 512, 1, 1, 0), (1, 3001, 64, 64, 64, 2, 1, 0), (2, 18, 8, 64, 128, 2, 0, 2), (2, 17, 32, 64, 64, 1, 1, 3),
     # half-empty n-tile (32 channels), fewer rows than a tile, one row
     (1, 9, 16, 64, 32, 2, 1, 0), (3, 2, 32, 64, 256, 1, 0, 0), (2, 1, 8, 32, 32, 1, 1, 0)])
-def test_conv_fused_bnrelu_pool_eval(ops, dev, B, H, W, Cin, C, ph, pro, pool):
+def test_conv_fused_bnrelu_pool_eval(ops, dev, monkeypatch, B, H, W, Cin, C, ph, pro, pool):
     """Inference forward of a ConvBlock stage in ONE kernel (tag_conv3x3_forward_bnrelu_pool_eval, EPI == 3: the conv pools its own
     output tile, the raw conv output never touches HBM) against the two kernels it replaces: BIT-identical, and against the fp64
     chain conv -> BatchNorm(eval) -> ReLU -> avg / max pool (models/panns.py:49-60).  Odd heights (floor-dropped last row), 64-wide
     images (two tile columns), 1x2 and 2x2 windows, with and without the producer's BatchNorm+ReLU prologue, the three pool types,
-    and the 30 s clip length of BASELINE configs[4]."""
+    and the 30 s clip length of BASELINE configs[4].  (The DIRECT kernel: the Winograd twin the inference forward uses for the
+    deep layers has its own test, tests/test_gpu_wino.py::test_wino_forward_bnrelu_pool_eval.)"""
+    monkeypatch.setattr(ops, "CONV_WINOGRAD_EVAL", False)
     pw = 2
     g = torch.Generator().manual_seed(H * W + C + pool)
     x = torch.randn(B, Cin, H, W, generator=g)

@@ -160,7 +160,8 @@ template <bool AKC, bool BKC, int T, bool BF = false, bool FAST = false, int GKT
 __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                    Epilogue ep, bool a_al, bool b_al, int splits, int kchunk,
-                                                   float* __restrict__ partial, long sA = 0, long sB = 0, long sC = 0) {
+                                                   float* __restrict__ partial, long sA = 0, long sB = 0, long sC = 0,
+                                                   int batch1d = 0) {
     // batched launches (tag_gemm_batched: the 16 Winograd-domain products of conv_wino.hip): blockIdx.y = batch entry
     if (gridDim.y > 1) { A += (size_t)blockIdx.y * sA; B += (size_t)blockIdx.y * sB; C += (size_t)blockIdx.y * sC; }
     constexpr int LDSA = Stage<AKC, T, GKT>::LD, LDSB = Stage<BKC, T, GKT>::LD;
@@ -172,7 +173,20 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
     float* As = smem;                      // [2][ASZ]
     float* Bs = smem + 2 * ASZ;            // [2][BSZ]
     const int n_tiles = (N + T - 1) / T, m_tiles = (M + T - 1) / T;
-    int L = xcd_remap(blockIdx.x, n_tiles * m_tiles * splits);
+    int L;
+    if (batch1d > 0) {
+        // ONE-dimensional batched launch (the weight-gradient products: few tiles per entry, many entries): the XCD remap runs over
+        // (entry, tile), so ALL tiles of an entry -- which read the same two K-slice slabs -- sit on one XCD and share its L2.  As a
+        // 2-D launch of 16-tile rows every XCD ran 2 tiles of every entry and fetched both slabs again: 5.2 GB per launch from HBM
+        // for 2.1 GB of operands (PMC).
+        const int per = n_tiles * m_tiles;
+        const int Lb = xcd_remap(blockIdx.x, per * batch1d);
+        const int e = Lb / per;
+        L = Lb - e * per;
+        A += (size_t)e * sA; B += (size_t)e * sB; C += (size_t)e * sC;
+    } else {
+        L = xcd_remap(blockIdx.x, n_tiles * m_tiles * splits);
+    }
     // split-K: all tiles of ONE K slice are neighbours -- they read the same A and B slices, and xcd_remap gives an XCD a
     // contiguous run of L, i.e. whole K slices whose operands are then fetched once into that XCD's L2 (the tile-major order
     // put the K slices of one tile side by side, which share nothing: 4 x the algorithmic fetch on the weight-gradient GEMMs)
@@ -387,7 +401,7 @@ int gemm_splits(int M, int N, int K) {
 template <bool AKC, bool BKC, int T, bool BF = false, int GKT = GK>
 void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    Epilogue ep, bool a_al, bool b_al, int splits, float* partial, hipStream_t st, int batch = 1, long sA = 0,
-                   long sB = 0, long sC = 0) {
+                   long sB = 0, long sC = 0, bool one_d = false) {
     constexpr int ASZ = BF ? T * BFROW / 4 : Stage<AKC, T, GKT>::SZ;
     constexpr int BSZ = BF ? T * BFROW / 4 : Stage<BKC, T, GKT>::SZ;
     const size_t lds = (size_t)(2 * ASZ + 2 * BSZ) * sizeof(float);
@@ -410,11 +424,11 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             fast_attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, true, GKT>), dim3(grid, batch), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M,
-                           N, K, ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC);
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, true, GKT>), one_d ? dim3(grid * batch) : dim3(grid, batch), dim3(256), lds, st,
+                           A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC, one_d ? batch : 0);
     } else {
-        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, false, GKT>), dim3(grid, batch), dim3(256), lds, st, A, lda, B, ldb, C, ldc, M, N, K,
-                           ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC);
+        hipLaunchKernelGGL((gemm_kernel<AKC, BKC, T, BF, false, GKT>), one_d ? dim3(grid * batch) : dim3(grid, batch), dim3(256), lds, st,
+                           A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, splits, kchunk, partial, sA, sB, sC, one_d ? batch : 0);
     }
     if (splits > 1) {
         long nb = ((long)M * N + 255) / 256;
@@ -580,11 +594,12 @@ int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, in
     static const int gkt = getenv("TAG_WINO_GK") ? atoi(getenv("TAG_WINO_GK")) : 16;        // A/B: 32 = the dense GEMM's chunk
     if (transA) {
         if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)
-            launch_gemm_t<false, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+            launch_gemm_t<false, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC,
+                                                        true);
         else if (M >= 128 && N >= 128)
-            launch_gemm_t<false, false, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+            launch_gemm_t<false, false, 128>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC, true);
         else
-            launch_gemm_t<false, false, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC);
+            launch_gemm_t<false, false, 64>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC, true);
         return 0;
     }
     if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)

@@ -369,7 +369,7 @@ WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
 #: must not depend on the batch, or the same clip would score differently in a 4-clip and in a 64-clip pass (the forward is
 #: batch-invariant, tests/test_gpu_infer.py); batches are cut so that the transform planes stay under WINO_WS_MAX bytes
 CONV_WINOGRAD_EVAL = os.environ.get("TAG_CONV_WINOGRAD_EVAL", "1") != "0"
-WINO_WS_MAX = int(os.environ.get("TAG_WINO_WS_MAX", str(3 << 30)))
+WINO_WS_MAX = int(os.environ.get("TAG_WINO_WS_MAX", str(4 << 30)))
 #: a training forward launch keeps its transformed input (16 T Cin floats) on the input tensor for the weight gradient of the same
 #: convolution: three input transforms per step less (0.67 ms at B = 64) for 2.6 GB more live memory
 WINO_KEEP_V = os.environ.get("TAG_WINO_KEEP_V", "1") != "0"
@@ -410,10 +410,16 @@ def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None, training_launch=
     return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False, training_launch=training_launch)[0]
 
 
-def _batch_chunks(B, bytes_per_clip):
+def _batch_chunks(B, bytes_per_clip, tiles_per_clip=0):
     """Batch slices [b0, b1) whose Winograd transform planes stay under WINO_WS_MAX (any cut gives the same rows: every tile is
-    transformed and multiplied independently of the others)."""
+    transformed and multiplied independently of the others).  Among the sizes within a factor 2 of the largest that fits, one
+    whose tile count is a whole number of 128-row product tiles is preferred (the product kernel's loader without tail handling)."""
     nb = max(1, min(B, WINO_WS_MAX // max(1, bytes_per_clip)))
+    if nb < B and tiles_per_clip > 0:
+        for cand in range(nb, max(1, nb // 2) - 1, -1):
+            if (cand * tiles_per_clip) % 128 == 0:
+                nb = cand
+                break
     return [(b0, min(B, b0 + nb)) for b0 in range(0, B, nb)]
 
 
@@ -428,7 +434,7 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     if not x3 and inference and not want_stats:
         u = _wino_u(wpack, x, Cout, any_size=True)
         if u is not None:                      # inference forward: batch cuts bound the workspace (30 s x 256 clips: 25 GB uncut)
-            for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout)):
+            for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout), ((H + 1) // 2) * ((W + 1) // 2)):
                 ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
                 with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
                     call("tag_conv3x3_wino_forward", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y[b0:b1]), None,
@@ -613,7 +619,7 @@ def conv3x3_bnrelu_pool_eval(x, wpack, Cout, st: BNStat, ph, pw, prologue=0, sca
     out = _empty(B, H // ph, W // pw, Cout, like=x)
     u = _wino_u(wpack, x, Cout, any_size=True)
     if u is not None:
-        for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout)):
+        for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout), ((H + 1) // 2) * ((W + 1) // 2)):
             ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
             with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
                 call("tag_conv3x3_wino_forward_bnrelu_pool_eval", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift),

@@ -956,3 +956,53 @@ def max_margin_ranking_loss(x, margin=1.0, lamda1=1.0):
     t1 = F.relu(margin - (d - x))[off]
     t2 = F.relu(margin - (d - lamda1 * x.t()))[off]
     return torch.cat([t1, t2]).mean()
+
+
+# --------------------------------------------------------------------------
+# Winograd F(2x2, 3x3) restatement of the ConvBlock convolutions (row A1) -- the ALGORITHM of csrc/conv_wino.hip stage by
+# stage (input transform, 16 products, output transform; the weight gradient as the adjoint), in the dtype of its inputs.
+# The convolution being restated is nn.Conv2d(kernel 3, stride 1, padding 1, bias=False) of models/panns.py:29-38 as applied in
+# models/panns.py:49-50; tests/test_oracle_golden.py pins these functions to F.conv2d and to autograd's weight gradient.
+# --------------------------------------------------------------------------
+WINO_BT = ((1.0, 0.0, -1.0, 0.0), (0.0, 1.0, 1.0, 0.0), (0.0, -1.0, 1.0, 0.0), (0.0, 1.0, 0.0, -1.0))
+WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+WINO_AT = ((1.0, 1.0, 1.0, 0.0), (0.0, 1.0, -1.0, -1.0))
+
+
+def _wino_mats(like):
+    k = dict(dtype=like.dtype, device=like.device)
+    return torch.tensor(WINO_BT, **k), torch.tensor(WINO_G, **k), torch.tensor(WINO_AT, **k)
+
+
+def _wino_tiles(x):
+    """x (B,C,H,W) -> the 4 x 4 input windows (B,C,th,tw,4,4) of the 2 x 2 output tiles (zero outside the image), th = ceil(H/2)."""
+    B, C, H, W = x.shape
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    xp = F.pad(x, (1, 2 * tw - W + 1, 1, 2 * th - H + 1))
+    return xp.unfold(2, 4, 2).unfold(3, 4, 2)
+
+
+def winograd_conv3x3(x, w):
+    """y = conv2d(x, w, padding=1) as  A^T [ (G g G^T) (.) (B^T d B) ] A  per 2 x 2 output tile (csrc/conv_wino.hip:
+    wino_pack_kernel, wino_input_kernel, the 16 products, wino_output_kernel).  x (B,Cin,H,W), w (Cout,Cin,3,3)."""
+    Bt, G, At = _wino_mats(x)
+    B, _, H, W = x.shape
+    U = torch.einsum("ri,ocij,sj->ocrs", G, w, G)                     # (Cout,Cin,4,4)
+    V = torch.einsum("ri,bcthij,sj->bcthrs", Bt, _wino_tiles(x), Bt)  # (B,Cin,th,tw,4,4)
+    M = torch.einsum("bcthrs,ocrs->bothrs", V, U)                     # 16 products over the input channels
+    Y = torch.einsum("ar,bothrs,es->bothae", At, M, At)               # (B,Cout,th,tw,2,2)
+    th, tw = Y.shape[2], Y.shape[3]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(B, w.shape[0], 2 * th, 2 * tw)[:, :, :H, :W]
+
+
+def winograd_conv3x3_wgrad(x, dy):
+    """dL/dw of y = conv2d(x, w, padding=1) given dL/dy:  G^T [ sum over tiles (A dY A^T) (.) (B^T d B) ] G  -- the adjoint of
+    winograd_conv3x3 in w (csrc/conv_wino.hip: wino_dy_kernel, the K-sliced products, wino_wgrad_finish_kernel)."""
+    Bt, G, At = _wino_mats(x)
+    B, Co, H, W = dy.shape
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    dyp = F.pad(dy, (0, 2 * tw - W, 0, 2 * th - H)).reshape(B, Co, th, 2, tw, 2).permute(0, 1, 2, 4, 3, 5)   # (B,Co,th,tw,2,2)
+    D = torch.einsum("ar,bothae,es->bothrs", At, dyp, At)             # A dY A^T with A = At^T
+    V = torch.einsum("ri,bcthij,sj->bcthrs", Bt, _wino_tiles(x), Bt)
+    dU = torch.einsum("bothrs,bcthrs->ocrs", D, V)
+    return torch.einsum("ri,ocrs,sj->ocij", G, dU, G)                 # G^T dU G

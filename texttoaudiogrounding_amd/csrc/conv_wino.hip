@@ -1,25 +1,33 @@
 // Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / padding 1 convolutions of the DEEP ConvBlocks (models/panns.py:29-38,
-// 49-50: conv1 / conv2 of blocks 3 and 4 of Cnn8Rnn, models/audio_encoder.py:134-138), forward and dgrad, all fp32.
+// 49-50: conv1 / conv2 of blocks 3 and 4 of Cnn8Rnn, models/audio_encoder.py:134-138): forward, dgrad and weight gradient of the
+// training step and the inference forward, all fp32.
 //
-//   y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2 x 2 output tile, 4 x 4 input tile d and filter g (Lavin & Gray 2015)
+//   y  = A^T [ (G g G^T) (.) (B^T d B) ] A             per 2 x 2 output tile, 4 x 4 input window d, filter g (Lavin & Gray 2015)
+//   dw = G^T [ sum over tiles (A dY A^T) (.) (B^T d B) ] G                       (the adjoint in g)
 //
 // 16 multiplies per 2 x 2 outputs and channel pair instead of 36: the contraction over the input channels becomes 16
 // independent dense products  M_xi (T x Cout) = V_xi (T x Cin) . U_xi (Cin x Cout),  T = B * ceil(H/2) * ceil(W/2) tiles,
-// with 2.25 x fewer MFMA FLOP than the direct kernel (csrc/conv.hip) spends -- the direct kernel runs at 0.86-0.88 of the
-// fp32 MFMA peak, so on the layers whose channel count makes the products long enough this is the only lever left that is
-// worth more than a per cent.  Every operation is fp32 (transforms on the VALU, products on v_mfma_f32_32x32x2_f32 through
-// the dense GEMM kernel of gemm.hip, one batched launch); the transform constants are 0, +-1 and 1/2, the measured error
-// against an fp64 convolution is 2.3 x the direct fp32 kernel's (1.1e-7 against 4.6e-8 of the output range, rms, at 512
-// input channels) -- the same rounding class.  Three kernels per convolution:
+// with 2.25 x fewer MFMA FLOP than the direct kernels (csrc/conv.hip) spend -- those run at 0.86-0.88 of the fp32 MFMA peak on
+// these layers, so executing fewer FLOP is the lever that is left.  Every operation is fp32 (transforms on the VALU, products on
+// v_mfma_f32_32x32x2_f32 through the dense GEMM kernel of gemm.hip as ONE batched launch); the transform constants are 0, +-1
+// and 1/2; against an fp64 convolution the result is at least as close as the direct kernel's on these layers (512 input
+// channels, tools/wino_bench.py: 9.0e-7 max / 1.2e-7 rms of the output range against 2.0e-6 / 1.7e-7 -- sixteen chains of Cin
+// products round less than one chain of 9 Cin).  oracle/tag_oracle.py winograd_conv3x3 / winograd_conv3x3_wgrad restate the
+// algorithm stage by stage.  Kernels:
+//   wino_pack_kernel     U = G g G^T of the filter (forward) and of the tap-flipped, channel-swapped filter (dgrad)
 //   wino_input_kernel    x (B,H,W,Cin) -> V [16][T][Cin]: producer BatchNorm + ReLU prologue and zero padding applied on load
-//                        (the same prologue modes as conv3x3_halo_kernel), B^T d B on 4 channels per thread, 16-byte accesses;
-//   gemm_kernel (gemm.hip, tag_launch_gemm_batched)  M [16][T][Cout] = V . U, 128 x 128 tiles;
-//   wino_output_kernel   M -> y (B,H,W,Cout) = A^T m A, and in the same pass EITHER the BatchNorm batch statistics of y
-//                        (pivoted partial rows [K | r | q] + counts, the layout tag_bn_stats_from_partials folds) OR the
-//                        sums of the BatchNorm+ReLU backward the gradient flows into (rows [sum g | sum g xhat] for
-//                        tag_bn_grad_from_partials) -- the EPI == 0 / EPI == 1 epilogues of the direct kernel.
-// The two transform passes are HBM-bound (V and M are 4 x the activation each); they cost ~0.5 ms of the ~1.5 ms the
-// 512 -> 512 layer gains per launch at B = 64.  Fixed summation order everywhere, no atomics: bit-reproducible.
+//                        (the prologue modes of conv3x3_halo_kernel), B^T d B on 4 channels per thread, 16-byte accesses
+//   gemm_kernel<..,16>   (gemm.hip, tag_launch_gemm_batched) the 16 products, 128 x 128 tiles, 16-wide K chunk
+//   wino_output_kernel   M -> y = A^T m A and, in the same pass, EITHER the BatchNorm batch statistics of y (pivoted partial
+//                        rows [K | r | q] + counts, folded by tag_bn_stats_from_partials), OR the sums of the BatchNorm+ReLU
+//                        backward the gradient flows into (rows [sum g | sum g xhat], tag_bn_grad_from_partials) -- the
+//                        EPI == 0 / 1 epilogues of the direct kernel --, OR (inference) BatchNorm(eval) + ReLU + avg/max pool of
+//                        its own 2 x 2 tile, the direct kernel's EPI == 3
+//   wino_dy_kernel, wino_wgrad_finish_kernel   the weight gradient: D = A dY A^T, 16 S products over S slices of the tile axis
+//                        as one batched launch, the slices folded in a fixed order and G^T . G applied; the input planes can be
+//                        the ones the forward launch of the same convolution left behind (v_keep / v_saved)
+// The transform passes are HBM-bound (V and M are 4 x the activation each; 5-7 TB/s); per launch at B = 64 the 512 -> 512 layer
+// takes 2.65-2.7 ms (forward / dgrad / weight gradient) against 4.4-4.5 ms direct.  Fixed summation order, no atomics.
 #include "tag_common.h"
 
 int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,

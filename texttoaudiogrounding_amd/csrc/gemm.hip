@@ -4,7 +4,8 @@
 // backward GEMM of those, and align.DotProduct (models/align.py:14-31) through the fused
 // sigmoid/clamp + (B,B,T,N) scatter epilogue.
 //
-// 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 double-buffered in LDS.
+// 128x128 (large problems) or 64x64 tiles, 4 waves x (2x2 | 1x1) 32x32 MFMA tiles, K chunks of 32 double-buffered in LDS
+// (16 for the batched Winograd-domain products of conv_wino.hip: tag_launch_gemm_batched, blockIdx.y or a 1-D index = product).
 // Both kinds of operand are COPIED into LDS with 16-byte writes (round 4: a ds_write_b32 waits for gaps in the co-resident
 // workgroups' fp32 MFMA streams, tools/coissue_probe.hip, and the transposing store of a k-contiguous operand was four of them
 // per float4): an mn-contiguous operand k-major (S[k][r]), a k-contiguous one row-major (S[r][32 k + 4 pad], the halo conv's

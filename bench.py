@@ -589,8 +589,8 @@ def main():
                "config": {"workload": workload_name(args), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math,
-                          "conv_algo": ("fp32 Winograd F(2x2,3x3) for the forward and dgrad convs of blocks 3-4 (both channel counts "
-                                        ">= 256; csrc/conv_wino.hip), direct MFMA convolution elsewhere"
+                          "conv_algo": ("fp32 Winograd F(2x2,3x3) for the forward, dgrad and weight-gradient convs of blocks 3-4 (channel "
+                                        "counts >= 128 / 256; csrc/conv_wino.hip), direct MFMA convolution elsewhere"
                                         if (args.conv_math == "fp32" and ops.CONV_WINOGRAD) else "direct MFMA convolution")},
                "loss": loss_value,
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /

@@ -249,7 +249,9 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     ops.conv3x3_wgrad(x, dyv)
     assert ops.WINO_LAUNCHES == n0 + 3
     monkeypatch.setattr(ops, "CONV_WINOGRAD", True)
-    wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 channels: below WINO_MIN_C, no Winograd weights made
+    wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 -> 128: the larger count is below WINO_MIN_CMAX
     assert not hasattr(wf64, "wino_u")
+    wf12, _ = ops.pack_conv_weight(w[:, :128].contiguous(), W=W)        # 128 -> 256: taken
+    assert hasattr(wf12, "wino_u")
     wf32, _ = ops.pack_conv_weight(w, W=32)                              # 32-wide image: direct
     assert not hasattr(wf32, "wino_u")

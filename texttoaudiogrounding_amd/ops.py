@@ -361,7 +361,10 @@ FUSE_BN_STATS = os.environ.get("TAG_FUSE_BN_STATS", "1") != "0"
 #: runs at 0.86-0.88 of the fp32 MFMA peak.  Used where it was measured faster at B = 64 (tools/wino_bench.py): both channel
 #: counts >= WINO_MIN_C on the 8- / 16-wide images (Cnn8Rnn blocks 3 and 4: x1.13 ... x1.50 per launch).  "0" = direct kernels only.
 CONV_WINOGRAD = os.environ.get("TAG_CONV_WINOGRAD", "1") != "0"
-WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "256"))
+#: channel rule: the smaller count >= WINO_MIN_C and the larger >= WINO_MIN_CMAX (128 / 256: with the final product kernel the
+#: 128 <-> 256 convs of block 3 gain x1.11 ... x1.34 per launch too; 128 -> 128 on the 32-wide images does not: x0.90 ... x1.01)
+WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "128"))
+WINO_MIN_CMAX = int(os.environ.get("TAG_WINO_MIN_CMAX", "256"))
 #: ... and only on launches with at least this many 2 x 2 output tiles (B * ceil(H/2) * ceil(W/2); 8192 = batch 17 of 10 s clips in
 #: block 4): below that the 16 products are too short to fill the chip and the direct kernel keeps the launch
 WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
@@ -378,7 +381,8 @@ WINO_LAUNCHES = 0
 
 
 def _wino_shape(W, Cin, Cout) -> bool:
-    return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16) and min(Cin, Cout) >= WINO_MIN_C)
+    return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16) and min(Cin, Cout) >= WINO_MIN_C
+            and max(Cin, Cout) >= WINO_MIN_CMAX)
 
 
 def _wino_flop(B, H, W, Cin, Cout) -> float:

@@ -197,6 +197,13 @@ int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, 
 int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
                              float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, float* v_keep,
                              void* stream);
+/* Winograd twin of tag_conv3x3_dgrad_poolsums (same arguments + ws): dx = conv(dy, udgrad) and, from the output transform, the
+ * partial sums [sum dz | sum dz*xhat][Cout] of the BatchNorm+ReLU+pool(ph x 2)+dropout backward of the block below (yref unpooled
+ * (B,Hf,Wf,Cout)); P = tag_conv3x3_wino_stats_rows rows for tag_bn_grad_from_partials. */
+int tag_conv3x3_wino_dgrad_poolsums(const float* dy, const float* udgrad, float* dx, const float* yref, const float* bn_scale,
+                                    const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart, int B,
+                                    int H, int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool, float drop_p,
+                                    uint64_t seed, void* ws, void* stream);
 /* inference twin of tag_conv3x3_forward_bnrelu_pool_eval: the output transform pools its own 2 x 2 tile (one 2 x 2 window or two
  * 1 x 2 windows) after BatchNorm(eval) + ReLU; the raw conv output is never written. */
 int tag_conv3x3_wino_forward_bnrelu_pool_eval(const float* x, const float* ufwd, int prologue, const float* in_scale,

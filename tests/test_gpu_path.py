@@ -692,7 +692,7 @@ def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_)
     loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
     lv = runner.loss_value(loss)                       # also raises if the GRU exchange timed out at this grid
     # the four convs of blocks 3 and 4 (128->256, 256->256, 256->512, 512->512): 4 forward launches, 2 dgrad launches carrying
-    # BatchNorm-backward sums (their conv2), 2 plain dgrads (their conv1), 4 weight gradients
+    # BatchNorm-backward sums (their conv2), 2 dgrads carrying the pool-backward sums of the block below (their conv1), 4 weight gradients
     assert ops.WINO_LAUNCHES - wino0 == (12 if math_ == "fp32" else 0), ops.WINO_LAUNCHES - wino0
     info = model.audio_encoder._last_dropout
     assert info["seeds"] == [int(v) for v in gold["dropout_seeds"]]

@@ -188,6 +188,41 @@ def test_wino_forward_bnrelu_pool_eval(ops, dev, B, H, W, Cin, Cout, pro, ph, po
     assert torch.equal(out, two)
 
 
+@pytest.mark.parametrize("B,Hf,Wf,Cin,C,ph,train,p", [(2, 21, 16, 256, 128, 2, True, 0.2), (2, 9, 16, 128, 256, 1, True, 0.0),
+                                                      (3, 11, 14, 64, 64, 2, False, 0.2), (2, 16, 32, 512, 256, 1, True, 0.2)])
+def test_wino_dgrad_pool_backward_sums(ops, dev, B, Hf, Wf, Cin, C, ph, train, p):
+    """tag_conv3x3_wino_dgrad_poolsums (one-read pool backward on the Winograd path: the output transform of the NEXT block's first
+    conv dgrad carries the sums of the BatchNorm+ReLU+pool+dropout backward below it) against the two-pass kernels on the same dx
+    (tag_bnrelu_pool_backward: pool_bwd_reduce + apply) -- dx bit-identical to the plain Winograd dgrad, dgamma / dbeta to summation
+    round-off, dy accordingly.  2x2 and 1x2 windows, odd Hf / Wf-derived tile overhang, dropout on and off, eval statistics."""
+    pw = 2
+    H, W = Hf // ph, Wf // pw
+    g = torch.Generator().manual_seed(Hf * Wf + C)
+    y = torch.randn(B, C, Hf, Wf, generator=g) * (1.0 + torch.arange(C).view(1, C, 1, 1) % 5) + 0.3
+    w = torch.randn(Cin, C, 3, 3, generator=g) / math.sqrt(9 * C)       # the conv that CONSUMES the pooled output: C -> Cin
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    du = torch.randn(B, Cin, H, W, generator=g)
+    yh, duh, gd = nhwc(y).to(dev), nhwc(du).to(dev), gamma.to(dev)
+    st = ops.bn_stats(yh.view(-1, C), gd, beta.to(dev), rm.clone().to(dev), rv.clone().to(dev), train)
+    seed = 4242
+    _, ud = wino_pack(ops, w.to(dev))                                   # dgrad planes: Cin -> C
+    P = ops.query("tag_conv3x3_wino_stats_rows", B, H, W, C)
+    dx = torch.full((B, H, W, C), float("nan"), device=dev)
+    part = torch.full((P * 2 * C,), float("nan"), device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, C) // 4, device=dev)
+    ops.call("tag_conv3x3_wino_dgrad_poolsums", ops.ptr(duh), ops.ptr(ud), ops.ptr(dx), ops.ptr(yh), ops.ptr(st.scale), ops.ptr(st.shift),
+             ops.ptr(st.mean), ops.ptr(st.invstd), ops.ptr(part), B, H, W, Cin, C, Hf, Wf, ph, pw, 0, float(p), seed, ops.ptr(ws))
+    dx_plain = torch.empty_like(dx)
+    ops.call("tag_conv3x3_wino_forward", ops.ptr(duh), ops.ptr(ud), 0, None, None, ops.ptr(dx_plain), None, B, H, W, Cin, C, ops.ptr(ws),
+             None)
+    assert torch.equal(dx, dx_plain)
+    dy, dg, db = ops.bnrelu_pool_backward(yh, st, gd, dx, ph, pw, p, seed, partials=(P, part))
+    dy2, dg2, db2 = ops.bnrelu_pool_backward(yh, st, gd, dx, ph, pw, p, seed)
+    assert relerr(dg, dg2) < 2e-6 and relerr(db, db2) < 2e-6
+    assert torch.equal(dy, dy2) if not train else relerr(dy, dy2) < 2e-6
+
+
 def test_wino_wgrad_reuses_the_forward_planes(ops, dev, monkeypatch):
     """A training forward launch leaves its transformed input on the input tensor (ops.WINO_KEEP_V); the weight gradient of the same
     convolution multiplies those planes instead of transforming x again: bit-identical dw, the planes released after one use, and

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 struct WinoEpi {
     const float* yref;      // EPI == 1: (B,H,W,C) raw conv output saved by the forward pass (= BatchNorm input)
     const float* scale; const float* shift; const float* mean; const float* invstd;
-    int ph; float wavg, wmax;   // EPI == 3: pool window ph x 2 and the weights of its average / maximum (conv.hip's EPI == 3)
+    int ph; float wavg, wmax;   // EPI == 2 / 3: pool window ph x 2 and the weights of its average / maximum (conv.hip's EPI == 2 / 3)
+    int Hf, Wf;                 // EPI == 2: yref is the UNPOOLED (B,Hf,Wf,C) tensor of the block below, H = Hf / ph, W = Wf / 2
+    float drop_p; unsigned long long seed;
+    int kind;                   // 1 | 2 | 3 = the EPI instance to launch (host side only)
 };
 
 // y (2 x 2 pixels of tile t) = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]],  m[r][s] = M[4 r + s][t][c].  A workgroup holds
@@ -174,10 +177,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     float cnt = 0.0f;
     bool have_pivot = false;
     f32x4 bsc = {0, 0, 0, 0}, bsh = {0, 0, 0, 0}, bmu = {0, 0, 0, 0}, bis = {0, 0, 0, 0};
-    if (EPI == 1 || EPI == 3) {
+    if (EPI == 1 || EPI == 2 || EPI == 3) {
         bsc = *reinterpret_cast<const f32x4*>(epi.scale + 4 * q); bsh = *reinterpret_cast<const f32x4*>(epi.shift + 4 * q);
     }
-    if (EPI == 1) {
+    if (EPI == 1 || EPI == 2) {
         bmu = *reinterpret_cast<const f32x4*>(epi.mean + 4 * q); bis = *reinterpret_cast<const f32x4*>(epi.invstd + 4 * q);
     }
     for (int it = 0; it < WINO_ITERS; ++it) {
@@ -259,6 +262,49 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     for (int k = 0; k < 4; ++k) { const float dv = ov[k] - sk[k]; s1[k] += dv; s2[k] = fmaf(dv, dv, s2[k]); }
                     cnt += 1.0f;
                 }
+                if (EPI == 2) {
+                    // the dgrad of a block's FIRST conv: o = dL/d(dropout(pool(relu(bn(yref))))) at pooled pixel (h, w) of the block
+                    // BELOW; its BatchNorm+ReLU+pool+dropout backward needs sum(dz), sum(dz xhat) over the ph x 2 window of yref before
+                    // any dy can be formed -- the arithmetic of conv3x3_halo_kernel's EPI == 2 / pool_bwd_reduce_kernel: undo the
+                    // dropout (one hash per 4 channels), recompute a = bn(yref), the ReLU mask and the first-maximum arg-max
+                    f32x4 g = o;
+                    if (epi.drop_p > 0.0f) {
+                        const uint64_t grp = ((uint64_t)((unsigned)b * (unsigned)H + (unsigned)h) * (unsigned)W + (unsigned)w) * (unsigned)cq
+                                             + (unsigned)q;
+                        const uint64_t bits = tag_keep4_bits(epi.seed, grp);
+                        const float keep_scale = 1.0f / (1.0f - epi.drop_p);
+                        const unsigned thr = tag_keep4_threshold(epi.drop_p);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[k] = tag_keep4(bits, k, thr) ? g[k] * keep_scale : 0.0f;
+                    }
+                    const float* yw = epi.yref + (((size_t)b * epi.Hf + (size_t)h * epi.ph) * epi.Wf + 2 * w) * C + 4 * q;
+                    f32x4 vw[4];
+                    vw[0] = *reinterpret_cast<const f32x4*>(yw);
+                    vw[1] = *reinterpret_cast<const f32x4*>(yw + C);
+                    if (epi.ph == 2) {
+                        vw[2] = *reinterpret_cast<const f32x4*>(yw + (size_t)epi.Wf * C);
+                        vw[3] = *reinterpret_cast<const f32x4*>(yw + (size_t)epi.Wf * C + C);
+                    } else { vw[2] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; vw[3] = vw[2]; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a4[4];
+#pragma unroll
+                        for (int u2 = 0; u2 < 4; ++u2) a4[u2] = fmaf(vw[u2][k], bsc[k], bsh[k]);
+                        if (epi.ph != 2) { a4[2] = -INFINITY; a4[3] = -INFINITY; }
+                        const float mx = fmaxf(fmaxf(a4[0], a4[1]), fmaxf(a4[2], a4[3]));
+                        const float gw = g[k] * epi.wavg, gwm = g[k] * (epi.wavg + epi.wmax);
+                        bool found = false;
+#pragma unroll
+                        for (int u2 = 0; u2 < 4; ++u2) {
+                            const bool eq = a4[u2] == mx;
+                            const bool hit = eq && !found;
+                            found = found || eq;
+                            const float dz = a4[u2] > 0.0f ? (hit ? gwm : gw) : 0.0f;
+                            s1[k] += dz;
+                            s2[k] = fmaf(dz, (vw[u2][k] - bmu[k]) * bis[k], s2[k]);
+                        }
+                    }
+                }
                 if (EPI == 1) {
                     const f32x4 yr = *reinterpret_cast<const f32x4*>(epi.yref + off);
                     const float yv[4] = {yr.x, yr.y, yr.z, yr.w};
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         *reinterpret_cast<f32x4*>(ps + 2 * C) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
         if (q == 0) stats[(size_t)P * 3 * C + prow] = cnt;
     }
-    if (EPI == 1) {
+    if (EPI == 1 || EPI == 2) {
         float* ps = stats + (size_t)prow * 2 * C + 4 * q;
         *reinterpret_cast<f32x4*>(ps) = (f32x4){s1[0], s1[1], s1[2], s1[3]};
         *reinterpret_cast<f32x4*>(ps + C) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
@@ -417,8 +463,10 @@ int wino_run(const float* x, const float* U, int pro, const float* s, const floa
     }
     tag_launch_gemm_batched(V, Cin, g.T * Cin, U, Cout, (long)Cin * Cout, Mb, Cout, g.T * Cout, (int)g.T, Cout, Cin, 16, st, 0);
     const int gout = g.P / g.G;
-    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f};
-    if (epi && epi->ph > 0)
+    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f, 0, 0, 0.0f, 0ull, 0};
+    if (epi && epi->kind == 2)
+        hipLaunchKernelGGL(wino_output_kernel<2>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
+    else if (epi && epi->kind == 3)
         hipLaunchKernelGGL(wino_output_kernel<3>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
     else if (epi)
         hipLaunchKernelGGL(wino_output_kernel<1>, dim3(gout), dim3(256), 0, st, Mb, y, stats, *epi, B, H, W, Cout, g.th, g.tw, g.T, g.P);
@@ -452,6 +500,23 @@ extern "C" size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Co
 extern "C" int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout) {
     if (!wino_channels_ok(Cout)) return 0;
     return wino_geom(B, H, W, Cout).P;
+}
+
+// dgrad of a block's FIRST conv + the reduction half of the BatchNorm+ReLU+pool+dropout backward of the block BELOW it: the Winograd
+// twin of tag_conv3x3_dgrad_poolsums (same arguments + ws; bnpart rows [P][2][Cout], P = tag_conv3x3_wino_stats_rows).
+extern "C" int tag_conv3x3_wino_dgrad_poolsums(const float* dy, const float* u, float* dx, const float* yref, const float* bn_scale,
+                                               const float* bn_shift, const float* bn_mean, const float* bn_invstd, float* bnpart,
+                                               int B, int H, int W, int Cin, int Cout, int Hf, int Wf, int ph, int pw, int pool,
+                                               float drop_p, uint64_t seed, void* ws, void* stream) {
+    TAG_CHECK_ARG(dy && u && dx && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && ws);
+    TAG_CHECK_ARG(tag_conv3x3_wino_ok(B, H, W, Cin, Cout) && (long)B * Hf * Wf < (1L << 31));
+    TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H == Hf / ph && W == Wf / pw);
+    TAG_CHECK_ARG((pool == 0 || pool == 2 || pool == 3) && drop_p >= 0.0f && drop_p < 1.0f);
+    const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
+    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, ph, wavg, wmax, Hf, Wf, drop_p, (unsigned long long)seed, 2};
+    wino_run(dy, u, 0, nullptr, nullptr, dx, bnpart, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
+    TAG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -518,7 +583,7 @@ extern "C" int tag_conv3x3_wino_forward_bnrelu_pool_eval(const float* x, const f
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
     TAG_CHECK_ARG(pw == 2 && (ph == 1 || ph == 2) && H / ph > 0 && W >= 2 && (pool == 0 || pool == 2 || pool == 3));
     const float wavg = pool == 3 ? 0.0f : 1.0f / (float)(ph * pw), wmax = pool == 2 ? 0.0f : 1.0f;
-    const WinoEpi epi{nullptr, bn_scale, bn_shift, nullptr, nullptr, ph, wavg, wmax};
+    const WinoEpi epi{nullptr, bn_scale, bn_shift, nullptr, nullptr, ph, wavg, wmax, 0, 0, 0.0f, 0ull, 3};
     wino_run(x, u, prologue, in_scale, in_shift, out, nullptr, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();
     return 0;
@@ -529,7 +594,7 @@ extern "C" int tag_conv3x3_wino_dgrad_bnsums(const float* dy, const float* u, fl
                                              int B, int H, int W, int Cin, int Cout, void* ws, void* stream) {
     TAG_CHECK_ARG(dy && u && da && yref && bn_scale && bn_shift && bn_mean && bn_invstd && bnpart && ws);
     TAG_CHECK_ARG(tag_conv3x3_wino_ok(B, H, W, Cin, Cout));
-    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0.0f, 0.0f};
+    const WinoEpi epi{yref, bn_scale, bn_shift, bn_mean, bn_invstd, 0, 0.0f, 0.0f, 0, 0, 0.0f, 0ull, 1};
     wino_run(dy, u, 0, nullptr, nullptr, da, bnpart, &epi, B, H, W, Cin, Cout, static_cast<float*>(ws), as_stream(stream));
     TAG_LAUNCH_CHECK();
     return 0;

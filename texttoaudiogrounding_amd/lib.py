@@ -56,6 +56,7 @@ _SIGS = {
     "tag_conv3x3_wino_wgrad": (c_int, [P, c_int, P, P, P, P] + [c_int] * 5 + [P, P, P]),
     "tag_conv3x3_wino_forward": (c_int, [P, P, c_int, P, P, P, P] + [c_int] * 5 + [P, P, P]),
     "tag_conv3x3_wino_forward_bnrelu_pool_eval": (c_int, [P, P, c_int, P, P, P, P, P] + [c_int] * 8 + [P, P]),
+    "tag_conv3x3_wino_dgrad_poolsums": (c_int, [P] * 9 + [c_int] * 10 + [c_float, c_uint64, P, P]),
     "tag_conv3x3_wino_dgrad_bnsums": (c_int, [P] * 9 + [c_int] * 5 + [P, P]),
     "tag_conv3x3_forward_bnrelu_pool_eval": (c_int, [P, P, c_int, P, P, P, P, P] + [c_int] * 8 + [P]),
     "tag_conv3x3_dgrad_poolsums": (c_int, [P] * 9 + [c_int] * 10 + [c_float, c_uint64, P]),

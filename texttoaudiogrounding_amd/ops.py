@@ -597,6 +597,16 @@ def conv3x3_dgrad_poolsums(dy_in, wpack, yref, st: BNStat, ph, pw, drop_p=0.0, s
             call("tag_conv3x3_dgrad_poolsums_bf16", ptr(dy_in), ptr(wpack.blob), ptr(dx), ptr(yref), ptr(st.scale), ptr(st.shift),
                  ptr(st.mean), ptr(st.invstd), ptr(part), B, H, W, Cin, C, Hf, Wf, ph, pw, int(pool), float(drop_p), seed)
         return dx, (P, part)
+    u = _wino_u(wpack, dy_in, C)
+    if u is not None:                  # Winograd dgrad: the sums come from its output transform (conv_wino.hip, EPI == 2)
+        P = query("tag_conv3x3_wino_stats_rows", B, H, W, C)
+        dx = _empty(B, H, W, C, like=dy_in)
+        part = _empty(P * 2 * C, like=dy_in)
+        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, C), dy_in)
+        with _timed(("conv3x3_wino", B, H, W, Cin, C), _wino_flop(B, H, W, Cin, C)):
+            call("tag_conv3x3_wino_dgrad_poolsums", ptr(dy_in), ptr(u), ptr(dx), ptr(yref), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                 ptr(st.invstd), ptr(part), B, H, W, Cin, C, Hf, Wf, ph, pw, int(pool), float(drop_p), seed, ptr(ws))
+        return dx, (P, part)
     P = query("tag_conv3x3_stats_rows", B, H, W, C)
     dx = _empty(B, H, W, C, like=dy_in)
     part = _empty(P * 2 * C, like=dy_in)
@@ -1340,12 +1350,11 @@ class Cnn8RnnFunction(TagFunction):
             if i > 0:
                 _deliver(grads, sk, o, sw.wgrad(x_in, dy1, out=sk[o]))
                 below = sv["acts"][i - 1]          # (x, y1, s1, y2, s2, ...) of the block whose pooled output x_in is
-                if _wino_u(wd1, dy1, x_in.shape[3], count=False) is not None:
-                    # Winograd dgrad (block 4's first conv at the benched size: 2.24 -> 1.67 ms); the pool-backward sums of the
-                    # block below keep their own pass (pool_bwd_reduce, 0.1 ms there)
-                    dx = conv3x3(dy1, wd1, x_in.shape[3], training_launch=True)
-                elif pool_sums_fusable(dy1, wd1, below[3], *CNN8_POOLS[i - 1]):
+                if pool_sums_fusable(dy1, wd1, below[3], *CNN8_POOLS[i - 1]):
+                    # (direct halo-tile kernel or, for the deep layers, the Winograd form: both carry the sums in their epilogue)
                     dx, poolpart = conv3x3_dgrad_poolsums(dy1, wd1, below[3], below[4], *CNN8_POOLS[i - 1], drop[0], seeds[i - 1])
+                elif _wino_u(wd1, dy1, x_in.shape[3], count=False) is not None:
+                    dx = conv3x3(dy1, wd1, x_in.shape[3], training_launch=True)
                 else:
                     dx = conv3x3(dy1, wd1, x_in.shape[3])
                 sw.release()

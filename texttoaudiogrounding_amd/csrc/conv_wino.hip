@@ -21,8 +21,9 @@
 //   wino_output_kernel   M -> y = A^T m A and, in the same pass, EITHER the BatchNorm batch statistics of y (pivoted partial
 //                        rows [K | r | q] + counts, folded by tag_bn_stats_from_partials), OR the sums of the BatchNorm+ReLU
 //                        backward the gradient flows into (rows [sum g | sum g xhat], tag_bn_grad_from_partials) -- the
-//                        EPI == 0 / 1 epilogues of the direct kernel --, OR (inference) BatchNorm(eval) + ReLU + avg/max pool of
-//                        its own 2 x 2 tile, the direct kernel's EPI == 3
+//                        EPI == 0 / 1 epilogues of the direct kernel --, OR (dgrad of a block's first conv) the sums of the
+//                        BatchNorm+ReLU+pool+dropout backward of the block below on the thread's own 2 x 2 tile (EPI == 2), OR
+//                        (inference) BatchNorm(eval) + ReLU + avg/max pool of its own 2 x 2 tile, the direct kernel's EPI == 3
 //   wino_dy_kernel, wino_wgrad_finish_kernel   the weight gradient: D = A dY A^T, 16 S products over S slices of the tile axis
 //                        as one batched launch, the slices folded in a fixed order and G^T . G applied; the input planes can be
 //                        the ones the forward launch of the same convolution left behind (v_keep / v_saved)

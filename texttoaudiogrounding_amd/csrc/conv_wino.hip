@@ -29,7 +29,7 @@
 //                        the ones the forward launch of the same convolution left behind (v_keep / v_saved)
 // The transform passes are HBM-bound (V and M are 4 x the activation each; 5-7 TB/s); per launch at B = 64 the 512 -> 512 layer
 // takes 2.65-2.7 ms (forward / dgrad / weight gradient) against 4.4-4.5 ms direct.  Fixed summation order, no atomics.
-#include "tag_common.h"
+#include "conv_wino.h"
 
 int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC, int M,
                             int N, int K, int batch, hipStream_t st, int transA);
@@ -148,14 +148,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     }
 }
 
-struct WinoEpi {
-    const float* yref;      // EPI == 1: (B,H,W,C) raw conv output saved by the forward pass (= BatchNorm input)
-    const float* scale; const float* shift; const float* mean; const float* invstd;
-    int ph; float wavg, wmax;   // EPI == 2 / 3: pool window ph x 2 and the weights of its average / maximum (conv.hip's EPI == 2 / 3)
-    int Hf, Wf;                 // EPI == 2: yref is the UNPOOLED (B,Hf,Wf,C) tensor of the block below, H = Hf / ph, W = Wf / 2
-    float drop_p; unsigned long long seed;
-    int kind;                   // 1 | 2 | 3 = the EPI instance to launch (host side only)
-};
 
 // y (2 x 2 pixels of tile t) = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]],  m[r][s] = M[4 r + s][t][c].  A workgroup holds
 // G = 256 / (C / 4) tile slots and walks ITERS tiles per slot (tile = (blockIdx.x * ITERS + it) * G + slot); every slot
@@ -449,6 +441,21 @@ inline bool wino_channels_ok(int C) { return C >= 32 && C <= 1024 && C % 4 == 0 
 
 int wino_run(const float* x, const float* U, int pro, const float* s, const float* t, float* y, float* stats, const WinoEpi* epi,
              int B, int H, int W, int Cin, int Cout, float* ws, hipStream_t st, float* v_keep = nullptr) {
+    if (wino_fused_ok(Cin, Cout)) {
+        // one kernel, no planes (conv_wino_fused.hip); a caller that still asks for the transformed input gets it from the plane
+        // form's input transform (the fused weight gradient does not need it)
+        if (v_keep) {
+            const WinoGeom gk = wino_geom(B, H, W, Cout);
+            const int gk_in = (int)((gk.T * (Cin / 4) + 255) / 256);
+            switch (pro) {
+                case 0: hipLaunchKernelGGL(wino_input_kernel<0>, dim3(gk_in), dim3(256), 0, st, x, s, t, v_keep, B, H, W, Cin, gk.th, gk.tw, gk.T, gk.T); break;
+                case 1: hipLaunchKernelGGL(wino_input_kernel<1>, dim3(gk_in), dim3(256), 0, st, x, s, t, v_keep, B, H, W, Cin, gk.th, gk.tw, gk.T, gk.T); break;
+                case 2: hipLaunchKernelGGL(wino_input_kernel<2>, dim3(gk_in), dim3(256), 0, st, x, s, t, v_keep, B, H, W, Cin, gk.th, gk.tw, gk.T, gk.T); break;
+                default: hipLaunchKernelGGL(wino_input_kernel<3>, dim3(gk_in), dim3(256), 0, st, x, s, t, v_keep, B, H, W, Cin, gk.th, gk.tw, gk.T, gk.T); break;
+            }
+        }
+        return wino_fused_run(x, U, pro, s, t, y, stats, epi, B, H, W, Cin, Cout, st);
+    }
     const WinoGeom g = wino_geom(B, H, W, Cout);
     // v_keep: the transformed input goes to a buffer of the caller's (16 T Cin floats) that outlives the call -- the weight
     // gradient of the same convolution multiplies the same planes (tag_conv3x3_wino_wgrad, v_saved); ws then holds the products only
@@ -500,6 +507,7 @@ extern "C" size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Co
 
 extern "C" int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout) {
     if (!wino_channels_ok(Cout)) return 0;
+    if (wino_fused_ok(32, Cout)) return wino_fused_rows(B, H, W);      // (every Cin tag_conv3x3_wino_ok accepts is a multiple of 32)
     return wino_geom(B, H, W, Cout).P;
 }
 

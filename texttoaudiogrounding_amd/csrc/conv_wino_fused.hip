@@ -1,0 +1,466 @@
+// Winograd F(2x2,3x3) convolution as ONE kernel per launch (round 6): the input transform B^T d B is formed on the way into LDS,
+// the 16 products M_xi = V_xi . U_xi run into 16 accumulator sets that never leave the registers, and the output transform
+// A^T m A + the epilogue forms of conv3x3_halo_kernel (BatchNorm statistics / BatchNorm-backward sums / pool-backward sums /
+// inference pooling) are applied from a parked output tile.  Replaces the plane form of conv_wino.hip (wino_input_kernel ->
+// batched gemm_kernel<..,16> -> wino_output_kernel: V and M planes of 4 x the activation each, written and read once per launch:
+// 47 of the 86.5 GB per training step in round 5) for the convs of models/panns.py:29-38,49-50 in Cnn8Rnn blocks 3-4
+// (models/audio_encoder.py:134-138).  Same arithmetic: fp32 transforms on the VALU with constants 0, +-1, 1/2, products on
+// v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain).
+//
+// wino_fused_kernel<PRO, EPI>: 512 threads (8 waves, two per SIMD) own 64 tiles x 64 couts x 16 xi:
+//   * wave (h, wm, wn): xi half h (transform rows 2h, 2h+1), 32 couts x 32 tiles -> 8 accumulator sets of 16 registers = 128 AGPRs;
+//     A operand = U (rows = couts), B operand = V (columns = tiles): a lane then holds 4 CONSECUTIVE couts of one tile per register
+//     quad, so the parked tile is written with 16-byte LDS stores and no lane transposes.
+//   * K chunk = 8 input channels.  Per chunk every thread stages ONE (tile, channel quad, window column s) item of V -- 4 global loads
+//     (the window column's 4 rows; the addresses are fixed for the whole K loop, only the channel offset moves), producer prologue +
+//     zero padding, the column transform locally and the row transform with ONE quad-permute DPP exchange per value, 4 ds_write_b128
+//     -- and ONE 4 x 4 (k x n) block of U per xi: 4 global loads, the transpose is register naming, 4 ds_write_b128.
+//   * LDS image of both operands: [xi][row 64][k 8] with the 16-byte slot XOR-ed by (row >> 3) & 1 and planes 2080 B apart: the
+//     fragment of four k-steps is ONE conflict-free ds_read_b128 per operand, and the 8 lanes of a ds_write_b128 group (same row,
+//     different xi / slot) cover 128 contiguous bytes.  Two buffers of (V + U) = 133 KB; one barrier per chunk.
+//   * pipeline: global loads of chunk c+2 | transform + LDS writes of chunk c+1 | MFMAs of chunk c, the staging work cut into
+//     slices between the 8 MFMA groups of a chunk (sched_barrier keeps the slices where they are).
+//   * epilogue: each wave reduces its 8 sets to its share of the 2 x 2 outputs (A^T . A is linear, the two xi halves add), parks
+//     it in LDS [half][pixel of the tile][tile][cout]; then thread = (pixel, cout quad): the two halves are added, y leaves with
+//     fully coalesced 16-byte stores and the epilogue sums are formed per thread, folded over the workgroup through LDS in a fixed
+//     order: ONE partial row per 64-tile block (P = number of blocks).
+// Workgroup order: groups of 8 tile blocks x all cout blocks, tile block fastest, an XCD gets a contiguous run (xcd_remap): the
+// 32 workgroups resident on an XCD share 4 cout blocks of U and 8 tile blocks of x in its L2.
+//
+// wino_fused_wgrad_kernel: dw = G^T [ sum_t (A dY A^T) (.) (B^T d B) ] G with BOTH transforms formed at staging: 64 ci x 64 co x
+// 16 xi accumulators per workgroup, K = tiles in chunks of 8, split over S slices of the tile axis; partial 3 x 3 filters per
+// (slice, xi half) are folded in a fixed order by wino_fused_wgrad_finish_kernel.
+#include "conv_wino.h"
+
+namespace {
+
+constexpr int FPL = 64 * 8 + 8;               // floats per xi plane of an operand buffer (2080 B: planes rotate by 32 B mod 128)
+constexpr int FBUF = 16 * FPL;                // one operand buffer (V or U) of one pipeline stage
+constexpr int FPARK_LD = 68;                  // floats per (pixel, tile) row of the parked tile (272 B: conflict-free 16-byte stores)
+constexpr int FPARK = 2 * 4 * 64 * FPARK_LD;  // [xi half][pixel of the 2 x 2 tile][tile][cout]
+constexpr int FRED = 32 * 16 * 8 + 32;        // per-slot epilogue sums + counts
+constexpr int FLDS = FPARK + FRED;            // 155,776 B
+constexpr int FSS = 4 * FBUF;                 // producer scale / shift (2 x Cin floats) behind the operand buffers
+constexpr int FGM = 8;                        // tile blocks per workgroup-order group
+static_assert(FSS + 2048 <= FLDS, "scale/shift staging must fit");
+
+template <int PRO>
+__device__ __forceinline__ f32x4 fused_prologue(f32x4 v, f32x4 s, f32x4 t) {      // = apply_prologue of conv.hip
+    if (PRO == 1) {
+        v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.0f); v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.0f);
+        v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.0f); v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.0f);
+    } else if (PRO == 2) {
+        v.x = fmaf(v.x > 0 ? v.x : 0.1f * v.x, s.x, t.x); v.y = fmaf(v.y > 0 ? v.y : 0.1f * v.y, s.y, t.y);
+        v.z = fmaf(v.z > 0 ? v.z : 0.1f * v.z, s.z, t.z); v.w = fmaf(v.w > 0 ? v.w : 0.1f * v.w, s.w, t.w);
+    } else if (PRO == 3) {
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float dpp_quad_2211(float v) {       // lane s of a quad receives the value of lane {2, 2, 1, 1}[s]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
+}
+
+// the wave's share of the 2 x 2 outputs from its 8 accumulator sets (xi = 4 r + s, r = 2 HH + {0, 1}), register quad rq
+template <int HH>
+__device__ __forceinline__ void fused_out_quad(const f32x16 (&acc)[8], int rq, f32x4 (&o)[4]) {
+    f32x4 p0[4], p1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float m0 = acc[s][4 * rq + k], m1 = acc[4 + s][4 * rq + k];
+            if (HH == 0) { p0[s][k] = m0 + m1; p1[s][k] = m1; }          // rows r = 0, 1 of  [[1,1,1,0],[0,1,-1,-1]]
+            else { p0[s][k] = m0; p1[s][k] = -m0 - m1; }                 // rows r = 2, 3
+        }
+    o[0] = p0[0] + p0[1] + p0[2];
+    o[1] = p0[1] - p0[2] - p0[3];
+    o[2] = p1[0] + p1[1] + p1[2];
+    o[3] = p1[1] - p1[2] - p1[3];
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                         float* __restrict__ y, float* __restrict__ stats, WinoEpi epi, int B, int H,
+                                                         int W, int Cin, int Cout, int th, int tw, long T, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- workgroup -> (tile block mt, cout block nt)
+    int mt, nt;
+    {
+        const int L = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+        const int gsz = FGM * n_tiles, g = L / gsz, rem = L - g * gsz;
+        const int mcount = (m_tiles - g * FGM) < FGM ? (m_tiles - g * FGM) : FGM;
+        nt = rem / mcount;
+        mt = g * FGM + (rem - nt * mcount);
+    }
+    const long m0 = (long)mt * 64;
+    const int n0 = nt * 64;
+    const int nch = Cin >> 3;
+
+    // ---- V staging role: (tile tl, channel quad q of the chunk, window column s)
+    const int s = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
+    const float fa = s == 3 ? -1.0f : 1.0f, fb = (s & 1) ? 1.0f : -1.0f;     // V[r][s] = fa tt[r][s] + fb tt[r][{2,2,1,1}[s]]
+    const float* xp;
+    int xo[4];
+    bool okr[4];
+    {
+        const long t = m0 + tl;
+        const bool okt = t < T;
+        const long tt_ = okt ? t : 0;
+        const int j = (int)(tt_ % tw);
+        const long bi = tt_ / tw;
+        const int i = (int)(bi % th), b = (int)(bi / th);
+        const int w = 2 * j - 1 + s;
+        const bool okw = okt && (unsigned)w < (unsigned)W;
+        xp = x + (size_t)b * H * W * Cin + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = 2 * i - 1 + r;
+            okr[r] = okw && (unsigned)h < (unsigned)H;
+            xo[r] = okr[r] ? (h * W + w) * Cin : 0;
+        }
+    }
+    const int vw0 = s * FPL + tl * 8 + ((q ^ ((tl >> 3) & 1)) << 2);         // + 4 r FPL
+
+    // ---- U staging role: 4 x 4 block (k = 4 kq .. +3, n = 4 nq .. +3) of plane xu
+    const int kq = tid & 1, xu = ((tid >> 1) & 3) + 4 * (wave & 3), nq = ((tid >> 3) & 7) + 8 * (wave >> 2);
+    const float* up = U + ((size_t)xu * Cin + 4 * kq) * Cout + n0 + 4 * nq;
+    const int uw0 = xu * FPL + 32 * nq + ((kq ^ ((nq >> 1) & 1)) << 2);      // + 8 i for row n = 4 nq + i
+
+    // ---- MFMA role
+    const int hh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kl = lane >> 5, ml = lane & 31;
+    const int fsw = (kl ^ ((ml >> 3) & 1)) << 2;
+    const int aoff = FBUF + 8 * hh * FPL + (wm * 32 + ml) * 8 + fsw;          // U fragment (A operand)
+    const int boff = 8 * hh * FPL + (wn * 32 + ml) * 8 + fsw;                 // V fragment (B operand)
+
+    if (PRO != 0) {
+        for (int i = tid; i < Cin; i += 512) { smem[FSS + i] = in_scale[i]; smem[FSS + Cin + i] = in_shift[i]; }
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    f32x4 xr[4], ur[4];
+    auto load_x = [&](int c) {
+        const float* p = xp + c * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[r] = *reinterpret_cast<const f32x4*>(p + xo[r]);
+    };
+    auto load_u = [&](int c) {
+        const float* p = up + (size_t)c * 8 * Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ur[j] = *reinterpret_cast<const f32x4*>(p + (size_t)j * Cout);
+    };
+    f32x4 d[4], tt[4];
+    f32x4 psc = {1.0f, 1.0f, 1.0f, 1.0f}, psh = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto ld_ss = [&](int c) {
+        if (PRO != 0) {
+            psc = *reinterpret_cast<const f32x4*>(smem + FSS + c * 8 + 4 * q);
+            psh = *reinterpret_cast<const f32x4*>(smem + FSS + Cin + c * 8 + 4 * q);
+        }
+    };
+    auto xs_rows = [&](int r0) {                       // prologue + zero padding of window rows r0, r0 + 1
+#pragma unroll
+        for (int r = r0; r < r0 + 2; ++r) {
+            const f32x4 v = fused_prologue<PRO>(xr[r], psc, psh);
+            d[r] = okr[r] ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto xs_cols = [&]() {                             // column transform (B^T d): the thread's window column
+        tt[0] = d[0] - d[2];
+        tt[1] = d[1] + d[2];
+        tt[2] = d[2] - d[1];
+        tt[3] = d[1] - d[3];
+    };
+    auto xs_write = [&](float* Vb, int r0) {           // row transform (. B) across the quad + store, rows r0, r0 + 1
+#pragma unroll
+        for (int r = r0; r < r0 + 2; ++r) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), fa * tt[r][k]);
+            *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = v;
+        }
+    };
+    auto us_write = [&](float* Ub, int i0) {           // rows n = 4 nq + i0, + 1 of the transposed block
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i)
+            *reinterpret_cast<f32x4*>(Ub + uw0 + 8 * i) = (f32x4){ur[0][i], ur[1][i], ur[2][i], ur[3][i]};
+    };
+
+    // ---- prologue of the pipeline: chunk 0 into buffer 0, chunk 1 into the registers
+    load_x(0);
+    load_u(0);
+    __syncthreads();
+    ld_ss(0);
+    xs_rows(0); xs_rows(2); xs_cols();
+    xs_write(smem, 0); xs_write(smem, 2);
+    us_write(smem + FBUF, 0); us_write(smem + FBUF, 2);
+    {
+        const int c1 = nch > 1 ? 1 : 0;
+        load_x(c1);
+        load_u(c1);
+        ld_ss(c1);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        const float* cur = smem + (c & 1) * 2 * FBUF;
+        float* nxt = smem + ((c + 1) & 1) * 2 * FBUF;
+        const int c2 = c + 2 < nch ? c + 2 : nch - 1;
+        f32x4 af[2], bf[2];
+        af[0] = *reinterpret_cast<const f32x4*>(cur + aoff);
+        bf[0] = *reinterpret_cast<const f32x4*>(cur + boff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            if (jj + 1 < 8) {
+                af[(jj + 1) & 1] = *reinterpret_cast<const f32x4*>(cur + aoff + (jj + 1) * FPL);
+                bf[(jj + 1) & 1] = *reinterpret_cast<const f32x4*>(cur + boff + (jj + 1) * FPL);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj & 1][e], bf[jj & 1][e], acc[jj], 0, 0, 0);
+            // staging slices of chunk c + 1 (in the registers since the previous iteration) and the loads of chunk c + 2
+            if (jj == 0) xs_rows(0);
+            if (jj == 1) { xs_rows(2); xs_cols(); }
+            if (jj == 2) xs_write(nxt, 0);
+            if (jj == 3) { xs_write(nxt, 2); load_x(c2); }
+            if (jj == 4) us_write(nxt + FBUF, 0);
+            if (jj == 5) { us_write(nxt + FBUF, 2); load_u(c2); }
+            if (jj == 6) ld_ss(c2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform: each wave parks its share of the 2 x 2 outputs  [half][pixel 2a+e][tile][cout]
+    {
+        float* park = smem + hh * (4 * 64 * FPARK_LD) + (wn * 32 + ml) * FPARK_LD + wm * 32 + 4 * kl;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 o[4];
+            if (hh == 0) fused_out_quad<0>(acc, rq, o); else fused_out_quad<1>(acc, rq, o);
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) *reinterpret_cast<f32x4*>(park + ae * 64 * FPARK_LD + 8 * rq) = o[ae];
+        }
+    }
+    __syncthreads();
+
+    // ---- thread = (pixel, cout quad): add the halves, store, epilogue sums
+    const int cq = tid & 15, slot = tid >> 4;
+    const float* pk = smem + 4 * cq;
+    constexpr int HALF = 4 * 64 * FPARK_LD;
+    int tb[2], ti[2], tj[2];
+    bool tok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long t = m0 + slot + 32 * u;
+        tok[u] = t < T;
+        const long t2 = tok[u] ? t : 0;
+        tj[u] = (int)(t2 % tw);
+        const long bi = t2 / tw;
+        ti[u] = (int)(bi % th);
+        tb[u] = (int)(bi / th);
+    }
+    const int co = n0 + 4 * cq;
+
+    if (EPI == 3) {
+        // inference: out (B, H/ph, W/2, C) = avg/max pool(relu(y * scale + shift)) of the tile's own 2 x 2 outputs (the expression and
+        // summation order of bnact_pool_fwd_kernel / wino_output_kernel<3>)
+        const f32x4 bsc = *reinterpret_cast<const f32x4*>(epi.scale + co), bsh = *reinterpret_cast<const f32x4*>(epi.shift + co);
+        const int Hp = H / epi.ph, Wp = W >> 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tile = slot + 32 * u;
+            f32x4 a[4];
+#pragma unroll
+            for (int ae = 0; ae < 4; ++ae) {
+                const float* p = pk + (ae * 64 + tile) * FPARK_LD;
+                const f32x4 o = *reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + HALF);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[ae][k] = fmaxf(fmaf(o[k], bsc[k], bsh[k]), 0.0f);
+            }
+            if (!tok[u] || tj[u] >= Wp) continue;
+            if (epi.ph == 2) {
+                if (ti[u] < Hp) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sum = ((a[0][k] + a[1][k]) + a[2][k]) + a[3][k];
+                        const float mx = fmaxf(fmaxf(fmaxf(a[0][k], a[1][k]), a[2][k]), a[3][k]);
+                        o[k] = sum * epi.wavg + mx * epi.wmax;
+                    }
+                    *reinterpret_cast<f32x4*>(y + (((size_t)tb[u] * Hp + ti[u]) * Wp + tj[u]) * Cout + co) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int hp = 2 * ti[u] + r;
+                    if (hp >= Hp) continue;
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = (a[2 * r][k] + a[2 * r + 1][k]) * epi.wavg + fmaxf(a[2 * r][k], a[2 * r + 1][k]) * epi.wmax;
+                    *reinterpret_cast<f32x4*>(y + (((size_t)tb[u] * Hp + hp) * Wp + tj[u]) * Cout + co) = o;
+                }
+            }
+        }
+        return;
+    }
+
+    const bool want = (EPI == 0) ? (stats != nullptr) : true;
+    f32x4 bsc = {0, 0, 0, 0}, bsh = {0, 0, 0, 0}, bmu = {0, 0, 0, 0}, bis = {0, 0, 0, 0};
+    if (EPI == 1 || EPI == 2) {
+        bsc = *reinterpret_cast<const f32x4*>(epi.scale + co); bsh = *reinterpret_cast<const f32x4*>(epi.shift + co);
+        bmu = *reinterpret_cast<const f32x4*>(epi.mean + co); bis = *reinterpret_cast<const f32x4*>(epi.invstd + co);
+    }
+    f32x4 piv = {0, 0, 0, 0};
+    if (EPI == 0 && want) piv = *reinterpret_cast<const f32x4*>(pk) + *reinterpret_cast<const f32x4*>(pk + HALF);   // pixel (0,0) of tile 0
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, cnt = 0.0f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int ae = it >> 1, u = it & 1, a = ae >> 1, e = ae & 1;
+        const int tile = slot + 32 * u;
+        const float* p = pk + (ae * 64 + tile) * FPARK_LD;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + HALF);
+        const int h = 2 * ti[u] + a, w = 2 * tj[u] + e;
+        if (!tok[u] || h >= H || w >= W) continue;
+        const size_t off = (((size_t)tb[u] * H + h) * W + w) * Cout + co;
+        *reinterpret_cast<f32x4*>(y + off) = o;
+        if (EPI == 0 && want) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float dv = o[k] - piv[k]; s1[k] += dv; s2[k] = fmaf(dv, dv, s2[k]); }
+            cnt += 1.0f;
+        }
+        if (EPI == 1) {
+            const f32x4 yr = *reinterpret_cast<const f32x4*>(epi.yref + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = fmaf(yr[k], bsc[k], bsh[k]) > 0.0f ? o[k] : 0.0f;
+                s1[k] += g;
+                s2[k] = fmaf(g, (yr[k] - bmu[k]) * bis[k], s2[k]);
+            }
+        }
+        if (EPI == 2) {
+            // o = dL/d(dropout(pool(relu(bn(yref))))) at pooled pixel (h, w) of the block BELOW: the arithmetic of
+            // wino_output_kernel<2> / conv3x3_halo_kernel's EPI == 2 (dropout undone with one hash per 4 channels, a = bn(yref), ReLU
+            // mask and first-maximum arg-max recomputed from the ph x 2 window)
+            f32x4 g = o;
+            if (epi.drop_p > 0.0f) {
+                const uint64_t grp = ((uint64_t)((unsigned)tb[u] * (unsigned)H + (unsigned)h) * (unsigned)W + (unsigned)w)
+                                     * (unsigned)(Cout >> 2) + (unsigned)(co >> 2);
+                const uint64_t bits = tag_keep4_bits(epi.seed, grp);
+                const float keep_scale = 1.0f / (1.0f - epi.drop_p);
+                const unsigned thr = tag_keep4_threshold(epi.drop_p);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = tag_keep4(bits, k, thr) ? g[k] * keep_scale : 0.0f;
+            }
+            const float* yw = epi.yref + (((size_t)tb[u] * epi.Hf + (size_t)h * epi.ph) * epi.Wf + 2 * w) * Cout + co;
+            f32x4 vw[4];
+            vw[0] = *reinterpret_cast<const f32x4*>(yw);
+            vw[1] = *reinterpret_cast<const f32x4*>(yw + Cout);
+            if (epi.ph == 2) {
+                vw[2] = *reinterpret_cast<const f32x4*>(yw + (size_t)epi.Wf * Cout);
+                vw[3] = *reinterpret_cast<const f32x4*>(yw + (size_t)epi.Wf * Cout + Cout);
+            } else { vw[2] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; vw[3] = vw[2]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a4[4];
+#pragma unroll
+                for (int u2 = 0; u2 < 4; ++u2) a4[u2] = fmaf(vw[u2][k], bsc[k], bsh[k]);
+                if (epi.ph != 2) { a4[2] = -INFINITY; a4[3] = -INFINITY; }
+                const float mx = fmaxf(fmaxf(a4[0], a4[1]), fmaxf(a4[2], a4[3]));
+                const float gw = g[k] * epi.wavg, gwm = g[k] * (epi.wavg + epi.wmax);
+                bool found = false;
+#pragma unroll
+                for (int u2 = 0; u2 < 4; ++u2) {
+                    const bool eq = a4[u2] == mx;
+                    const bool hit = eq && !found;
+                    found = found || eq;
+                    const float dz = a4[u2] > 0.0f ? (hit ? gwm : gw) : 0.0f;
+                    s1[k] += dz;
+                    s2[k] = fmaf(dz, (vw[u2][k] - bmu[k]) * bis[k], s2[k]);
+                }
+            }
+        }
+    }
+    if (!want) return;
+    // ---- fold the 32 slots in a fixed order: ONE partial row per tile block
+    float* red = smem + FPARK;
+    *reinterpret_cast<f32x4*>(red + (slot * 16 + cq) * 8) = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+    *reinterpret_cast<f32x4*>(red + (slot * 16 + cq) * 8 + 4) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+    if (EPI == 0 && cq == 0) red[32 * 16 * 8 + slot] = cnt;
+    __syncthreads();
+    const int P = m_tiles;
+    if (tid < 128) {
+        float a = 0.0f;
+        for (int sl = 0; sl < 32; ++sl) a += red[sl * 128 + tid];
+        const int c = n0 + 4 * (tid >> 3) + (tid & 3), which = (tid >> 2) & 1;
+        if (EPI == 0) stats[((size_t)mt * 3 + 1 + which) * Cout + c] = a;
+        else stats[((size_t)mt * 2 + which) * Cout + c] = a;
+    }
+    if (EPI == 0) {
+        if (slot == 0) *reinterpret_cast<f32x4*>(stats + (size_t)mt * 3 * Cout + co) = piv;
+        if (tid == 128 && nt == 0) {
+            float a = 0.0f;
+            for (int sl = 0; sl < 32; ++sl) a += red[32 * 16 * 8 + sl];
+            stats[(size_t)P * 3 * Cout + mt] = a;
+        }
+    }
+}
+
+template <int PRO, int EPI>
+void launch_fused(const float* x, const float* U, const float* s, const float* t, float* y, float* stats, const WinoEpi& epi, int B,
+                  int H, int W, int Cin, int Cout, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_fused_kernel<PRO, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FLDS * (int)sizeof(float));
+        attr_set = true;
+    }
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long T = (long)B * th * tw;
+    const int m_tiles = (int)((T + 63) / 64), n_tiles = Cout / 64;
+    hipLaunchKernelGGL((wino_fused_kernel<PRO, EPI>), dim3(m_tiles * n_tiles), dim3(512), FLDS * sizeof(float), st, x, U, s, t, y, stats,
+                       epi, B, H, W, Cin, Cout, th, tw, T, m_tiles, n_tiles);
+}
+
+}  // namespace
+
+bool wino_fused_ok(int Cin, int Cout) { return Cin >= 8 && Cin % 8 == 0 && Cin <= 1024 && Cout >= 64 && Cout % 64 == 0; }
+
+int wino_fused_rows(int B, int H, int W) {
+    const long T = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return (int)((T + 63) / 64);
+}
+
+int wino_fused_run(const float* x, const float* U, int pro, const float* s, const float* t, float* y, float* stats, const WinoEpi* epi,
+                   int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+    const WinoEpi none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f, 0, 0, 0.0f, 0ull, 0};
+    const int kind = epi ? epi->kind : 0;
+    const WinoEpi& e = epi ? *epi : none;
+#define FUSED_CASE(P_, E_) launch_fused<P_, E_>(x, U, s, t, y, stats, e, B, H, W, Cin, Cout, st); return 0
+    if (kind == 0) {
+        switch (pro) { case 0: FUSED_CASE(0, 0); case 1: FUSED_CASE(1, 0); case 2: FUSED_CASE(2, 0); default: FUSED_CASE(3, 0); }
+    }
+    if (kind == 3) {
+        switch (pro) { case 0: FUSED_CASE(0, 3); case 1: FUSED_CASE(1, 3); case 2: FUSED_CASE(2, 3); default: FUSED_CASE(3, 3); }
+    }
+    if (pro != 0) return -1;                      // the gradient launches have no producer prologue
+    if (kind == 1) { FUSED_CASE(0, 1); }
+    FUSED_CASE(0, 2);
+#undef FUSED_CASE
+}
+
+// (weight gradient: below, added with its own kernel)
+bool wino_fused_wgrad_ok(int, int) { return false; }
+size_t wino_fused_wgrad_ws_floats(int, int, int, int, int) { return 0; }
+int wino_fused_wgrad_run(const float*, int, const float*, const float*, const float*, float*, int, int, int, int, int, float*,
+                         hipStream_t) { return -1; }

@@ -52,8 +52,11 @@ __device__ __forceinline__ f32x4 wino_prologue(f32x4 v, int mode, f32x4 s, f32x4
 // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: Uf[xi][ci][co] from w[co][ci][ky][kx] (forward), and
 // Ud[xi][co][ci] from the tap-flipped filter w[co][ci][2-ky][2-kx] (dgrad: the transposed convolution as a convolution
 // from the Cout-channel gradient to the Cin-channel gradient).  One thread per (ci, co) pair.
+// tiled_f / tiled_d: the layout of the fused kernel (conv_wino_fused.hip) instead -- per (64-cout block, 8-channel K chunk) the
+// LDS image [xi][n 64][k 8] of that kernel as one contiguous 32 KB block: forward index ((((co >> 6) (Cin / 8) + (ci >> 3)) 16 + xi)
+// 64 + (co & 63)) 8 + (ci & 7); dgrad (K = co, N = ci) the same with the roles of ci and co exchanged.
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ Uf,
-                                                        float* __restrict__ Ud, int Cin, int Cout) {
+                                                        float* __restrict__ Ud, int Cin, int Cout, int tiled_f, int tiled_d) {
     const long n = (long)Cin * Cout;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const int co = (int)(e / Cin), ci = (int)(e % Cin);
@@ -78,11 +81,18 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
             for (int r = 0; r < 4; ++r) {
                 const float u0 = p[r][0], u1 = 0.5f * (p[r][0] + p[r][1] + p[r][2]), u2 = 0.5f * (p[r][0] - p[r][1] + p[r][2]),
                             u3 = p[r][2];
-                const size_t base = dir == 0 ? (size_t)ci * Cout + co : (size_t)co * Cin + ci;
-                U[(size_t)(4 * r + 0) * n + base] = u0;
-                U[(size_t)(4 * r + 1) * n + base] = u1;
-                U[(size_t)(4 * r + 2) * n + base] = u2;
-                U[(size_t)(4 * r + 3) * n + base] = u3;
+                size_t base = dir == 0 ? (size_t)ci * Cout + co : (size_t)co * Cin + ci, plane = (size_t)n;
+                if (dir == 0 && tiled_f) {
+                    base = ((size_t)((co >> 6) * (Cin >> 3) + (ci >> 3)) * 16 * 64 + (co & 63)) * 8 + (ci & 7);
+                    plane = 64 * 8;
+                } else if (dir == 1 && tiled_d) {
+                    base = ((size_t)((ci >> 6) * (Cout >> 3) + (co >> 3)) * 16 * 64 + (ci & 63)) * 8 + (co & 7);
+                    plane = 64 * 8;
+                }
+                U[(size_t)(4 * r + 0) * plane + base] = u0;
+                U[(size_t)(4 * r + 1) * plane + base] = u1;
+                U[(size_t)(4 * r + 2) * plane + base] = u2;
+                U[(size_t)(4 * r + 3) * plane + base] = u3;
             }
         }
     }
@@ -488,14 +498,15 @@ int wino_run(const float* x, const float* U, int pro, const float* s, const floa
 extern "C" int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout) {
     if (!(B > 0 && H > 0 && W > 0 && wino_channels_ok(Cin) && wino_channels_ok(Cout) && Cin % 32 == 0)) return 0;
     const WinoGeom g = wino_geom(B, H, W, Cout);
-    return g.T < (1L << 31) / 16 && (long)B * H * W < (1L << 31);
+    // (the fused kernel addresses a tensor with 32-bit byte offsets from a scalar base)
+    return g.T < (1L << 31) / 16 && (long)B * H * W < (1L << 31) && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 30);
 }
 
 extern "C" int tag_pack_conv_weight_wino(const float* w, float* ufwd, float* udgrad, int Cin, int Cout, void* stream) {
     TAG_CHECK_ARG(w && (ufwd || udgrad) && Cin > 0 && Cout > 0);
     const long n = (long)Cin * Cout;
     hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, ufwd,
-                       udgrad, Cin, Cout);
+                       udgrad, Cin, Cout, wino_fused_ok(Cin, Cout) ? 1 : 0, wino_fused_ok(Cout, Cin) ? 1 : 0);
     TAG_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,10 @@
 // (slice, xi half) are folded in a fixed order by wino_fused_wgrad_finish_kernel.
 #include "conv_wino.h"
 
+#ifndef TAG_WF_ABL
+#define TAG_WF_ABL 0        // ablation builds (tools/wino_fused_abl.sh; results wrong by construction): bit 0 no x loads in the K loop,
+#endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier
+
 namespace {
 
 constexpr int FPL = 64 * 8 + 8;               // floats per xi plane of an operand buffer (2080 B: planes rotate by 32 B mod 128)
@@ -75,9 +79,9 @@ __device__ __forceinline__ void fused_out_quad(const f32x16 (&acc)[8], int rq, f
             else { p0[s][k] = m0; p1[s][k] = -m0 - m1; }                 // rows r = 2, 3
         }
     o[0] = p0[0] + p0[1] + p0[2];
-    o[1] = p0[1] - p0[2] - p0[3];
+    o[1] = p0[1] - p0[2] + p0[3];            // (column 3 of V is stored negated: p[3] = -(A^T m)[.][3])
     o[2] = p1[0] + p1[1] + p1[2];
-    o[3] = p1[1] - p1[2] - p1[3];
+    o[3] = p1[1] - p1[2] + p1[3];
 }
 
 template <int PRO, int EPI>
@@ -100,11 +104,17 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     const int n0 = nt * 64;
     const int nch = Cin >> 3;
 
-    // ---- V staging role: (tile tl, channel quad q of the chunk, window column s)
+    // ---- V staging role: (tile tl, channel quad q of the chunk, window column s).  Buffer loads: descriptor + chunk offset in
+    // SGPRs, ONE 32-bit VGPR offset per window row that never changes (tools/coissue2_probe.hip: a global load with a 64-bit VGPR
+    // address costs the fp32 MFMA stream 24 clocks, the scalar-base form 7); rows outside the image get an offset beyond the
+    // descriptor's range and come back as zeros -- no mask arithmetic when there is no producer prologue.
     const int s = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
-    const float fa = s == 3 ? -1.0f : 1.0f, fb = (s & 1) ? 1.0f : -1.0f;     // V[r][s] = fa tt[r][s] + fb tt[r][{2,2,1,1}[s]]
-    const float* xp;
-    int xo[4];
+    // V[r][s] = tt[r][s] + fb tt[r][{2,2,1,1}[s]]; column s = 3 is stored NEGATED (tt3 - tt1: one fma per value for every lane), which
+    // negates the products M[r][3] exactly -- the output transform adds them instead of subtracting
+    const float fb = s == 1 ? 1.0f : -1.0f;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)B * H * W * Cin * 4), 0x00020000);
+    unsigned xo[4];
+    float okb[4];                                      // PRO == 1: upper clamp of the row (+inf inside the image, 0 outside)
     bool okr[4];
     {
         const long t = m0 + tl;
@@ -115,20 +125,24 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         const int i = (int)(bi % th), b = (int)(bi / th);
         const int w = 2 * j - 1 + s;
         const bool okw = okt && (unsigned)w < (unsigned)W;
-        xp = x + (size_t)b * H * W * Cin + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int h = 2 * i - 1 + r;
             okr[r] = okw && (unsigned)h < (unsigned)H;
-            xo[r] = okr[r] ? (h * W + w) * Cin : 0;
+            okb[r] = okr[r] ? INFINITY : 0.0f;
+            xo[r] = okr[r] ? (unsigned)(((((size_t)b * H + h) * W + w) * Cin + 4 * q) * sizeof(float)) : 0x80000000u;
         }
     }
     const int vw0 = s * FPL + tl * 8 + ((q ^ ((tl >> 3) & 1)) << 2);         // + 4 r FPL
 
-    // ---- U staging role: 4 x 4 block (k = 4 kq .. +3, n = 4 nq .. +3) of plane xu
-    const int kq = tid & 1, xu = ((tid >> 1) & 3) + 4 * (wave & 3), nq = ((tid >> 3) & 7) + 8 * (wave >> 2);
-    const float* up = U + ((size_t)xu * Cin + 4 * kq) * Cout + n0 + 4 * nq;
-    const int uw0 = xu * FPL + 32 * nq + ((kq ^ ((nq >> 1) & 1)) << 2);      // + 8 i for row n = 4 nq + i
+    // ---- U staging role.  U is packed per (cout block, chunk) as the LDS image itself, [xi][n 64][k 8] (wino_pack_fused_kernel): a
+    // thread copies pieces tid + 512 i of the 32 KB block: plane 4 i + (tid >> 7), row n = (tid & 127) >> 1, 16-byte slot tid & 1
+    // (the k quad that belongs there is slot ^ ((n >> 3) & 1)) -- coalesced loads, conflict-free stores, no arithmetic.
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)((size_t)16 * Cin * Cout * 4), 0x00020000);
+    const int un = (tid & 127) >> 1, uslot = tid & 1;
+    const unsigned uo0 = (unsigned)((((tid >> 7) * 64 + un) * 8 + ((uslot ^ ((un >> 3) & 1)) << 2)) * sizeof(float));   // + i * 4 planes
+    const int uw0 = (tid >> 7) * FPL + un * 8 + (uslot << 2);                                                            // + i * 4 FPL
+    const unsigned ublk = (unsigned)nt * (unsigned)nch;                     // block index of chunk 0
 
     // ---- MFMA role
     const int hh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
@@ -148,17 +162,13 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     f32x4 xr[4], ur[4];
-    auto load_x = [&](int c) {
-        const float* p = xp + c * 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xr[r] = *reinterpret_cast<const f32x4*>(p + xo[r]);
+    auto load_x = [&](int c, int r) {
+        xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[r], c * 32, 0));
     };
-    auto load_u = [&](int c) {
-        const float* p = up + (size_t)c * 8 * Cout;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ur[j] = *reinterpret_cast<const f32x4*>(p + (size_t)j * Cout);
+    auto load_u = [&](int c, int i) {
+        ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uo0 + i * (4 * 64 * 8 * 4), (ublk + c) * (16 * 64 * 8 * 4), 0));
     };
-    f32x4 d[4], tt[4];
+    f32x4 d[4], tt[4], vv;
     f32x4 psc = {1.0f, 1.0f, 1.0f, 1.0f}, psh = {0.0f, 0.0f, 0.0f, 0.0f};
     auto ld_ss = [&](int c) {
         if (PRO != 0) {
@@ -166,79 +176,115 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
             psh = *reinterpret_cast<const f32x4*>(smem + FSS + Cin + c * 8 + 4 * q);
         }
     };
-    auto xs_rows = [&](int r0) {                       // prologue + zero padding of window rows r0, r0 + 1
+    auto x_row = [&](int r) {                          // producer prologue + zero padding of window row r
+        if (TAG_WF_ABL & 4) return;
+        if (PRO == 0) {
+            d[r] = xr[r];                              // (rows outside the image were loaded as zeros)
+        } else if (PRO == 1) {
+            // relu(bn(x)) inside the image, 0 outside: the median of (bn(x), 0, +inf | 0) -- one operation for both
 #pragma unroll
-        for (int r = r0; r < r0 + 2; ++r) {
+            for (int k = 0; k < 4; ++k) d[r][k] = __builtin_amdgcn_fmed3f(fmaf(xr[r][k], psc[k], psh[k]), 0.0f, okb[r]);
+        } else {
             const f32x4 v = fused_prologue<PRO>(xr[r], psc, psh);
             d[r] = okr[r] ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
-    auto xs_cols = [&]() {                             // column transform (B^T d): the thread's window column
-        tt[0] = d[0] - d[2];
-        tt[1] = d[1] + d[2];
-        tt[2] = d[2] - d[1];
-        tt[3] = d[1] - d[3];
+    auto x_col = [&](int r) {                          // column transform (B^T d) of the thread's window column
+        if (TAG_WF_ABL & 4) return;
+        if (r == 0) tt[0] = d[0] - d[2];
+        if (r == 1) tt[1] = d[1] + d[2];
+        if (r == 2) tt[2] = d[2] - d[1];
+        if (r == 3) tt[3] = d[1] - d[3];
     };
-    auto xs_write = [&](float* Vb, int r0) {           // row transform (. B) across the quad + store, rows r0, r0 + 1
+    auto v_row = [&](int r) {                          // row transform (. B): one quad-permute exchange per value
+        if (TAG_WF_ABL & 4) return;
 #pragma unroll
-        for (int r = r0; r < r0 + 2; ++r) {
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), fa * tt[r][k]);
-            *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = v;
-        }
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
     };
-    auto us_write = [&](float* Ub, int i0) {           // rows n = 4 nq + i0, + 1 of the transposed block
-#pragma unroll
-        for (int i = i0; i < i0 + 2; ++i)
-            *reinterpret_cast<f32x4*>(Ub + uw0 + 8 * i) = (f32x4){ur[0][i], ur[1][i], ur[2][i], ur[3][i]};
+    auto v_write = [&](float* Vb, int r) {
+#if TAG_WF_ABL & 4
+        vv = xr[r];
+#endif
+#if TAG_WF_ABL & 8
+        asm volatile("" ::"v"(vv));
+#else
+        *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
+#endif
+    };
+    auto u_write = [&](float* Ub, int i) {
+#if TAG_WF_ABL & 8
+        asm volatile("" ::"v"(ur[i]));
+#else
+        *reinterpret_cast<f32x4*>(Ub + uw0 + 4 * i * FPL) = ur[i];
+#endif
+    };
+    auto lx = [&](int c, int r) {
+#if !(TAG_WF_ABL & 1)
+        load_x(c, r);
+#endif
+    };
+    auto lu = [&](int c, int j) {
+#if !(TAG_WF_ABL & 2)
+        load_u(c, j);
+#endif
     };
 
     // ---- prologue of the pipeline: chunk 0 into buffer 0, chunk 1 into the registers
-    load_x(0);
-    load_u(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { load_x(0, r); load_u(0, r); }
     __syncthreads();
     ld_ss(0);
-    xs_rows(0); xs_rows(2); xs_cols();
-    xs_write(smem, 0); xs_write(smem, 2);
-    us_write(smem + FBUF, 0); us_write(smem + FBUF, 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x_row(r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x_col(r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v_row(r); v_write(smem, r); u_write(smem + FBUF, r); }
     {
         const int c1 = nch > 1 ? 1 : 0;
-        load_x(c1);
-        load_u(c1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { load_x(c1, r); load_u(c1, r); }
         ld_ss(c1);
     }
     __syncthreads();
 
+    // ---- K loop.  A chunk is 8 MFMA groups M_j (4 dependent MFMAs into accumulator set j, back to back) and 8 staging slices S_j
+    // (chunk c + 1 from the registers into the other buffer, loads of chunk c + 2), one barrier.  On gfx950 NOTHING of the
+    // staging hides behind an fp32 MFMA -- v_mfma_f32_32x32x2_f32 runs at the vector rate and streams its 16 accumulator registers
+    // through the register file on every instruction; tools/coissue2_probe.hip: beside it every VALU operation costs ~3 clocks of
+    // matrix time, a ds_write_b128 ~8, a scalar-base load ~7 (a 64-bit-address load 24, LDS-DMA 14-80), an LDS read ~1, in EVERY
+    // order (fillers between groups, behind every MFMA, the two waves of a SIMD in complementary phases) -- so the loop is built
+    // for the fewest instructions, not for overlap: bare MFMA loop 1.95 ms, staging +0.85 ms (round-6 first form) for the
+    // 512 -> 512 layer.
+    f32x4 afP, bfP, afQ, bfQ;
+#define WF_M4(J, A_, B_)                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[e], B_[e], acc[J], 0, 0, 0)
+#define WF_FRAG(A_, B_, J)                                                                                   \
+    A_ = *reinterpret_cast<const f32x4*>(cur + aoff + (J) * FPL);                                            \
+    B_ = *reinterpret_cast<const f32x4*>(cur + boff + (J) * FPL)
+#define WF_SB __builtin_amdgcn_sched_barrier(0)
     for (int c = 0; c < nch; ++c) {
         const float* cur = smem + (c & 1) * 2 * FBUF;
         float* nxt = smem + ((c + 1) & 1) * 2 * FBUF;
         const int c2 = c + 2 < nch ? c + 2 : nch - 1;
-        f32x4 af[2], bf[2];
-        af[0] = *reinterpret_cast<const f32x4*>(cur + aoff);
-        bf[0] = *reinterpret_cast<const f32x4*>(cur + boff);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            if (jj + 1 < 8) {
-                af[(jj + 1) & 1] = *reinterpret_cast<const f32x4*>(cur + aoff + (jj + 1) * FPL);
-                bf[(jj + 1) & 1] = *reinterpret_cast<const f32x4*>(cur + boff + (jj + 1) * FPL);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj & 1][e], bf[jj & 1][e], acc[jj], 0, 0, 0);
-            // staging slices of chunk c + 1 (in the registers since the previous iteration) and the loads of chunk c + 2
-            if (jj == 0) xs_rows(0);
-            if (jj == 1) { xs_rows(2); xs_cols(); }
-            if (jj == 2) xs_write(nxt, 0);
-            if (jj == 3) { xs_write(nxt, 2); load_x(c2); }
-            if (jj == 4) us_write(nxt + FBUF, 0);
-            if (jj == 5) { us_write(nxt + FBUF, 2); load_u(c2); }
-            if (jj == 6) ld_ss(c2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        WF_SB;
+        WF_FRAG(afP, bfP, 0); WF_SB;
+        WF_FRAG(afQ, bfQ, 1); WF_M4(0, afP, bfP); WF_SB; x_row(0); x_row(1); WF_SB;
+        WF_FRAG(afP, bfP, 2); WF_M4(1, afQ, bfQ); WF_SB; x_row(2); x_row(3); x_col(0); x_col(1); x_col(2); x_col(3); WF_SB;
+        WF_FRAG(afQ, bfQ, 3); WF_M4(2, afP, bfP); WF_SB; v_row(0); v_write(nxt, 0); v_row(1); v_write(nxt, 1); lx(c2, 0); lx(c2, 1); WF_SB;
+        WF_FRAG(afP, bfP, 4); WF_M4(3, afQ, bfQ); WF_SB; v_row(2); v_write(nxt, 2); v_row(3); v_write(nxt, 3); lx(c2, 2); lx(c2, 3); WF_SB;
+        WF_FRAG(afQ, bfQ, 5); WF_M4(4, afP, bfP); WF_SB; u_write(nxt + FBUF, 0); u_write(nxt + FBUF, 1); lu(c2, 0); lu(c2, 1); WF_SB;
+        WF_FRAG(afP, bfP, 6); WF_M4(5, afQ, bfQ); WF_SB; u_write(nxt + FBUF, 2); u_write(nxt + FBUF, 3); lu(c2, 2); lu(c2, 3); WF_SB;
+        WF_FRAG(afQ, bfQ, 7); WF_M4(6, afP, bfP); WF_SB; ld_ss(c2); WF_SB;
+        WF_M4(7, afQ, bfQ); WF_SB;
+#if !(TAG_WF_ABL & 16)
         __syncthreads();
+#endif
     }
+#undef WF_M4
+#undef WF_FRAG
+#undef WF_SB
 
     // ---- output transform: each wave parks its share of the 2 x 2 outputs  [half][pixel 2a+e][tile][cout]
     {

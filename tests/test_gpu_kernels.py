@@ -33,6 +33,13 @@ def ops(dev):
     return _ops
 
 
+@pytest.fixture(autouse=True)
+def _direct_kernels_only(ops, monkeypatch):
+    """This file tests the DIRECT convolution kernels (csrc/conv.hip & co.) through the ops-level entry points; the Winograd
+    kernels that take the same launches above ops.WINO_MIN_WORK have their own file (tests/test_gpu_wino.py)."""
+    monkeypatch.setattr(ops, "CONV_WINOGRAD", False)
+
+
 # ------------------------------------------------------------------------------------------- frontend
 @pytest.mark.parametrize("kind", ["cnn8rnn", "crnn"])
 def test_logmel_vs_oracle(ops, dev, kind):

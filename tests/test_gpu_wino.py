@@ -54,7 +54,10 @@ SHAPES = [(2, 10, 8, 64, 128, 1),      # whole tiles, 40-tile launch: ragged GEM
           (3, 9, 7, 128, 64, 0),       # odd height AND width: the last tile row / column hangs over the image
           (1, 1, 2, 32, 32, 3),        # a single tile row of one-pixel height
           (2, 37, 16, 256, 256, 2),    # the 1.5 s fixture's block-3 geometry
-          (8, 64, 8, 512, 256, 1)]     # 1024 tiles = whole 128-row GEMM tiles (the loader without tail handling)
+          (8, 64, 8, 512, 256, 1),     # 1024 tiles = whole 128-row GEMM tiles (the loader without tail handling)
+          (2, 33, 32, 64, 128, 1),     # block 2's first conv (32-wide image, odd height), fused kernels (round 6)
+          (1, 21, 64, 64, 64, 0),      # block 1's second conv (64-wide image, one 64-cout block)
+          (3, 10, 16, 128, 192, 1)]    # 192 couts = three 64-cout blocks; 120 tiles: a ragged last tile block
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES)
@@ -153,7 +156,7 @@ def test_wino_wgrad(ops, dev, B, H, W, Cin, Cout, pro):
     assert torch.equal(dw, dw2)                   # fixed summation order: bit-reproducible
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES[1:] + [(2, 11, 8, 64, 64, 1)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pro", SHAPES[1:-1] + [(2, 11, 8, 64, 64, 1)])     # (the two-pass reference takes C | 256)
 @pytest.mark.parametrize("ph,pool", [(2, 0), (1, 0), (2, 2), (1, 3)])
 def test_wino_forward_bnrelu_pool_eval(ops, dev, B, H, W, Cin, Cout, pro, ph, pool):
     """tag_conv3x3_wino_forward_bnrelu_pool_eval (inference: the output transform pools its own tile) against the fp64 chain
@@ -221,45 +224,69 @@ def test_wino_dgrad_pool_backward_sums(ops, dev, B, Hf, Wf, Cin, C, ph, train, p
     dy2, dg2, db2 = ops.bnrelu_pool_backward(yh, st, gd, dx, ph, pw, p, seed)
     assert relerr(dg, dg2) < 2e-6 and relerr(db, db2) < 2e-6
     assert torch.equal(dy, dy2) if not train else relerr(dy, dy2) < 2e-6
+    # ... and against an fp64 reduction over the kernel's OWN dx (round 6; not another HIP kernel): dz = the gradient reaching
+    # a = relu(bn(y)) through dropout and avg + max pool, with the mask from the exact y * scale + shift (an fp64 product of fp32
+    # factors is exact, so its sign is the kernels' fmaf's) and the FIRST maximum of each window; dbeta = sum dz, dgamma = sum dz xhat
+    sc, sh = st.scale.double().cpu().view(1, C, 1, 1), st.shift.double().cpu().view(1, C, 1, 1)
+    mu, isd = st.mean.double().cpu().view(1, C, 1, 1), st.invstd.double().cpu().view(1, C, 1, 1)
+    y64 = y.double()
+    a = (y64.float().double() * sc + sh)[:, :, :H * ph, :W * pw]
+    gp = nchw(dx).double().cpu()
+    if p > 0:
+        keep = ops.dropout_mask(seed, (B, H, W, C), p, dev, pooled=True).cpu().permute(0, 3, 1, 2).double()
+        gp = gp * keep * float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))
+    win = a.reshape(B, C, H, ph, W, pw).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H, W, ph * pw)
+    first = torch.zeros_like(win)
+    first.scatter_(-1, torch.relu(win.float()).argmax(-1, keepdim=True), 1.0)
+    dz = (win > 0) * (gp.unsqueeze(-1) * (1.0 / (ph * pw)) + gp.unsqueeze(-1) * first)
+    xh = ((y64.float().double() - mu) * isd)[:, :, :H * ph, :W * pw].reshape(B, C, H, ph, W, pw).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H, W, ph * pw)
+    db64, dg64 = dz.sum(dim=(0, 2, 3, 4)), (dz * xh).sum(dim=(0, 2, 3, 4))
+    norm = max(db64.abs().max().item(), dg64.abs().max().item())
+    e_b, e_g = (db.double().cpu() - db64).abs().max().item() / norm, (dg.double().cpu() - dg64).abs().max().item() / norm
+    print(f"wino pool sums {B}x{Hf}x{Wf} {C}<-{Cin} window {ph}x2 train={train} p={p}: vs fp64 dbeta {e_b:.1e} dgamma {e_g:.1e}")
+    assert e_b < 5e-6 and e_g < 5e-6
 
 
-def test_wino_wgrad_reuses_the_forward_planes(ops, dev, monkeypatch):
-    """A training forward launch leaves its transformed input on the input tensor (ops.WINO_KEEP_V); the weight gradient of the same
-    convolution multiplies those planes instead of transforming x again: bit-identical dw, the planes released after one use, and
-    a different prologue / different BatchNorm tensors do NOT take them."""
-    B, H, W, C = 8, 64, 8, 256                    # 1024 tiles, 2 K slices of 512: no padding rows
+def test_plane_form_wgrad_reuses_the_forward_planes(ops, dev):
+    """Channel counts the fused kernels do not take (Cout % 64 != 0) keep round 5's plane form: its forward launch can leave the
+    transformed input in a caller's buffer (v_keep) and the weight gradient multiplies those planes (v_saved) instead of
+    transforming x again -- bit-identical dw.  The fused shapes report that they have no planes to keep."""
+    B, H, W, C = 8, 64, 8, 32                     # 1024 tiles
     g = torch.Generator().manual_seed(9)
     x = torch.randn(B, H, W, C, generator=g).to(dev)
     dy = torch.randn(B, H, W, C, generator=g).to(dev)
     w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
     s, t = (torch.rand(C, generator=g) + 0.5).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
-    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1024)
     assert ops.query("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, C, C) == 1
-    wf, _ = ops.pack_conv_weight(w, W=W)
-    monkeypatch.setattr(ops, "WINO_KEEP_V", False)
-    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
-    assert not hasattr(x, "_wino_v")
-    dw_plain = ops.conv3x3_wgrad(x, dy, prologue=1, scale=s, shift=t)
-    monkeypatch.setattr(ops, "WINO_KEEP_V", True)
-    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
-    assert hasattr(x, "_wino_v")
-    dw_other = ops.conv3x3_wgrad(x, dy, prologue=0)              # another prologue: the planes do not apply (and are dropped)
-    assert not hasattr(x, "_wino_v")
-    ops.conv3x3_stats(x, wf, C, prologue=1, scale=s, shift=t)
-    dw_kept = ops.conv3x3_wgrad(x, dy, prologue=1, scale=s, shift=t)
-    assert not hasattr(x, "_wino_v")
-    assert torch.equal(dw_kept, dw_plain) and not torch.equal(dw_other, dw_plain)
+    assert ops.query("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, 256, 256) == 0
+    uf, _ = wino_pack(ops, w)
+    T = B * (H // 2) * (W // 2)
+    vkeep = torch.empty(16 * T * C, device=dev)
+    y = torch.empty(B, H, W, C, device=dev)
+    ws = torch.empty(ops.query("tag_conv3x3_wino_ws_bytes", B, H, W, C, C) // 4, device=dev)
+    ops.call("tag_conv3x3_wino_forward", ops.ptr(x), ops.ptr(uf), 1, ops.ptr(s), ops.ptr(t), ops.ptr(y), None, B, H, W, C, C,
+             ops.ptr(ws), ops.ptr(vkeep))
+    wsw = torch.empty(ops.query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, C, C) // 4, device=dev)
+    dw_plain, dw_kept = torch.empty(C, C, 3, 3, device=dev), torch.empty(C, C, 3, 3, device=dev)
+    ops.call("tag_conv3x3_wino_wgrad", ops.ptr(x), 1, ops.ptr(s), ops.ptr(t), ops.ptr(dy), ops.ptr(dw_plain), B, H, W, C, C,
+             ops.ptr(wsw), None)
+    ops.call("tag_conv3x3_wino_wgrad", None, 1, ops.ptr(s), ops.ptr(t), ops.ptr(dy), ops.ptr(dw_kept), B, H, W, C, C,
+             ops.ptr(wsw), ops.ptr(vkeep))
+    assert torch.equal(dw_kept, dw_plain)
+    ref = F.conv2d(torch.relu(nchw(x).double() * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1)).transpose(0, 1),
+                   nchw(dy).double().transpose(0, 1), padding=1).transpose(0, 1)
+    assert relerr(dw_plain, ref) < 1e-5
 
 
 def test_wino_dispatch_rule(ops, dev, monkeypatch):
-    """ops.conv3x3_stats / conv3x3_dgrad_bnrelu_backward take the Winograd form exactly for fp32 training launches on 8- / 16-wide
-    images with both channel counts >= WINO_MIN_C and at least WINO_MIN_TILES tiles; everything else keeps the direct kernel; the
+    """ops.conv3x3_stats / conv3x3_dgrad_bnrelu_backward take the Winograd form exactly for fp32 training launches on 8- ... 64-wide
+    images with both channel counts >= WINO_MIN_C and at least WINO_MIN_WORK tiles x output channels; everything else keeps the direct kernel; the
     two forms agree to both kernels' rounding, and a run is bit-reproducible."""
     B, H, W, C = 4, 64, 16, 256                   # 1024 tiles
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, H, W, C, generator=g).to(dev)
     w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
-    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1024)
+    monkeypatch.setattr(ops, "WINO_MIN_WORK", 1024 * 256)
     wf, wd = ops.pack_conv_weight(w, W=W)
     assert hasattr(wf, "wino_u") and hasattr(wd, "wino_u")
     n0 = ops.WINO_LAUNCHES
@@ -268,7 +295,7 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     assert ops.WINO_LAUNCHES == n0 + 2 and torch.equal(y_w, y_w2)
     y_e = ops.conv3x3(x, wf, C)                   # no statistics wanted (inference): direct
     assert ops.WINO_LAUNCHES == n0 + 2
-    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1025)
+    monkeypatch.setattr(ops, "WINO_MIN_WORK", 1024 * 256 + 1)
     y_d, part_d = ops.conv3x3_stats(x, wf, C)
     assert ops.WINO_LAUNCHES == n0 + 2 and torch.equal(y_d, y_e)
     assert relerr(y_w, y_d) < 5e-6
@@ -276,7 +303,7 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     dyv = torch.randn(B, H, W, C, generator=g).to(dev)
     dw_d = ops.conv3x3_wgrad(x, dyv)
     assert ops.WINO_LAUNCHES == n0 + 2
-    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINO_MIN_WORK", 1)
     dw_w = ops.conv3x3_wgrad(x, dyv)
     assert ops.WINO_LAUNCHES == n0 + 3 and relerr(dw_w, dw_d) < 1e-5
     monkeypatch.setattr(ops, "CONV_WINOGRAD", False)
@@ -284,9 +311,11 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     ops.conv3x3_wgrad(x, dyv)
     assert ops.WINO_LAUNCHES == n0 + 3
     monkeypatch.setattr(ops, "CONV_WINOGRAD", True)
-    wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 -> 128: the larger count is below WINO_MIN_CMAX
-    assert not hasattr(wf64, "wino_u")
-    wf12, _ = ops.pack_conv_weight(w[:, :128].contiguous(), W=W)        # 128 -> 256: taken
-    assert hasattr(wf12, "wino_u")
-    wf32, _ = ops.pack_conv_weight(w, W=32)                              # 32-wide image: direct
-    assert not hasattr(wf32, "wino_u")
+    wf64, _ = ops.pack_conv_weight(w[:128, :128].contiguous(), W=W)     # 128 -> 128: taken since the fused kernels (round 6)
+    assert hasattr(wf64, "wino_u")
+    wf32, _ = ops.pack_conv_weight(w, W=32)                              # 32-wide image: taken
+    assert hasattr(wf32, "wino_u")
+    wf4, _ = ops.pack_conv_weight(w, W=4)                                # the 4-wide images of the CrnnEncoder: direct
+    assert not hasattr(wf4, "wino_u")
+    wfs, _ = ops.pack_conv_weight(w[:32, :32].contiguous(), W=W)         # 32 channels: direct
+    assert not hasattr(wfs, "wino_u")

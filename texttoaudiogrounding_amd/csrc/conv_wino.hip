@@ -496,10 +496,12 @@ int wino_run(const float* x, const float* U, int pro, const float* s, const floa
 }  // namespace
 
 extern "C" int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout) {
-    if (!(B > 0 && H > 0 && W > 0 && wino_channels_ok(Cin) && wino_channels_ok(Cout) && Cin % 32 == 0)) return 0;
+    // fused kernels (forward, dgrad and weight gradient all take the layer): channel counts that are multiples of 64; else the plane form
+    const bool fused = Cin % 64 == 0 && Cout % 64 == 0 && Cin >= 64 && Cout >= 64 && Cin <= 1024 && Cout <= 1024;
+    if (!(B > 0 && H > 0 && W > 0 && (fused || (wino_channels_ok(Cin) && wino_channels_ok(Cout) && Cin % 32 == 0)))) return 0;
     const WinoGeom g = wino_geom(B, H, W, Cout);
-    // (the fused kernel addresses a tensor with 32-bit byte offsets from a scalar base)
-    return g.T < (1L << 31) / 16 && (long)B * H * W < (1L << 31) && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 30);
+    // (the fused kernels address a tensor through a buffer descriptor: < 2^31 bytes; larger launches are cut by the caller)
+    return g.T < (1L << 31) / 16 && (long)B * H * W < (1L << 31) && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 29);
 }
 
 extern "C" int tag_pack_conv_weight_wino(const float* w, float* ufwd, float* udgrad, int Cin, int Cout, void* stream) {
@@ -512,13 +514,14 @@ extern "C" int tag_pack_conv_weight_wino(const float* w, float* ufwd, float* udg
 }
 
 extern "C" size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (wino_fused_ok(Cin > 0 ? Cin : 32, Cout)) return 64;          // the fused kernel has no planes
     const WinoGeom g = wino_geom(B, H, W, Cout);
     return (size_t)16 * g.T * ((size_t)Cin + Cout) * sizeof(float);
 }
 
 extern "C" int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout) {
-    if (!wino_channels_ok(Cout)) return 0;
-    if (wino_fused_ok(32, Cout)) return wino_fused_rows(B, H, W);      // (every Cin tag_conv3x3_wino_ok accepts is a multiple of 32)
+    if (wino_fused_ok(32, Cout)) return wino_fused_rows(B, H, W);
+    if (!wino_channels_ok(Cout)) return 0;      // (every Cin tag_conv3x3_wino_ok accepts is a multiple of 32)
     return wino_geom(B, H, W, Cout).P;
 }
 
@@ -540,11 +543,13 @@ extern "C" int tag_conv3x3_wino_dgrad_poolsums(const float* dy, const float* u, 
 }
 
 extern "C" size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (wino_fused_wgrad_ok(Cin, Cout)) return wino_fused_wgrad_ws_floats(B, H, W, Cin, Cout) * sizeof(float);
     const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
     return ((size_t)16 * g.Tpad * ((size_t)Cin + Cout) + (size_t)16 * g.S * Cin * Cout) * sizeof(float);
 }
 
 extern "C" int tag_conv3x3_wino_wgrad_can_reuse_v(int B, int H, int W, int Cin, int Cout) {
+    if (wino_fused_wgrad_ok(Cin, Cout)) return 0;        // the fused weight gradient transforms its operands at staging: no planes
     const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
     return g.Tpad == g.T;                      // the K slices need no zero rows: the forward's planes are the operand as they are
 }
@@ -556,6 +561,11 @@ extern "C" int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float*
     TAG_CHECK_ARG(v_saved == nullptr || tag_conv3x3_wino_wgrad_can_reuse_v(B, H, W, Cin, Cout));
     TAG_CHECK_ARG(prologue >= 0 && prologue <= 3 && (prologue == 0 || (in_scale && in_shift)));
     hipStream_t st = as_stream(stream);
+    if (wino_fused_wgrad_ok(Cin, Cout) && x) {
+        wino_fused_wgrad_run(x, prologue, in_scale, in_shift, dy, dw, B, H, W, Cin, Cout, static_cast<float*>(ws), st);
+        TAG_LAUNCH_CHECK();
+        return 0;
+    }
     const WinoWgGeom g = wino_wg_geom(B, H, W, Cin, Cout);
     // v_saved: B^T prologue(x) B as the forward launch of this convolution left it (tag_conv3x3_wino_forward, v_keep): the input
     // transform (0.12-0.27 ms per layer at B = 64) is not repeated; ws then starts with the gradient planes

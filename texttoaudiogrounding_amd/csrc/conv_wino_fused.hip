@@ -478,6 +478,235 @@ void launch_fused(const float* x, const float* U, const float* s, const float* t
                        epi, B, H, W, Cin, Cout, th, tw, T, m_tiles, n_tiles);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  dU_xi (Cin x Cout) = sum over tiles V_xi[t][ci] D_xi[t][co],  V = B^T d B of the (prologued) input window,
+// D = A dY A^T of the 2 x 2 gradient tile, dw = G^T dU G -- the arithmetic of wino_input_kernel / wino_dy_kernel /
+// wino_wgrad_finish_kernel with BOTH transforms formed at staging and the 16 dU_xi kept in registers.  A workgroup owns 64 ci x
+// 64 co x 16 xi over ONE slice of the tile axis (K chunks of 8 tiles; S slices so that the launch is one workgroup per CU);
+// wave (h, wm, wn) = xi half, 32 ci x 32 co.  A wave stages ONE tile per chunk (lane = channel quad x window column s), so the
+// tile geometry -- image, tile row / column, row validity, row offsets -- is wave-uniform and lives on the scalar unit, advanced
+// by 8 tiles per chunk without a division; only the column validity needs a vector compare.  LDS images are k-major,
+// [xi][tile 8][channel 64] (16-byte stores from the channel-quad threads; fragments are four ds_read_b32 per operand and group
+// instead of one ds_read_b128 -- reads cost the MFMA stream ~1 clock each, a transposing store would be 32-bit LDS writes, the
+// one form that waits for gaps in the matrix pipe).  Column 3 of both V and D is stored negated (their product is unchanged).
+// Each wave folds its 8 sets to its share of the 3 x 3 filter and writes it to part[slice][half][co][ci][9];
+// wino_fused_wgrad_finish_kernel adds the 2 S shares in a fixed order.
+struct WgGeom { int th, tw; long T; int nci, nco, S, cps; };
+inline WgGeom wg_geom(int B, int H, int W, int Cin, int Cout) {
+    WgGeom g;
+    g.th = (H + 1) / 2; g.tw = (W + 1) / 2;
+    g.T = (long)B * g.th * g.tw;
+    g.nci = Cin / 64; g.nco = Cout / 64;
+    const long chunks = (g.T + 7) / 8;
+    long S = 256 / ((long)g.nci * g.nco);
+    if (S < 1) S = 1;
+    if (S > chunks) S = chunks;
+    const long cps = (chunks + S - 1) / S;
+    g.cps = (int)cps;
+    g.S = (int)((chunks + cps - 1) / cps);
+    return g;
+}
+
+__device__ __forceinline__ float dpp_quad_0033(float v) {       // lane s of a quad receives the value of lane {0, 0, 3, 3}[s]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF0, 0xF, 0xF, true));
+}
+
+template <int PRO>
+__global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                               const float* __restrict__ in_shift, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int B, int H, int W, int Cin, int Cout,
+                                                               int th, int tw, int nci, int nco, int S, int cps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int sl, cib, cob;
+    {
+        const int per = nci * nco;
+        const int L = xcd_remap(blockIdx.x, per * S);
+        sl = L / per;
+        const int rem = L - sl * per;
+        cib = rem / nco;
+        cob = rem - cib * nco;
+    }
+    // ---- staging role: tile = wave (8 tiles per chunk), lane = (channel quad, window column s)
+    const int s = tid & 3, quad = (tid >> 2) & 15;
+    const float fb = s == 1 ? 1.0f : -1.0f;                       // V[r][s] = tt[r][s] + fb tt[r][{2,2,1,1}[s]]  (column 3 negated)
+    const float cb = s == 1 ? 1.0f : (s == 2 ? -1.0f : 0.0f);     // D[r][s] = R[r][s & 1] + cb R[r][{0,0,3,3}[s] & 1] (column 3 negated)
+    // descriptors: x one pixel early, so that the window column 2 j - 1 of a tile is a non-negative offset from (row, 2 j)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - Cin, 0, (int)(((size_t)B * H * W + 1) * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)((size_t)B * H * W * Cout * 4), 0x00020000);
+    const unsigned xvo = (unsigned)((s * Cin + cib * 64 + 4 * quad) * 4);
+    const unsigned dvo = (unsigned)(((s & 1) * Cout + cob * 64 + 4 * quad) * 4);
+    const int vw0 = s * FPL + wave * 64 + 4 * quad;               // + 4 r FPL  (V image; the D image is FBUF further)
+    // tile of this wave in the chunk being LOADED (uniform): image b, tile row i, tile column j
+    int tb, ti, tj;
+    {
+        const long t = (long)sl * cps * 8 + wave;
+        tj = (int)(t % tw);
+        const long bi = t / tw;
+        ti = (int)(bi % th);
+        tb = (int)(bi / th);
+        tb = __builtin_amdgcn_readfirstlane(tb); ti = __builtin_amdgcn_readfirstlane(ti); tj = __builtin_amdgcn_readfirstlane(tj);
+    }
+    auto advance = [&]() {                            // + 8 tiles
+        tj += 8;
+        while (tj >= tw) { tj -= tw; ++ti; }
+        while (ti >= th) { ti -= th; ++tb; }
+    };
+    f32x4 psc = {1.0f, 1.0f, 1.0f, 1.0f}, psh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (PRO != 0) {
+        psc = *reinterpret_cast<const f32x4*>(in_scale + cib * 64 + 4 * quad);
+        psh = *reinterpret_cast<const f32x4*>(in_shift + cib * 64 + 4 * quad);
+    }
+
+    // ---- MFMA role
+    const int hh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kl = lane >> 5, ml = lane & 31;
+    const int aoff = 8 * hh * FPL + kl * 64 + wm * 32 + ml;             // V fragment (A operand: rows = ci); + xi FPL + 128 e
+    const int boff = FBUF + 8 * hh * FPL + kl * 64 + wn * 32 + ml;      // D fragment (B operand: columns = co)
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    f32x4 xr[4], gr[2];
+    float okn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, okc[4];   // PRO != 0: upper clamp (+inf | 0) of the rows in flight / being transformed
+    auto load_x = [&](int r) {                         // window row r of the tile (tb, ti, tj)
+        const int h = 2 * ti - 1 + r;
+        const bool rv = tb < B && (unsigned)h < (unsigned)H;
+        const bool ok = rv && (unsigned)(2 * tj - 1 + s) < (unsigned)W;
+        const int so = rv ? (int)((((size_t)tb * H + h) * W + 2 * tj) * Cin * 4) : 0;
+        xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xvo : 0x80000000u, so, 0));
+        if (PRO != 0) okn[r] = ok ? INFINITY : 0.0f;
+    };
+    auto load_g = [&](int a) {                         // gradient row 2 ti + a, column 2 tj + (s & 1)
+        const int h = 2 * ti + a;
+        const bool rv = tb < B && h < H;
+        const bool ok = rv && (2 * tj + (s & 1)) < W;
+        const int so = rv ? (int)((((size_t)tb * H + h) * W + 2 * tj) * Cout * 4) : 0;
+        gr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok ? dvo : 0x80000000u, so, 0));
+    };
+    f32x4 d[4], tt[4], R[4], vv;
+    auto x_row = [&](int r) {
+        if (PRO == 0) {
+            d[r] = xr[r];
+        } else if (PRO == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[r][k] = __builtin_amdgcn_fmed3f(fmaf(xr[r][k], psc[k], psh[k]), 0.0f, okc[r]);
+        } else {
+            const f32x4 v = fused_prologue<PRO>(xr[r], psc, psh);
+            d[r] = okc[r] > 0.0f ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto x_col = [&]() {
+        tt[0] = d[0] - d[2];
+        tt[1] = d[1] + d[2];
+        tt[2] = d[2] - d[1];
+        tt[3] = d[1] - d[3];
+    };
+    auto v_write = [&](float* Vb, int r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+        *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
+    };
+    auto g_rows = [&]() {                              // R = A g (the thread's gradient column)
+        R[0] = gr[0];
+        R[1] = gr[0] + gr[1];
+        R[2] = gr[0] - gr[1];
+        R[3] = -gr[1];
+    };
+    auto d_write = [&](float* Db, int r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(cb, dpp_quad_0033(R[r][k]), R[r][k]);
+        *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
+    };
+    auto rotate_ok = [&]() {
+        if (PRO != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) okc[r] = okn[r];
+        }
+    };
+
+    // ---- pipeline prologue: chunk 0 into buffer 0, chunk 1 into the registers
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_x(r);
+    load_g(0); load_g(1);
+    advance();
+    rotate_ok();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x_row(r);
+    x_col();
+    g_rows();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v_write(smem, r); d_write(smem + FBUF, r); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_x(r);
+    load_g(0); load_g(1);
+    advance();
+    __syncthreads();
+
+#define WG_M4(J)                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[aoff + (J) * FPL + 128 * e], cur[boff + (J) * FPL + 128 * e], acc[J], 0, 0, 0)
+#define WG_SB __builtin_amdgcn_sched_barrier(0)
+    for (int c = 0; c < cps; ++c) {
+        const float* cur = smem + (c & 1) * 2 * FBUF;
+        float* nxt = smem + ((c + 1) & 1) * 2 * FBUF;
+        WG_SB;
+        WG_M4(0); WG_SB; rotate_ok(); x_row(0); x_row(1); WG_SB;
+        WG_M4(1); WG_SB; x_row(2); x_row(3); x_col(); WG_SB;
+        WG_M4(2); WG_SB; v_write(nxt, 0); v_write(nxt, 1); load_x(0); load_x(1); WG_SB;
+        WG_M4(3); WG_SB; v_write(nxt, 2); v_write(nxt, 3); load_x(2); load_x(3); WG_SB;
+        WG_M4(4); WG_SB; g_rows(); d_write(nxt + FBUF, 0); d_write(nxt + FBUF, 1); WG_SB;
+        WG_M4(5); WG_SB; d_write(nxt + FBUF, 2); d_write(nxt + FBUF, 3); load_g(0); load_g(1); advance(); WG_SB;
+        WG_M4(6); WG_SB;
+        WG_M4(7); WG_SB;
+        __syncthreads();
+    }
+#undef WG_M4
+#undef WG_SB
+
+    // ---- dw share of this wave: G^T (rows of its xi half) . G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    float* pb = part + ((size_t)(sl * 2 + hh) * Cout + cob * 64 + wn * 32 + ml) * Cin * 9 + (size_t)(cib * 64 + wm * 32 + 4 * kl) * 9;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        float o[4][9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float P[3][4];
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const float m0 = acc[sx][4 * rq + k], m1 = acc[4 + sx][4 * rq + k];
+                if (hh == 0) { P[0][sx] = m0 + 0.5f * m1; P[1][sx] = 0.5f * m1; P[2][sx] = 0.5f * m1; }      // transform rows r = 0, 1
+                else { P[0][sx] = 0.5f * m0; P[1][sx] = -0.5f * m0; P[2][sx] = 0.5f * m0 + m1; }              // rows r = 2, 3
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float hs = 0.5f * (P[a][1] + P[a][2]), hd = 0.5f * (P[a][1] - P[a][2]);
+                o[k][3 * a + 0] = P[a][0] + hs;
+                o[k][3 * a + 1] = hd;
+                o[k][3 * a + 2] = hs + P[a][3];
+            }
+        }
+        float* q = pb + (size_t)(8 * rq) * 9;          // 4 consecutive ci x 9 taps = 36 floats
+        const float* of = &o[0][0];
+#pragma unroll
+        for (int v4 = 0; v4 < 9; ++v4) *reinterpret_cast<f32x4*>(q + 4 * v4) = (f32x4){of[4 * v4], of[4 * v4 + 1], of[4 * v4 + 2], of[4 * v4 + 3]};
+    }
+}
+
+// dw (Cout,Cin,3,3) = the 2 S shares added in a fixed order; one thread per 4 consecutive floats
+__global__ __launch_bounds__(256) void wino_fused_wgrad_finish_kernel(const float* __restrict__ part, int nshare, long n4, float* __restrict__ dw) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int p = 0; p < nshare; ++p) a += *reinterpret_cast<const f32x4*>(part + ((size_t)p * n4 + e) * 4);
+        *reinterpret_cast<f32x4*>(dw + e * 4) = a;
+    }
+}
+
 }  // namespace
 
 bool wino_fused_ok(int Cin, int Cout) { return Cin >= 8 && Cin % 8 == 0 && Cin <= 1024 && Cout >= 64 && Cout % 64 == 0; }
@@ -505,8 +734,37 @@ int wino_fused_run(const float* x, const float* U, int pro, const float* s, cons
 #undef FUSED_CASE
 }
 
-// (weight gradient: below, added with its own kernel)
-bool wino_fused_wgrad_ok(int, int) { return false; }
-size_t wino_fused_wgrad_ws_floats(int, int, int, int, int) { return 0; }
-int wino_fused_wgrad_run(const float*, int, const float*, const float*, const float*, float*, int, int, int, int, int, float*,
-                         hipStream_t) { return -1; }
+bool wino_fused_wgrad_ok(int Cin, int Cout) { return Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0; }
+
+size_t wino_fused_wgrad_ws_floats(int B, int H, int W, int Cin, int Cout) {
+    const WgGeom g = wg_geom(B, H, W, Cin, Cout);
+    return (size_t)2 * g.S * Cin * Cout * 9;
+}
+
+int wino_fused_wgrad_run(const float* x, int pro, const float* s, const float* t, const float* dy, float* dw, int B, int H, int W,
+                         int Cin, int Cout, float* ws, hipStream_t st) {
+    const WgGeom g = wg_geom(B, H, W, Cin, Cout);
+    const int grid = g.nci * g.nco * g.S;
+    const size_t lds = (size_t)4 * FBUF * sizeof(float);
+#define WG_CASE(P_)                                                                                                          \
+    {                                                                                                                        \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_fused_wgrad_kernel<P_>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+            attr_set = true;                                                                                                 \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((wino_fused_wgrad_kernel<P_>), dim3(grid), dim3(512), lds, st, x, s, t, dy, ws, B, H, W, Cin, Cout, g.th,  \
+                           g.tw, g.nci, g.nco, g.S, g.cps);                                                                  \
+    }
+    switch (pro) {
+        case 0: WG_CASE(0) break;
+        case 1: WG_CASE(1) break;
+        case 2: WG_CASE(2) break;
+        default: WG_CASE(3) break;
+    }
+#undef WG_CASE
+    const long n4 = (long)Cin * Cout * 9 / 4;
+    hipLaunchKernelGGL(wino_fused_wgrad_finish_kernel, dim3(cdiv(n4, 256) > 2048 ? 2048 : cdiv(n4, 256)), dim3(256), 0, st, ws, 2 * g.S, n4, dw);
+    return 0;
+}

@@ -356,32 +356,33 @@ def pack_conv_weight(w, want_dgrad=True, W=None):
 
 FUSE_BN_STATS = os.environ.get("TAG_FUSE_BN_STATS", "1") != "0"
 
-#: Winograd F(2x2,3x3) form (csrc/conv_wino.hip, all fp32) of the TRAINING forward (with fused BatchNorm statistics) and of the
-#: dgrad + BatchNorm-backward-sums launches of the deep layers: 2.25 x fewer MFMA FLOP than the direct halo-tile kernel, which
-#: runs at 0.86-0.88 of the fp32 MFMA peak.  Used where it was measured faster at B = 64 (tools/wino_bench.py): both channel
-#: counts >= WINO_MIN_C on the 8- / 16-wide images (Cnn8Rnn blocks 3 and 4: x1.13 ... x1.50 per launch).  "0" = direct kernels only.
+#: Winograd F(2x2,3x3) form of the 3x3 convolutions, all fp32 (csrc/conv_wino_fused.hip: ONE kernel per launch, the transforms inside
+#: the product kernel; round 5's plane form, csrc/conv_wino.hip, remains for channel counts the fused kernels do not take): forward
+#: (training: + BatchNorm statistics; inference: + BatchNorm / ReLU / pool), dgrad (+ BatchNorm-backward or pool-backward sums) and
+#: weight gradient.  2.25 x fewer MFMA FLOP than the direct halo-tile kernels; since round 6 faster on EVERY layer with >= 64
+#: channels on both sides (tools/wino_bench.py, B = 64: x1.5 ... x1.9 per launch).  "0" = direct kernels only.
 CONV_WINOGRAD = os.environ.get("TAG_CONV_WINOGRAD", "1") != "0"
-#: channel rule: the smaller count >= WINO_MIN_C and the larger >= WINO_MIN_CMAX (128 / 256: with the final product kernel the
-#: 128 <-> 256 convs of block 3 gain x1.11 ... x1.34 per launch too; 128 -> 128 on the 32-wide images does not: x0.90 ... x1.01)
-WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "128"))
-WINO_MIN_CMAX = int(os.environ.get("TAG_WINO_MIN_CMAX", "256"))
-#: ... and only on launches with at least this many 2 x 2 output tiles (B * ceil(H/2) * ceil(W/2); 8192 = batch 17 of 10 s clips in
-#: block 4): below that the 16 products are too short to fill the chip and the direct kernel keeps the launch
-WINO_MIN_TILES = int(os.environ.get("TAG_WINO_MIN_TILES", "8192"))
+#: channel rule: the smaller count >= WINO_MIN_C and the larger >= WINO_MIN_CMAX
+WINO_MIN_C = int(os.environ.get("TAG_WINO_MIN_C", "64"))
+WINO_MIN_CMAX = int(os.environ.get("TAG_WINO_MIN_CMAX", "64"))
+#: ... and only training launches of at least this much work, tiles x output channels (tiles = B * ceil(H/2) * ceil(W/2); 2^20 = one
+#: 64-tile x 64-cout workgroup of the fused kernel per CU): smaller launches cannot fill the chip with those blocks and keep the
+#: direct kernel.  (At B = 64 every layer is 30 ... 120 times above it; the 2-clip fixtures of the parity tests are below it and
+#: are ALSO run with the rule forced to 1 and the step's decisions imposed on the oracle: tests/test_gpu_path.py.)
+WINO_MIN_WORK = int(os.environ.get("TAG_WINO_MIN_WORK", str(1 << 20)))
 #: the inference forward (BatchNorm in eval mode, nothing saved) of the same layers as Winograd too, at EVERY launch size: the choice
 #: must not depend on the batch, or the same clip would score differently in a 4-clip and in a 64-clip pass (the forward is
-#: batch-invariant, tests/test_gpu_infer.py); batches are cut so that the transform planes stay under WINO_WS_MAX bytes
+#: batch-invariant, tests/test_gpu_infer.py)
 CONV_WINOGRAD_EVAL = os.environ.get("TAG_CONV_WINOGRAD_EVAL", "1") != "0"
-WINO_WS_MAX = int(os.environ.get("TAG_WINO_WS_MAX", str(4 << 30)))
-#: a training forward launch keeps its transformed input (16 T Cin floats) on the input tensor for the weight gradient of the same
-#: convolution: three input transforms per step less (0.67 ms at B = 64) for 2.6 GB more live memory
-WINO_KEEP_V = os.environ.get("TAG_WINO_KEEP_V", "1") != "0"
+#: the fused kernels address a tensor through a buffer descriptor (32-bit byte offsets): launches without per-batch sums are cut into
+#: batch slices below this many bytes per tensor (any cut gives the same rows: every tile is computed independently of the others)
+WINO_MAX_BYTES = int(os.environ.get("TAG_WINO_MAX_BYTES", str((1 << 31) - (1 << 20))))
 #: launches that took the Winograd path since import (tests assert that the benched-size step really runs through it)
 WINO_LAUNCHES = 0
 
 
 def _wino_shape(W, Cin, Cout) -> bool:
-    return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16) and min(Cin, Cout) >= WINO_MIN_C
+    return (CONV_WINOGRAD and CONV_MATH == "fp32" and W in (8, 16, 32, 64) and min(Cin, Cout) >= WINO_MIN_C
             and max(Cin, Cout) >= WINO_MIN_CMAX)
 
 
@@ -400,8 +401,8 @@ def _wino_u(wpack, x, Cout, count=True, any_size=False):
     B, H, W, Cin = x.shape
     if any_size and not CONV_WINOGRAD_EVAL:
         return None
-    if ((not any_size and B * ((H + 1) // 2) * ((W + 1) // 2) < WINO_MIN_TILES)
-            or not query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout)):
+    if ((not any_size and B * ((H + 1) // 2) * ((W + 1) // 2) * Cout < WINO_MIN_WORK)
+            or not query("tag_conv3x3_wino_ok", 1 if any_size else B, H, W, Cin, Cout)):     # (inference launches are cut by batch)
         return None
     if count:
         global WINO_LAUNCHES
@@ -414,16 +415,9 @@ def conv3x3(x, wpack, Cout, prologue=0, scale=None, shift=None, training_launch=
     return conv3x3_stats(x, wpack, Cout, prologue, scale, shift, want_stats=False, training_launch=training_launch)[0]
 
 
-def _batch_chunks(B, bytes_per_clip, tiles_per_clip=0):
-    """Batch slices [b0, b1) whose Winograd transform planes stay under WINO_WS_MAX (any cut gives the same rows: every tile is
-    transformed and multiplied independently of the others).  Among the sizes within a factor 2 of the largest that fits, one
-    whose tile count is a whole number of 128-row product tiles is preferred (the product kernel's loader without tail handling)."""
-    nb = max(1, min(B, WINO_WS_MAX // max(1, bytes_per_clip)))
-    if nb < B and tiles_per_clip > 0:
-        for cand in range(nb, max(1, nb // 2) - 1, -1):
-            if (cand * tiles_per_clip) % 128 == 0:
-                nb = cand
-                break
+def _batch_chunks(B, bytes_per_clip):
+    """Batch slices [b0, b1) whose tensors stay under WINO_MAX_BYTES (the fused Winograd kernels' descriptor range)."""
+    nb = max(1, min(B, WINO_MAX_BYTES // max(1, bytes_per_clip)))
     return [(b0, min(B, b0 + nb)) for b0 in range(0, B, nb)]
 
 
@@ -437,8 +431,8 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
     u = None
     if not x3 and inference and not want_stats:
         u = _wino_u(wpack, x, Cout, any_size=True)
-        if u is not None:                      # inference forward: batch cuts bound the workspace (30 s x 256 clips: 25 GB uncut)
-            for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout), ((H + 1) // 2) * ((W + 1) // 2)):
+        if u is not None:                      # inference forward: batch cuts keep every tensor inside the descriptor range
+            for b0, b1 in _batch_chunks(B, H * W * max(Cin, Cout) * 4):
                 ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
                 with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
                     call("tag_conv3x3_wino_forward", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y[b0:b1]), None,
@@ -450,16 +444,10 @@ def conv3x3_stats(x, wpack, Cout, prologue=0, scale=None, shift=None, want_stats
         if want_stats and FUSE_BN_STATS:
             P = query("tag_conv3x3_wino_stats_rows", B, H, W, Cout)
             part = (P, _empty(P * (3 * Cout + 1), like=x))
-        # a training forward keeps its transformed input for the weight gradient of the same convolution (conv3x3_wgrad finds it
-        # on the input tensor: same x, same prologue) -- 0.5-1 GB per layer at B = 64 instead of a second input transform
-        vkeep = None
-        if want_stats and WINO_KEEP_V and query("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, Cin, Cout):
-            vkeep = _empty(16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin, like=x)
-            x._wino_v = (vkeep, prologue, scale, shift)
-        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, 0 if vkeep is not None else Cin, Cout), x)
+        ws = _ws(query("tag_conv3x3_wino_ws_bytes", B, H, W, Cin, Cout), x)
         with _timed(("conv3x3_wino", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
             call("tag_conv3x3_wino_forward", ptr(x), ptr(u), prologue, ptr(scale), ptr(shift), ptr(y), ptr(part[1]) if part else None,
-                 B, H, W, Cin, Cout, ptr(ws), ptr(vkeep))
+                 B, H, W, Cin, Cout, ptr(ws), None)
         return y, part
     if want_stats and FUSE_BN_STATS:
         if x3 and x.dtype == BF16:
@@ -633,7 +621,7 @@ def conv3x3_bnrelu_pool_eval(x, wpack, Cout, st: BNStat, ph, pw, prologue=0, sca
     out = _empty(B, H // ph, W // pw, Cout, like=x)
     u = _wino_u(wpack, x, Cout, any_size=True)
     if u is not None:
-        for b0, b1 in _batch_chunks(B, query("tag_conv3x3_wino_ws_bytes", 1, H, W, Cin, Cout), ((H + 1) // 2) * ((W + 1) // 2)):
+        for b0, b1 in _batch_chunks(B, H * W * max(Cin, Cout) * 4):
             ws = _ws(query("tag_conv3x3_wino_ws_bytes", b1 - b0, H, W, Cin, Cout), x)
             with _timed(("conv3x3_wino", b1 - b0, H, W, Cin, Cout), _wino_flop(b1 - b0, H, W, Cin, Cout)):
                 call("tag_conv3x3_wino_forward_bnrelu_pool_eval", ptr(x[b0:b1]), ptr(u), prologue, ptr(scale), ptr(shift),
@@ -663,19 +651,14 @@ def conv3x3_wgrad(x, dy, prologue=0, scale=None, shift=None, out=None):
             call("tag_conv3x3_wgrad_x3", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout,
                  _X3_PRODUCTS[CONV_MATH], ptr(ws))
         return dw
-    if (x.dtype == F32 and dy.dtype == F32 and _wino_shape(W, Cin, Cout) and B * ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_TILES
-            and query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout)):
+    if (x.dtype == F32 and dy.dtype == F32 and _wino_shape(W, Cin, Cout)
+            and B * ((H + 1) // 2) * ((W + 1) // 2) * max(Cin, Cout) >= WINO_MIN_WORK and query("tag_conv3x3_wino_ok", B, H, W, Cin, Cout)):
         global WINO_LAUNCHES
         WINO_LAUNCHES += 1
         ws = _ws(query("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
-        kept = getattr(x, "_wino_v", None)        # (planes, prologue, scale, shift) left by this convolution's forward launch
-        v = kept[0] if (kept is not None and kept[1] == prologue and kept[2] is scale and kept[3] is shift
-                        and kept[0].numel() == 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cin) else None
         with _timed(("conv3x3_wino_wgrad", B, H, W, Cin, Cout), _wino_flop(B, H, W, Cin, Cout)):
             call("tag_conv3x3_wino_wgrad", ptr(x), prologue, ptr(scale), ptr(shift), ptr(dy), ptr(dw), B, H, W, Cin, Cout, ptr(ws),
-                 ptr(v))
-        if kept is not None:
-            del x._wino_v                         # one use: the planes are released with this launch
+                 None)
         return dw
     ws = _ws(query("tag_conv3x3_wgrad_ws_bytes", B, H, W, Cin, Cout), x)
     # profile family: the all-taps decomposition (conv3x3_wgrad_alltaps_kernel at W = 8 / 16, its row-ring form

@@ -91,6 +91,16 @@ def cpu_baseline(batch=16, iters=5):
                               "sample": f"same step, B=2, median of {iters} after 1 warm-up"}}
 
 
+#: profile family (ops._timed key) -> the kernels behind it, as a trace names them
+KERNEL_TEXT = {
+    "conv3x3_wino": "wino_fused_kernel<PRO,EPI> (Winograd F(2x2,3x3) forward and dgrad launches: transforms, 16 products and "
+                    "epilogue in one kernel; csrc/conv_wino_fused.hip)",
+    "conv3x3_wino_wgrad": "wino_fused_wgrad_kernel<PRO> + wino_fused_wgrad_finish_kernel (Winograd weight gradient)",
+    "conv3x3_halo_kernel": "conv3x3_halo_kernel<BN,PRO,TW,EPI> (direct MFMA convolution, forward and dgrad)",
+    "conv3x3_wgrad_alltaps_kernel": "conv3x3_wgrad_alltaps_kernel / conv3x3_wgrad_rowring_kernel (direct weight gradient)",
+}
+
+
 def families(prof):
     """ops.PROFILE (key -> [(start event, end event, algorithmic FLOP)]) folded per kernel family."""
     fam = {}
@@ -109,7 +119,9 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
     sources the loaded libtag_hip.so attests it was built from (tag_build_id = sha256 of csrc/ at compile time)."""
     if not fam:
         return None
-    dom = max(fam, key=lambda k: fam[k]["flop"])
+    # the dominant family is the one that owns the most TIME of the timed region (round 5's record picked by FLOP and named a family
+    # that no longer described the step)
+    dom = max(fam, key=lambda k: fam[k]["ms"])
     ach = fam[dom]["flop"] / (fam[dom]["ms"] * 1e-3) / 1e12
     iso = fam_iso[dom]["flop"] / (fam_iso[dom]["ms"] * 1e-3) / 1e12
     # HBM bytes per launch of the dominant family: PMC counters cannot be collected from inside this process, so the
@@ -133,7 +145,8 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
         else:
             # the bf16 conv family is two kernels since round 4: the tile kernel and the row-streaming kernel of conv_rows.hip
             names = {"conv3x3_x3_kernel": ("conv3x3_x3_kernel", "conv3x3_rows_kernel"),
-                     "conv3x3_wgrad_x3_kernel": ("conv3x3_wgrad_x3_kernel", "conv3x3_wgrad_dma_kernel")}.get(dom, (dom,))
+                     "conv3x3_wgrad_x3_kernel": ("conv3x3_wgrad_x3_kernel", "conv3x3_wgrad_dma_kernel"),
+                     "conv3x3_wino": ("wino_fused_kernel",), "conv3x3_wino_wgrad": ("wino_fused_wgrad_kernel",)}.get(dom, (dom,))
             rows = [v for k, v in tj.items() if k.startswith(names)]
             n = sum(v["launches_in_run"] for v in rows)
             if n:
@@ -146,8 +159,24 @@ def roofline_of(fam, fam_iso, steps, mode, conv_math, batch, overlap):
     # x3 kernels: 6 bf16 MFMA products per fp32 multiply -> peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6
     nprod = {"x3": 6.0, "x9": 9.0, "bf16": 1.0}.get(conv_math, 6.0)
     peak = PEAK_FP32_MFMA if not dom.startswith("conv3x3_x3") and not dom.startswith("conv3x3_pc") else round(2500.0 / nprod, 1)
-    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC, offline profile)",
+    def fam_peak(k):
+        return PEAK_FP32_MFMA if not k.startswith("conv3x3_x3") and not k.startswith("conv3x3_wgrad_x3") and not k.startswith("conv3x3_pc") \
+            else round(2500.0 / nprod, 1)
+
+    wino = dom.startswith("conv3x3_wino")
+    secondary = {KERNEL_TEXT.get(k, k): {"TFLOP/s": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                         "frac": round(v["flop"] / (v["ms"] * 1e-3) / 1e12 / fam_peak(k), 4),
+                                         "ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": v["launches"] // steps}
+                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]) if k != dom}
+    return {"bound": "mfma", "kernel": KERNEL_TEXT.get(dom, dom), "family": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4),
+            # what `achieved` counts: the FLOP the launches EXECUTE on the matrix pipe.  A Winograd launch executes 16 products of
+            # (tiles x Cin x Cout) per 2 x 2 output tile = the direct-convolution FLOP / 2.25
+            "flop_counted": ("executed: 2 * 16 * tiles * Cin * Cout per launch (direct-convolution FLOP / 2.25)" if wino
+                             else "2 * B * H * W * 9 * Cin * Cout per launch"),
+            "ms_per_step": round(fam[dom]["ms"] / steps, 3),
+            "secondary": secondary,
+            "traffic": traffic, "traffic_unit": "GB per launch (HBM, PMC, offline profile)",
             "traffic_source": traffic_src,
             "avg_launch_ms": round(fam[dom]["ms"] / fam[dom]["launches"], 4),
             "launches_per_step": fam[dom]["launches"] // steps,
@@ -346,7 +375,10 @@ def main():
     ap.add_argument("--comm-only", action="store_true",
                     help="N > 1: time ONLY the gradient buckets' all-reduces (fp32 and bf16 payload), nothing else, and print "
                          "that as the JSON line (diagnosis of a scaling run; not the contract's metric)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the opt-in conv arithmetic")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra legs (direct kernels; the bf16 mode)")
+    ap.add_argument("--alt-math", default="bf16",
+                    help="comma list of the other conv arithmetics timed after the contract's leg: bf16 (configs[2]'s per-rank mode; "
+                         "default), x3, x9 (opt-in splits: no roofline credit, retired from the default record in round 6)")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the ~50 ms register-resident MFMA probes behind `measured_ceiling` (profile collection: they are "
                          "not kernels of the step)")
@@ -382,7 +414,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     device = torch.device(f"cuda:{local}")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible to this process")
     torch.cuda.set_device(device)
+    if world > 1 and os.environ.get("TAG_SHARE_GPU", "0") != "1":      # (the test hook puts every rank on cuda:0 on purpose)
+        # one line of diagnosis instead of a run that silently times one GPU: every rank on its own device, that device = LOCAL_RANK
+        me = (rank, local, torch.cuda.current_device(), str(getattr(torch.cuda.get_device_properties(local), "uuid", local)))
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        bad = [m for m in seen if m[1] != m[2]]
+        if bad or len({m[3] for m in seen}) != world or len(seen) != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: ranks do not map one-to-one onto GPUs (rank, LOCAL_RANK, current device, "
+                             f"uuid) = {seen}")
     torch.manual_seed(0)
     model = build_workload("crnn" if args.crnn else "cross_attention" if args.cross_attention else
                            "cross_encoder" if args.cross_encoder else "biencoder", device)
@@ -514,7 +557,7 @@ def main():
                         "statistics, GRU, heads, loss, Adam and master weights f32"}
         desc["x9"] = ("fp32 operands split exactly into 3 bf16 terms, ALL 9 partial products on v_mfma_f32_32x32x16_bf16 (every "
                       "partial product exact, f32 accumulate; forward, dgrad and wgrad convs; opt-in TAG_CONV_MATH=x9)")
-        for mode in ("x3", "x9", "bf16"):
+        for mode in [m for m in args.alt_math.split(",") if m in ("x3", "x9", "bf16")]:
             ops.CONV_MATH = mode
             ops.ACT_DTYPE = "bf16" if mode == "bf16" else "fp32"
             runner.train_step(dict(batch))
@@ -589,8 +632,9 @@ def main():
                "config": {"workload": workload_name(args), "batch_per_gpu": args.batch,
                           "global_batch": world * args.batch, "clip": "10 s @ 32 kHz", "parallelism": f"dp{world}",
                           "conv_math": args.conv_math,
-                          "conv_algo": ("fp32 Winograd F(2x2,3x3) for the forward, dgrad and weight-gradient convs of blocks 3-4 (channel "
-                                        "counts >= 128 / 256; csrc/conv_wino.hip), direct MFMA convolution elsewhere"
+                          "conv_algo": ("fp32 Winograd F(2x2,3x3), transforms fused into the product kernel, for the forward, dgrad and "
+                                        "weight-gradient convs of every layer with >= 64 channels (21 launches per step; "
+                                        "csrc/conv_wino_fused.hip); the Cin = 1 conv stays direct"
                                         if (args.conv_math == "fp32" and ops.CONV_WINOGRAD) else "direct MFMA convolution")},
                "loss": loss_value,
                "whole_step_mfma_frac": round(value / world * FLOP_PER_CLIP / 1e12 /
@@ -598,6 +642,11 @@ def main():
                # counts the ALGORITHMIC (direct-convolution) FLOP of the step, 101.7 GFLOP per clip; with the Winograd form of the deep
                # layers the matrix pipe executes fewer (2.25 x fewer in those launches), so this is an effective rate, not pipe utilisation
                "whole_step_mfma_frac_counts": "algorithmic direct-convolution FLOP (effective rate)",
+               # the FLOP the step EXECUTES on the matrix pipe (the timed conv families as launched + 2.36 GFLOP per clip of GEMM / GRU /
+               # mel work) over the whole step time: pipe utilisation, comparable with roofline.frac
+               "whole_step_mfma_frac_executed": round((sum(v["flop"] for v in fam.values()) / args.steps + 2.36e9 * args.batch)
+                                                      / (dt / args.steps) / 1e12 /
+                                                      (2500.0 if args.conv_math == "bf16" else PEAK_FP32_MFMA), 4) if fam else None,
                "roofline": roof,
                # socket power and shader clock sampled (hwmon, every 25 ms) while the timed region ran
                "board": board,
@@ -628,6 +677,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (bounded sample)")
             out["cpu_baseline"] = cpu_baseline()
+        # compact digest of every timed leg as the LAST key: a reader who only keeps the tail of this line still sees them
+        legs = {"value": [out["value"], out["ms_per_step"]]}
+        for k_, v_ in (alt_algo or {}).items():
+            legs[k_] = [v_["value"], v_["ms_per_step"]]
+        for k_, v_ in (alt or {}).items():
+            legs[k_] = [v_["value"], v_["ms_per_step"]]
+        for k_, v_ in (others or {}).items():
+            legs[k_] = [v_["value"], v_["ms_per_step"]]
+        out["legs_clips_per_s_and_ms"] = legs
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -34,7 +34,7 @@
 
 #ifndef TAG_WF_ABL
 #define TAG_WF_ABL 0        // ablation builds (tools/wino_fused_abl.sh; results wrong by construction): bit 0 no x loads in the K loop,
-#endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier
+#endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier, bit 5 no epilogue, bit 6 no epilogue sums, bit 7 no output stores
 
 namespace {
 
@@ -62,8 +62,27 @@ __device__ __forceinline__ f32x4 fused_prologue(f32x4 v, f32x4 s, f32x4 t) {    
     return v;
 }
 
-__device__ __forceinline__ float dpp_quad_2211(float v) {       // lane s of a quad receives the value of lane {2, 2, 1, 1}[s]
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
+// v[k] += c * (the value v[k] has in lane {2, 2, 1, 1}[s] of the quad): the row transform of the staging threads as ONE
+// v_fmac_f32_dpp per value (hipcc keeps a v_mov_b32_dpp + v_fma_f32 pair; beside an fp32 MFMA stream every VALU operation costs
+// ~3 clocks of matrix time).  s_nop 1: a VALU write of a VGPR needs two wait states before a DPP read of it, and nothing inside
+// an asm statement is padded by the compiler.
+__device__ __forceinline__ f32x4 quad_fmac_2211(f32x4 v, float c) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(c));
+    return v;
+}
+__device__ __forceinline__ f32x4 quad_fmac_0033(f32x4 v, float c) {      // the same with source lanes {0, 0, 3, 3}
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(c));
+    return v;
 }
 
 // the wave's share of the 2 x 2 outputs from its 8 accumulator sets (xi = 4 r + s, r = 2 HH + {0, 1}), register quad rq
@@ -117,12 +136,14 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     float okb[4];                                      // PRO == 1: upper clamp of the row (+inf inside the image, 0 outside)
     bool okr[4];
     {
-        const long t = m0 + tl;
-        const bool okt = t < T;
-        const long tt_ = okt ? t : 0;
-        const int j = (int)(tt_ % tw);
-        const long bi = tt_ / tw;
-        const int i = (int)(bi % th), b = (int)(bi / th);
+        // (32-bit arithmetic: T < 2^27 (tag_conv3x3_wino_ok); a 64-bit division is several hundred clocks, and with one workgroup
+        // per CU nothing hides a workgroup's set-up)
+        const unsigned t = (unsigned)m0 + (unsigned)tl;
+        const bool okt = t < (unsigned)T;
+        const unsigned tt_ = okt ? t : 0u;
+        const unsigned bi = tt_ / (unsigned)tw;
+        const int j = (int)(tt_ - bi * (unsigned)tw);
+        const int b = (int)(bi / (unsigned)th), i = (int)(bi - (unsigned)b * (unsigned)th);
         const int w = 2 * j - 1 + s;
         const bool okw = okt && (unsigned)w < (unsigned)W;
 #pragma unroll
@@ -198,8 +219,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     };
     auto v_row = [&](int r) {                          // row transform (. B): one quad-permute exchange per value
         if (TAG_WF_ABL & 4) return;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+        vv = quad_fmac_2211(tt[r], fb);
     };
     auto v_write = [&](float* Vb, int r) {
 #if TAG_WF_ABL & 4
@@ -229,21 +249,29 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #endif
     };
 
-    // ---- prologue of the pipeline: chunk 0 into buffer 0, chunk 1 into the registers
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { load_x(0, r); load_u(0, r); }
-    __syncthreads();
-    ld_ss(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x_row(r);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x_col(r);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v_row(r); v_write(smem, r); u_write(smem + FBUF, r); }
+    // ---- prologue of the pipeline: chunk 0 into buffer 0, chunk 1 into the registers.  BOTH chunks are requested before anything
+    // waits (the accumulators are not live yet, so chunk 1 has registers to land in): one exposed memory latency per workgroup
+    // instead of two -- with one workgroup per CU nothing else covers it, and a 64-channel layer has only 8 chunks to amortise it over
     {
         const int c1 = nch > 1 ? 1 : 0;
+        f32x4 x1[4], u1[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { load_x(c1, r); load_u(c1, r); }
+        for (int r = 0; r < 4; ++r) { load_x(0, r); load_u(0, r); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x1[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[r], c1 * 32, 0));
+            u1[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uo0 + r * (4 * 64 * 8 * 4), (ublk + c1) * (16 * 64 * 8 * 4), 0));
+        }
+        __syncthreads();                               // (the producer scale / shift are in LDS)
+        ld_ss(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x_row(r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x_col(r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v_row(r); v_write(smem, r); u_write(smem + FBUF, r); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xr[r] = x1[r]; ur[r] = u1[r]; }
         ld_ss(c1);
     }
     __syncthreads();
@@ -286,6 +314,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #undef WF_FRAG
 #undef WF_SB
 
+#if TAG_WF_ABL & 32
+    if (acc[0][0] != 12345.678f) return;               // ablation: no epilogue at all (prologue + K loop only)
+#endif
     // ---- output transform: each wave parks its share of the 2 x 2 outputs  [half][pixel 2a+e][tile][cout]
     {
         float* park = smem + hh * (4 * 64 * FPARK_LD) + (wn * 32 + ml) * FPARK_LD + wm * 32 + 4 * kl;
@@ -307,13 +338,13 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     bool tok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const long t = m0 + slot + 32 * u;
-        tok[u] = t < T;
-        const long t2 = tok[u] ? t : 0;
-        tj[u] = (int)(t2 % tw);
-        const long bi = t2 / tw;
-        ti[u] = (int)(bi % th);
-        tb[u] = (int)(bi / th);
+        const unsigned t = (unsigned)m0 + (unsigned)(slot + 32 * u);
+        tok[u] = t < (unsigned)T;
+        const unsigned t2 = tok[u] ? t : 0u;
+        const unsigned bi = t2 / (unsigned)tw;
+        tj[u] = (int)(t2 - bi * (unsigned)tw);
+        tb[u] = (int)(bi / (unsigned)th);
+        ti[u] = (int)(bi - (unsigned)tb[u] * (unsigned)th);
     }
     const int co = n0 + 4 * cq;
 
@@ -361,7 +392,11 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         return;
     }
 
+#if TAG_WF_ABL & 64
+    const bool want = false;                           // ablation: no epilogue sums
+#else
     const bool want = (EPI == 0) ? (stats != nullptr) : true;
+#endif
     f32x4 bsc = {0, 0, 0, 0}, bsh = {0, 0, 0, 0}, bmu = {0, 0, 0, 0}, bis = {0, 0, 0, 0};
     if (EPI == 1 || EPI == 2) {
         bsc = *reinterpret_cast<const f32x4*>(epi.scale + co); bsh = *reinterpret_cast<const f32x4*>(epi.shift + co);
@@ -379,6 +414,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         const int h = 2 * ti[u] + a, w = 2 * tj[u] + e;
         if (!tok[u] || h >= H || w >= W) continue;
         const size_t off = (((size_t)tb[u] * H + h) * W + w) * Cout + co;
+#if TAG_WF_ABL & 128
+        if (o[0] == 12345.678f)                        // ablation: no output stores
+#endif
         *reinterpret_cast<f32x4*>(y + off) = o;
         if (EPI == 0 && want) {
 #pragma unroll
@@ -508,9 +546,6 @@ inline WgGeom wg_geom(int B, int H, int W, int Cin, int Cout) {
     return g;
 }
 
-__device__ __forceinline__ float dpp_quad_0033(float v) {       // lane s of a quad receives the value of lane {0, 0, 3, 3}[s]
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF0, 0xF, 0xF, true));
-}
 
 template <int PRO>
 __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
@@ -542,11 +577,11 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     // tile of this wave in the chunk being LOADED (uniform): image b, tile row i, tile column j
     int tb, ti, tj;
     {
-        const long t = (long)sl * cps * 8 + wave;
-        tj = (int)(t % tw);
-        const long bi = t / tw;
-        ti = (int)(bi % th);
-        tb = (int)(bi / th);
+        const unsigned t = (unsigned)sl * (unsigned)cps * 8u + (unsigned)wave;
+        const unsigned bi = t / (unsigned)tw;
+        tj = (int)(t - bi * (unsigned)tw);
+        tb = (int)(bi / (unsigned)th);
+        ti = (int)(bi - (unsigned)tb * (unsigned)th);
         tb = __builtin_amdgcn_readfirstlane(tb); ti = __builtin_amdgcn_readfirstlane(ti); tj = __builtin_amdgcn_readfirstlane(tj);
     }
     auto advance = [&]() {                            // + 8 tiles
@@ -608,8 +643,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         tt[3] = d[1] - d[3];
     };
     auto v_write = [&](float* Vb, int r) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+        vv = quad_fmac_2211(tt[r], fb);
         *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
     };
     auto g_rows = [&]() {                              // R = A g (the thread's gradient column)
@@ -619,8 +653,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         R[3] = -gr[1];
     };
     auto d_write = [&](float* Db, int r) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(cb, dpp_quad_0033(R[r][k]), R[r][k]);
+        vv = quad_fmac_0033(R[r], cb);
         *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
     };
     auto rotate_ok = [&]() {
@@ -630,22 +663,36 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         }
     };
 
-    // ---- pipeline prologue: chunk 0 into buffer 0, chunk 1 into the registers
+    // ---- pipeline prologue: chunk 0 into buffer 0, chunk 1 into the registers (both requested before anything waits)
+    {
+        f32x4 x0[4], g0[2];
+        float ok0[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) load_x(r);
-    load_g(0); load_g(1);
-    advance();
-    rotate_ok();
+        for (int r = 0; r < 4; ++r) load_x(r);
+        load_g(0); load_g(1);
+        advance();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x_row(r);
-    x_col();
-    g_rows();
+        for (int r = 0; r < 4; ++r) { x0[r] = xr[r]; ok0[r] = okn[r]; }
+        g0[0] = gr[0]; g0[1] = gr[1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v_write(smem, r); d_write(smem + FBUF, r); }
+        for (int r = 0; r < 4; ++r) load_x(r);         // chunk 1 (stays in xr / gr / okn for the first iteration)
+        load_g(0); load_g(1);
+        advance();
+        f32x4 x1[4], g1[2];
+        float ok1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) load_x(r);
-    load_g(0); load_g(1);
-    advance();
+        for (int r = 0; r < 4; ++r) { x1[r] = xr[r]; ok1[r] = okn[r]; xr[r] = x0[r]; okc[r] = ok0[r]; }
+        g1[0] = gr[0]; g1[1] = gr[1]; gr[0] = g0[0]; gr[1] = g0[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x_row(r);
+        x_col();
+        g_rows();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v_write(smem, r); d_write(smem + FBUF, r); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xr[r] = x1[r]; okn[r] = ok1[r]; }
+        gr[0] = g1[0]; gr[1] = g1[1];
+    }
     __syncthreads();
 
 #define WG_M4(J)                                                                                              \

@@ -39,7 +39,8 @@ def ref64(x, w, scale, shift, nb=2):
     return torch.nn.functional.conv2d(xx.permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
 
 
-shapes = [(250, 8, 512, 512), (250, 8, 256, 512), (250, 16, 256, 256), (250, 16, 128, 256), (500, 32, 128, 128)]
+shapes = [(250, 8, 512, 512), (250, 8, 256, 512), (250, 16, 256, 256), (250, 16, 128, 256), (500, 32, 128, 128), (500, 32, 64, 128),
+          (1001, 64, 64, 64)]
 if len(sys.argv) > 2:                      # one shape only (under rocprofv3)
     shapes = [shapes[int(sys.argv[2])]]
 for (H, W, Cin, Cout) in shapes:

@@ -62,27 +62,14 @@ __device__ __forceinline__ f32x4 fused_prologue(f32x4 v, f32x4 s, f32x4 t) {    
     return v;
 }
 
-// v[k] += c * (the value v[k] has in lane {2, 2, 1, 1}[s] of the quad): the row transform of the staging threads as ONE
-// v_fmac_f32_dpp per value (hipcc keeps a v_mov_b32_dpp + v_fma_f32 pair; beside an fp32 MFMA stream every VALU operation costs
-// ~3 clocks of matrix time).  s_nop 1: a VALU write of a VGPR needs two wait states before a DPP read of it, and nothing inside
-// an asm statement is padded by the compiler.
-__device__ __forceinline__ f32x4 quad_fmac_2211(f32x4 v, float c) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(c));
-    return v;
+// v + c * (the value v has in lane {2, 2, 1, 1}[s] / {0, 0, 3, 3}[s] of the quad).  (A hand-written v_fmac_f32_dpp -- one instruction
+// per value instead of hipcc's v_mov_b32_dpp + v_fma_f32 -- was tried: the scalar asm operands cost three register copies per value
+// on the way from the transform to the 16-byte LDS store, 96 v_mov per chunk in the weight-gradient kernel.)
+__device__ __forceinline__ float dpp_quad_2211(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
-__device__ __forceinline__ f32x4 quad_fmac_0033(f32x4 v, float c) {      // the same with source lanes {0, 0, 3, 3}
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[0,0,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(c));
-    return v;
+__device__ __forceinline__ float dpp_quad_0033(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF0, 0xF, 0xF, true));
 }
 
 // the wave's share of the 2 x 2 outputs from its 8 accumulator sets (xi = 4 r + s, r = 2 HH + {0, 1}), register quad rq
@@ -219,7 +206,8 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     };
     auto v_row = [&](int r) {                          // row transform (. B): one quad-permute exchange per value
         if (TAG_WF_ABL & 4) return;
-        vv = quad_fmac_2211(tt[r], fb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
     };
     auto v_write = [&](float* Vb, int r) {
 #if TAG_WF_ABL & 4
@@ -613,7 +601,9 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         const int h = 2 * ti - 1 + r;
         const bool rv = tb < B && (unsigned)h < (unsigned)H;
         const bool ok = rv && (unsigned)(2 * tj - 1 + s) < (unsigned)W;
-        const int so = rv ? (int)((((size_t)tb * H + h) * W + 2 * tj) * Cin * 4) : 0;
+        // (32-bit scalar arithmetic: the tensor is < 2^31 bytes; for rows outside the image the offset is never used -- every lane
+        // of the wave then carries the out-of-range vector offset)
+        const int so = (int)(((unsigned)(tb * H + h) * (unsigned)W + 2u * (unsigned)tj) * (unsigned)(Cin * 4));
         xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xvo : 0x80000000u, so, 0));
         if (PRO != 0) okn[r] = ok ? INFINITY : 0.0f;
     };
@@ -621,7 +611,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         const int h = 2 * ti + a;
         const bool rv = tb < B && h < H;
         const bool ok = rv && (2 * tj + (s & 1)) < W;
-        const int so = rv ? (int)((((size_t)tb * H + h) * W + 2 * tj) * Cout * 4) : 0;
+        const int so = (int)(((unsigned)(tb * H + h) * (unsigned)W + 2u * (unsigned)tj) * (unsigned)(Cout * 4));
         gr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok ? dvo : 0x80000000u, so, 0));
     };
     f32x4 d[4], tt[4], R[4], vv;
@@ -643,7 +633,8 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         tt[3] = d[1] - d[3];
     };
     auto v_write = [&](float* Vb, int r) {
-        vv = quad_fmac_2211(tt[r], fb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
         *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
     };
     auto g_rows = [&]() {                              // R = A g (the thread's gradient column)
@@ -653,7 +644,8 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         R[3] = -gr[1];
     };
     auto d_write = [&](float* Db, int r) {
-        vv = quad_fmac_0033(R[r], cb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = fmaf(cb, dpp_quad_0033(R[r][k]), R[r][k]);
         *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
     };
     auto rotate_ok = [&]() {

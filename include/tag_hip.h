@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TAG_ABI_VERSION 2   /* bump whenever an existing entry point changes its argument list (lib.py checks it) */
+#define TAG_ABI_VERSION 3   /* bump whenever an entry point is added or changes its arguments / data layout (lib.py checks it FIRST) */
 #define TAG_EINVAL (-1) /* bad argument (shape not supported, null pointer, ...) */
 #define TAG_ELAUNCH (-2)
 
@@ -38,6 +38,10 @@ int tag_abi_version(void);
  * bench.py for the binary that actually ran (the reference has no native code: nothing is replaced) */
 const char* tag_build_id(void);
 const char* tag_last_error(void);
+/* Developer switch for A/B timing by tools/ and tests/ (csrc/tag_lib.hip lists the names: "halo_bn256", "gru_coop", ...): set before
+ * the first launch that reads it.  The launchers read no environment; texttoaudiogrounding_amd/lib.py forwards the TAG_* variables
+ * of the tool scripts here at load time.  Nothing of the reference is replaced.  TAG_EINVAL for an unknown name. */
+int tag_set_option(const char* name, int value);
 /* Measurement aid of bench.py (csrc/probe.hip; nothing of the reference is replaced): `workgroups` x 4 waves of register-resident
  * MFMA work for `iters` iterations.  kind 0: bf16 32x32x16 on RANDOM operands (what a real kernel's toggling costs: the part's
  * power limit), 1: bf16 constant operands (datasheet conditions), 2 / 3: the same for the exact-fp32 32x32x2.  clocks: 3 x u64,
@@ -167,32 +171,38 @@ int tag_conv3x3_dgrad_bnsums(const float* dy, const float* wpack, float* da, con
                              const float* bn_scale, const float* bn_shift, const float* bn_mean,
                              const float* bn_invstd, float* bnpart, int B, int H, int W, int Cin, int Cout,
                              void* stream);
-/* Winograd F(2x2,3x3) form of the same convolution (csrc/conv_wino.hip), all fp32: the A1 ConvBlock convs of
- * models/panns.py:29-38,49-50 as input transform (producer BatchNorm+ReLU prologue and zero padding applied on load) ->
- * 16 dense products (T x Cin).(Cin x Cout) on the exact-fp32 MFMA in one batched launch (T = B*ceil(H/2)*ceil(W/2) tiles,
- * 2.25 x fewer MFMA FLOP than tag_conv3x3_forward) -> output transform, which also writes EITHER the BatchNorm partial
- * statistics of y (rows [K | r | q][Cout] + counts, folded by tag_bn_stats_from_partials) OR, for the dgrad form, the sums
- * [sum g | sum g*xhat][Cout] of the BatchNorm+ReLU backward the gradient flows into (folded by tag_bn_grad_from_partials):
- * drop-in for tag_conv3x3_forward(stats) / tag_conv3x3_dgrad_bnsums on the deep layers.  Error vs an fp64 convolution:
- * ~2.3 x the direct fp32 kernel's (same rounding class).
- *   ufwd [16][Cin][Cout] / udgrad [16][Cout][Cin]: G g G^T of the filter / of the tap-flipped, channel-swapped filter;
- *   ws: tag_conv3x3_wino_ws_bytes (transformed input + product planes); P = tag_conv3x3_wino_stats_rows;
- *   tag_conv3x3_wino_ok: 1 when the shape is served (channel counts 32..1024 whose quarter divides 256, Cin % 32 == 0). */
+/* Winograd F(2x2,3x3) form of the same convolution, all fp32: the A1 ConvBlock convs of models/panns.py:29-38,49-50 with 2.25 x
+ * fewer MFMA FLOP than tag_conv3x3_forward.  Drop-in for tag_conv3x3_forward(stats) / tag_conv3x3_dgrad_bnsums / _dgrad_poolsums /
+ * _forward_bnrelu_pool_eval / tag_conv3x3_wgrad.  Error vs an fp64 convolution: at or below the direct fp32 kernel's.
+ *   Channel counts that are multiples of 64 (every Cnn8Rnn layer but the Cin = 1 conv): ONE kernel per launch (round 6,
+ *   csrc/conv_wino_fused.hip) -- the input transform B^T d B (producer BatchNorm+ReLU prologue and zero padding applied on load) is
+ *   formed on the way into LDS, the 16 products (tiles x Cin).(Cin x Cout) run on the exact-fp32 MFMA into 16 accumulator sets that
+ *   stay in registers, the output transform A^T m A and the epilogue (BatchNorm statistics rows [K | r | q][Cout] + counts for
+ *   tag_bn_stats_from_partials / rows [sum g | sum g*xhat][Cout] for tag_bn_grad_from_partials / pooled inference output) work from
+ *   a parked output tile.  No workspace (ws is ignored, tag_conv3x3_wino_ws_bytes = 64); one partial row per 64-tile block.
+ *   Other channel counts (32..1024 whose quarter divides 256, Cin % 32 == 0): round 5's plane form (csrc/conv_wino.hip): input
+ *   transform -> 16 batched products -> output transform through planes in ws.
+ *   ufwd / udgrad (16 * Cin * Cout floats each): G g G^T of the filter / of the tap-flipped, channel-swapped filter -- an OPAQUE
+ *   pack of tag_pack_conv_weight_wino (fused form: per (64-cout block, 8-channel K chunk) the kernel's LDS image [xi][n 64][k 8];
+ *   plane form: [16][Cin][Cout] / [16][Cout][Cin]); P = tag_conv3x3_wino_stats_rows; tag_conv3x3_wino_ok: 1 when the shape is served
+ *   (every tensor below 2^31 bytes: a caller cuts larger inference batches, any cut gives the same rows). */
 int tag_conv3x3_wino_ok(int B, int H, int W, int Cin, int Cout);
 int tag_pack_conv_weight_wino(const float* w /*(Cout,Cin,3,3)*/, float* ufwd, float* udgrad, int Cin, int Cout, void* stream);
 size_t tag_conv3x3_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wino_stats_rows(int B, int H, int W, int Cout);
 /* weight gradient in the Winograd domain: dw (Cout,Cin,3,3) = G^T [ sum over tiles (A dY A^T) (.) (B^T prologue(x) B) ] G -- the
- * adjoint of the forward form; 16 x S products (Cout x kc).(kc x Cin) over K slices of the tile axis in one batched launch,
- * folded in a fixed order.  Drop-in for tag_conv3x3_wgrad on the shapes tag_conv3x3_wino_ok accepts. */
+ * adjoint of the forward form.  Fused form (channel counts multiples of 64): both transforms at staging, 64 ci x 64 co x 16 xi
+ * accumulators per workgroup over one slice of the tile axis, ws = 2 S partial filters folded in a fixed order.  Plane form: 16 x S
+ * batched products over K slices.  Drop-in for tag_conv3x3_wgrad on the shapes tag_conv3x3_wino_ok accepts. */
 size_t tag_conv3x3_wino_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
-/* v_saved (optional): the transformed input the forward launch of the same convolution left in its
- * v_keep buffer -- the input transform is then not repeated (x may be NULL); allowed when tag_conv3x3_wino_wgrad_can_reuse_v. */
+/* v_saved (optional, plane form only): the transformed input the forward launch of the same convolution left in its v_keep
+ * buffer -- the input transform is then not repeated (x may be NULL); allowed when tag_conv3x3_wino_wgrad_can_reuse_v (0 for the
+ * fused form, which has no planes). */
 int tag_conv3x3_wino_wgrad_can_reuse_v(int B, int H, int W, int Cin, int Cout);
 int tag_conv3x3_wino_wgrad(const float* x, int prologue, const float* in_scale, const float* in_shift, const float* dy,
                            float* dw /*(Cout,Cin,3,3)*/, int B, int H, int W, int Cin, int Cout, void* ws, const float* v_saved,
                            void* stream);
-/* v_keep (optional): 16 * T * Cin floats that receive the transformed input instead of ws (which then
+/* v_keep (optional, plane form): 16 * T * Cin floats that receive the transformed input instead of ws (which then
  * needs the product planes only: 16 * T * Cout floats) -- kept by the caller for tag_conv3x3_wino_wgrad(v_saved). */
 int tag_conv3x3_wino_forward(const float* x, const float* ufwd, int prologue, const float* in_scale, const float* in_shift,
                              float* y, float* stats, int B, int H, int W, int Cin, int Cout, void* ws, float* v_keep,

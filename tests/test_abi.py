@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (tag_[a-z0-9_]+)", out))
     assert set(syms) <= exported
-    assert handle.tag_abi_version() == lib.ABI_VERSION == 2
+    assert handle.tag_abi_version() == lib.ABI_VERSION == 3
 
 
 def test_binary_attests_its_sources(tmp_path):

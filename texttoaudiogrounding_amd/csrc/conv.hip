@@ -2000,13 +2000,10 @@ int wgrad_tile(int Cin, int Cout) { return (Cin >= 128 && Cout >= 128) ? 128 : 6
 
 }  // namespace
 
-// TAG_CONV_IMPL (environment, read once): 0 = auto (halo-tile kernel when the width allows), 1 = tap-by-tap kernel
+// option conv_impl (read once): 0 = auto (halo-tile kernel when the width allows), 1 = tap-by-tap kernel
 static int conv_impl() {
     static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TAG_CONV_IMPL");
-        v = e ? atoi(e) : 0;
-    }
+    if (v < 0) v = tag_option("conv_impl");
     return v;
 }
 
@@ -2069,7 +2066,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
     // TAG_HALO_LDS_PAD (environment, experiments only: tools/hybrid_probe.py): extra dynamic LDS per workgroup, i.e. FEWER workgroups
     // per CU, to leave registers for waves of another kernel
     static int lds_pad = -1;
-    if (lds_pad < 0) { const char* e = getenv("TAG_HALO_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    if (lds_pad < 0) lds_pad = tag_option("halo_lds_pad");
     const size_t lds = (size_t)(G::ASZ + 2 * halo_stage<BN_>() * BN_ + 2 * ((Cin + 3) / 4 * 4)) * sizeof(float) + (size_t)lds_pad;
 #define LAUNCH_EPI(P, E)                                                                                          \
     {                                                                                                             \
@@ -2123,7 +2120,7 @@ static void launch_halo(const float* x, const float* wp, int pro, const float* s
 // a backward epilogue keep the 128-cout tiles.  TAG_HALO_BN256=0: 128-cout tiles everywhere, =2: 256-cout tiles everywhere (A/B).
 static bool halo_bn256(int W, int Cout, bool training_launch) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("TAG_HALO_BN256"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = tag_option("halo_bn256");
     return (on == 2 || (on == 1 && training_launch)) && W <= 16 && Cout % 256 == 0;
 }
 
@@ -2259,7 +2256,7 @@ static int alltaps_splits(int B, int H, int W, int Cin, int Cout, int* chunks_pe
     const int chunks = B * ((H + ch - 1) / ch) * (W / cw);
     const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64);
     static int target = 0;                                      // TAG_WGRAD_WGS (environment): workgroups per launch, A/B timing
-    if (target == 0) { const char* e = getenv("TAG_WGRAD_WGS"); target = e ? atoi(e) : 512; if (target < 64) target = 512; }
+    if (target == 0) { target = tag_option("wgrad_wgs"); if (target < 64) target = 512; }
     int s = target / tiles;
     if (s > chunks / 8) s = chunks / 8;
     if (s < 1) s = 1;

@@ -574,7 +574,7 @@ void launch_rows_pe(int pro, int epi_kind, const bf16_t* x, const u32x4* wp, con
 // TAG_CONV_ROWS=0 (environment) or tag_conv_rows_enable(0) keeps every layer on the tile kernel of conv_x3.hip (A/B timing)
 static int g_rows_on = -1;
 static bool rows_enabled() {
-    if (g_rows_on < 0) { const char* e = getenv("TAG_CONV_ROWS"); g_rows_on = (e && e[0] == '0') ? 0 : 1; }
+    if (g_rows_on < 0) g_rows_on = tag_option("conv_rows") ? 1 : 0;
     return g_rows_on == 1;
 }
 extern "C" int tag_conv_rows_enable(int on) {

@@ -341,7 +341,7 @@ void launch_wgrad_dma(const bf16_t* x, int pro, const float* s, const float* t, 
 // TAG_WGRAD_DMA=0 / tag_wgrad_dma_enable(0): never; =2 / enable(2): also the prologue-1 layers.
 static int g_wdma_on = -1;
 bool tag_wgrad_dma_takes(int prologue) {
-    if (g_wdma_on < 0) { const char* e = getenv("TAG_WGRAD_DMA"); g_wdma_on = e ? atoi(e) : 1; }
+    if (g_wdma_on < 0) g_wdma_on = tag_option("wgrad_dma");
     return (g_wdma_on == 1 && prologue == 0) || (g_wdma_on >= 2 && prologue <= 1);
 }
 extern "C" int tag_wgrad_dma_enable(int on) {

@@ -34,7 +34,7 @@
 
 #ifndef TAG_WF_ABL
 #define TAG_WF_ABL 0        // ablation builds (tools/wino_fused_abl.sh; results wrong by construction): bit 0 no x loads in the K loop,
-#endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier, bit 5 no epilogue, bit 6 no epilogue sums, bit 7 no output stores
+#endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier, bit 5 no epilogue, bit 6 no epilogue sums, bit 7 no output stores, bits 8 / 9 x / U loads always of chunk 0
 
 namespace {
 
@@ -227,12 +227,16 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #endif
     };
     auto lx = [&](int c, int r) {
-#if !(TAG_WF_ABL & 1)
+#if TAG_WF_ABL & 256
+        load_x(0, r);                                  // ablation: always chunk 0 (cache-resident: issue cost without latency)
+#elif !(TAG_WF_ABL & 1)
         load_x(c, r);
 #endif
     };
     auto lu = [&](int c, int j) {
-#if !(TAG_WF_ABL & 2)
+#if TAG_WF_ABL & 512
+        load_u(0, j);
+#elif !(TAG_WF_ABL & 2)
         load_u(c, j);
 #endif
     };
@@ -393,6 +397,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     f32x4 piv = {0, 0, 0, 0};
     if (EPI == 0 && want) piv = *reinterpret_cast<const f32x4*>(pk) + *reinterpret_cast<const f32x4*>(pk + HALF);   // pixel (0,0) of tile 0
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, cnt = 0.0f;
+    size_t tbase[2];                                   // offset of the tile's first output pixel (the 64-bit products once per tile)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) tbase[u] = (((size_t)tb[u] * H + 2 * ti[u]) * W + 2 * tj[u]) * Cout + co;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int ae = it >> 1, u = it & 1, a = ae >> 1, e = ae & 1;
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         const f32x4 o = *reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + HALF);
         const int h = 2 * ti[u] + a, w = 2 * tj[u] + e;
         if (!tok[u] || h >= H || w >= W) continue;
-        const size_t off = (((size_t)tb[u] * H + h) * W + w) * Cout + co;
+        const size_t off = tbase[u] + (size_t)((a * W + e) * Cout);
 #if TAG_WF_ABL & 128
         if (o[0] == 12345.678f)                        // ablation: no output stores
 #endif

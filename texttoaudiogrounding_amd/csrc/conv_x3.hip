@@ -1021,13 +1021,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_x3_kernel(const TS* __re
 }
 
 // products per fp32 multiply: 6 (default), 9 (every partial product), 1 (plain bf16, hi plane rounded to nearest);
-// 0 = the process default (environment TAG_X3_PRODUCTS, else 6)
+// 0 = the process default (option x3_products, else 6)
 static int x3_products(int requested) {
     if (requested == 1 || requested == 6 || requested == 9) return requested;
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("TAG_X3_PRODUCTS");
-        v = e ? atoi(e) : 6;
+        v = tag_option("x3_products");
         if (v != 1 && v != 6 && v != 9) v = 6;
     }
     return v;

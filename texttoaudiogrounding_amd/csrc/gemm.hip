@@ -448,7 +448,7 @@ int launch_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     const bool akc = !transA, bkc = transB != 0;
     // 128x128 tiles only when they still make >= 4 residency rounds: below that the 64-tiles (4 workgroups per CU, two rounds
     // whose epilogue stores overlap the next tiles' products) are 3-8 % faster at the step's shapes (tools/gemm_bench.py)
-    static const int big_min = getenv("TAG_GEMM_BIG_MIN") ? atoi(getenv("TAG_GEMM_BIG_MIN")) : 2048;
+    static const int big_min = tag_option("gemm_big_min");
     const bool big = splits == 1 && (long)((M + 127) / 128) * ((N + 127) / 128) >= big_min;
 #define GEMM_DISPATCH(AK, BK_)                                                                                        \
     if (bf) {                                                                                                         \
@@ -592,7 +592,7 @@ int tag_launch_gemm_batched(const float* A, int lda, long sA, const float* B, in
     Epilogue ep{nullptr, 0, 0, 1.0f, 0, 1, 1, 1};
     const bool a_al = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0) && (sA % 4 == 0);
     const bool b_al = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
-    static const int gkt = getenv("TAG_WINO_GK") ? atoi(getenv("TAG_WINO_GK")) : 16;        // A/B: 32 = the dense GEMM's chunk
+    constexpr int gkt = 16;         // K chunk of the batched products (32, the dense GEMM's chunk, measured 15 % slower: docs/experiments_r05.md)
     if (transA) {
         if (M >= 128 && N >= 128 && gkt == 16 && K % 16 == 0)
             launch_gemm_t<false, false, 128, false, 16>(A, lda, B, ldb, C, ldc, M, N, K, ep, a_al, b_al, 1, nullptr, st, batch, sA, sB, sC,

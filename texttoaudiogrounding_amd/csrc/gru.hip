@@ -833,13 +833,13 @@ bool gru_grid_fits(K kernel, int grid_blocks) {
     const int safe = per_cu > 1 ? per_cu - 1 : 1;
     return grid_blocks <= safe * cus;
 }
-// TAG_GRU_TILE=16 (environment) selects the 16-row persistent kernels (the round-2 form), for A/B timing
+// option gru_tile4 = 0 selects the 16-row persistent kernels (the round-2 form), for A/B timing
 bool gru_tile4_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TAG_GRU_TILE"); v = (e && e[0] == '1' && e[1] == '6') ? 0 : 1; }
+    if (v < 0) v = tag_option("gru_tile4") ? 1 : 0;
     return v == 1;
 }
-// TAG_GRU_XCD=0: never use the L2-resident (same-XCD) publishing, for A/B timing
+// option gru_xcd = 0: never use the L2-resident (same-XCD) publishing, for A/B timing
 // The L2-resident publishing relies on gfx950 behaviour beyond the HIP memory model (workgroup-scope sc0 stores of one
 // workgroup being served to agent-scope sc1 loads of another workgroup on the SAME XCD out of that XCD's L2; partition mode
 // SPX, MTYPE_RW) and is gated by the run-time HW_REG_XCC_ID check in the kernels.  A stale read shows as a tag mismatch ->
@@ -847,12 +847,12 @@ bool gru_tile4_enabled() {
 // launch of the process publishes write-through (sc1), which is correct under every placement.
 static int g_gru_xcd_fast = -1;
 bool gru_xcd_fast_enabled() {
-    if (g_gru_xcd_fast < 0) { const char* e = getenv("TAG_GRU_XCD"); g_gru_xcd_fast = (e && e[0] == '0') ? 0 : 1; }
+    if (g_gru_xcd_fast < 0) g_gru_xcd_fast = tag_option("gru_xcd") ? 1 : 0;
     return g_gru_xcd_fast == 1;
 }
 bool gru_coop_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TAG_GRU_COOP"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) v = tag_option("gru_coop") ? 1 : 0;
     return v == 1;
 }
 // returns hipSuccess when the persistent kernel was launched; anything else -> caller falls back to the step kernels

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void mha_cross_bwd_mfma_kernel(const float* __
 
 static bool mha_mfma_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TAG_MHA_MFMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) v = tag_option("mha_mfma") ? 1 : 0;
     return v == 1;
 }
 static bool mha_mfma_ok(int E, int H) {

@@ -9,6 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void tag_set_error(const char* fmt, ...);
+// developer switch (tag_lib.hip; set with tag_set_option before the first launch that reads it)
+int tag_option(const char* name);
 
 #define TAG_CHECK_ARG(cond)                                                              \
     do {                                                                                 \

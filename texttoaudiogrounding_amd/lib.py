@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("TAG_HIP_LIB") or os.path.join(_HERE, "libtag_hip.so")
 
 # = TAG_ABI_VERSION of include/tag_hip.h: bumped whenever an EXISTING entry point changes its argument list, so that a stale
 # libtag_hip.so (git-ignored, shipped separately) is refused instead of being called with shifted arguments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P = c_void_p
 _SIGS = {
@@ -47,6 +47,7 @@ _SIGS = {
     "tag_bn_stats_from_partials": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "tag_conv3x3_forward": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "tag_conv3x3_dgrad_bnsums": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "tag_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "tag_conv3x3_wino_ok": (c_int, [c_int] * 5),
     "tag_pack_conv_weight_wino": (c_int, [P, P, P, c_int, c_int, P]),
     "tag_conv3x3_wino_ws_bytes": (c_size_t, [c_int] * 5),
@@ -185,21 +186,46 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C texttoaudiogrounding_amd/csrc`). There is no CPU/eager fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    # version first: a stale library then says so, instead of failing on the first symbol it does not have yet
+    try:
+        lib.tag_abi_version.restype = c_int
+        have = lib.tag_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise RuntimeError(f"libtag_hip.so ABI version {have} != {ABI_VERSION} expected by lib.py: the shared library is stale, "
+                           "rebuild it (make -C texttoaudiogrounding_amd/csrc)")
     for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}: the shared library is stale, rebuild it "
+                               "(make -C texttoaudiogrounding_amd/csrc)") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.tag_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libtag_hip.so ABI version {lib.tag_abi_version()} != {ABI_VERSION} expected by lib.py: the "
-                           "shared library is stale, rebuild it (make -C texttoaudiogrounding_amd/csrc)")
     # the binary attests the sources it was compiled from: a stale .so beside edited kernels is refused (a private build named by
     # TAG_HIP_LIB is compiled from the same sources with extra -D flags and passes; TAG_ALLOW_STALE_LIB=1 is the developer's override)
     built = lib.tag_build_id().decode()
     if os.path.isdir(os.path.join(_HERE, "csrc")) and built != csrc_sha256() and os.environ.get("TAG_ALLOW_STALE_LIB") != "1":
         raise RuntimeError(f"{LIB_PATH} was built from other kernel sources (build id {built[:12]} != csrc sha256 "
                            f"{csrc_sha256()[:12]}): rebuild it (make -C texttoaudiogrounding_amd/csrc)")
+    # developer switches of the tool scripts: the launchers read no environment, the TAG_* variables are forwarded here
+    for env, (opt, conv) in _ENV_OPTIONS.items():
+        if env in os.environ:
+            if lib.tag_set_option(opt.encode(), conv(os.environ[env])) != 0:
+                raise RuntimeError(lib.tag_last_error().decode())
     _lib = lib
     return lib
+
+
+#: environment variable of a tool script -> (option of tag_set_option, value conversion)
+_ENV_OPTIONS = {
+    "TAG_CONV_IMPL": ("conv_impl", int), "TAG_HALO_LDS_PAD": ("halo_lds_pad", int), "TAG_HALO_BN256": ("halo_bn256", int),
+    "TAG_WGRAD_WGS": ("wgrad_wgs", int), "TAG_CONV_ROWS": ("conv_rows", int), "TAG_WGRAD_DMA": ("wgrad_dma", int),
+    "TAG_X3_PRODUCTS": ("x3_products", int), "TAG_GEMM_BIG_MIN": ("gemm_big_min", int),
+    "TAG_GRU_TILE": ("gru_tile4", lambda v: 0 if v == "16" else 1), "TAG_GRU_XCD": ("gru_xcd", int),
+    "TAG_GRU_COOP": ("gru_coop", int), "TAG_MHA_MFMA": ("mha_mfma", int),
+}
 
 
 def build_id() -> str:

@@ -29,7 +29,7 @@ for mode in fp32 bf16; do
   python tools/pmc_sq.py $(find $OUT/sq_$mode -name "*counter_collection.csv" | head -1) gru >> $OUT/${R}_pmc_sq_counters_${mode}.txt 2>&1
   # (round 5: the batched Winograd-domain products run on gemm_kernel; the transform passes beside them)
   python tools/pmc_sq.py $(find $OUT/sq_$mode -name "*counter_collection.csv" | head -1) gemm_kernel >> $OUT/${R}_pmc_sq_counters_${mode}.txt 2>&1
-  python tools/pmc_sq.py $(find $OUT/sq_$mode -name "*counter_collection.csv" | head -1) wino >> $OUT/${R}_pmc_sq_counters_${mode}.txt 2>&1
+  python tools/pmc_sq.py $(find $OUT/sq_$mode -name "*counter_collection.csv" | head -1) wino_fused >> $OUT/${R}_pmc_sq_counters_${mode}.txt 2>&1
   TAG_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/valu_$mode -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-others --no-probe $extra > $OUT/valu_$mode.log 2>&1
   python tools/pmc_valu.py $(find $OUT/valu_$mode -name "*counter_collection.csv" | head -1) > $OUT/${R}_pmc_valu_issue_${mode}.txt 2>&1
   rm -rf $OUT/sq_$mode $OUT/valu_$mode

@@ -72,16 +72,25 @@ def assert_grad_close(name, err, floor):
         assert err <= 4.0 * max(floor, 1e-6), (name, err, floor)
 
 
-@pytest.fixture(params=["fp32", "x3", "x9"])
+@pytest.fixture(params=["fp32"])
 def conv_math(request):
-    """The fp32-accurate arithmetics of the 3x3 convolutions: exact fp32 MFMA (default) and the opt-in 3 x bf16 split
-    (conv_x3.hip) with 6 partial products ("x3") or all 9 ("x9": every partial product exact); the assertions (tolerances)
-    are the same for all of them."""
+    """The arithmetic of the 3x3 convolutions the whole-path tests run under: exact fp32 MFMA.  (Rounds 2-5 also ran every test
+    here under the opt-in 3 x bf16 splits "x3" / "x9" of conv_x3.hip; they earn no roofline credit and since round 6 the exact fp32
+    path is as fast as x3, so they left the default matrix -- their kernels keep their own tests in tests/test_gpu_kernels.py and one
+    whole-path smoke test each below.)"""
     from texttoaudiogrounding_amd import ops
     old = ops.CONV_MATH
     ops.CONV_MATH = request.param
     yield request.param
     ops.CONV_MATH = old
+
+
+@pytest.mark.parametrize("split", ["x3", "x9"])
+def test_split_arithmetic_whole_path_smoke(dev, golden_dir, split, monkeypatch):
+    """One whole-path check per opt-in split arithmetic: the reference's eval fixture under CONV_MATH = x3 / x9."""
+    from texttoaudiogrounding_amd import ops
+    monkeypatch.setattr(ops, "CONV_MATH", split)
+    test_golden_eval(dev, golden_dir, split)
 
 
 def test_golden_eval(dev, golden_dir, conv_math):
@@ -748,7 +757,7 @@ def test_full_length_train_step_vs_oracle(dev):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 1e-6, name
 
 
-@pytest.mark.parametrize("math_", ["fp32", "fp32-direct", "x9"])
+@pytest.mark.parametrize("math_", ["fp32", "fp32-direct"])
 def test_benched_size_train_step_vs_fixture(dev, golden_dir, monkeypatch, math_):
     """Parity AT THE BENCHED SIZE (BASELINE configs[1]: B = 64, 10 s clips, train-mode BatchNorm, dropout ON) -- the grids
     where the XCD remap, 3-workgroup/CU residency, split-K counts and the 128-workgroup persistent GRU actually live.
@@ -1150,7 +1159,7 @@ def _oracle_trajectory(st, batch, names):
     return list(_TRAJECTORY_REF[key])
 
 
-@pytest.mark.parametrize("math_", ["fp32", "x3", "x9", "bf16mode"])
+@pytest.mark.parametrize("math_", ["fp32", "bf16mode"])
 def test_training_trajectory_matches_oracle(dev, math_):
     """Ten optimiser steps (forward, backward, clip_grad_norm_(1.0), Adam) on a fixed batch, dropout off: the loss
     trajectory of the HIP path follows the fp64 oracle's (torch.optim.Adam on the oracle's parameters).  "bf16mode" =
@@ -1183,7 +1192,7 @@ def test_training_trajectory_matches_oracle(dev, math_):
         assert abs(hip[0] - ref[0]) < 2e-5
 
 
-@pytest.mark.parametrize("math_", ["fp32", "x3"])
+@pytest.mark.parametrize("math_", ["fp32"])
 def test_training_step_is_bitwise_deterministic(dev, math_):
     """Every reduction of the path folds its partials in a fixed order and nothing uses atomics (the embedding-table
     gradient is summed per row by its first occurrence, in pair order; the batch repeats token ids on purpose): two runs

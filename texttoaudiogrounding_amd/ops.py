@@ -1230,13 +1230,13 @@ class Cnn8RnnFunction(TagFunction):
                                              out_dtype=BF16 if act_bf16() else F32)
                 wf1 = wd1 = None
             else:
-                wf1, wd1 = pack_conv_weight(c1w, W=x.shape[2])
+                wf1, wd1 = pack_conv_weight(c1w, want_dgrad=need_grad, W=x.shape[2])
                 y1, part1 = conv3x3_stats(x, wf1, c1w.shape[0], want_stats=bn_train,
                                           inference=not need_grad and not bn_train and drop[0] == 0.0)
             Bx, H, W, C = y1.shape
             s1 = bn_stats(y1.view(-1, C), g1, b1, blk.bn1.running_mean, blk.bn1.running_var, bn_train, blk.bn1.eps,
                           blk.bn1.momentum, partials=part1)
-            wf2, wd2 = pack_conv_weight(c2w, W=y1.shape[2])
+            wf2, wd2 = pack_conv_weight(c2w, want_dgrad=need_grad, W=y1.shape[2])
             ph, pw = CNN8_POOLS[i]
             if not need_grad and not bn_train and drop[0] == 0.0 and eval_pool_fusable(y1, wf2, ph, pw):
                 # inference (models/hf_modeling_grounding.py; evaluation between epochs): bn2's affine is known before the conv

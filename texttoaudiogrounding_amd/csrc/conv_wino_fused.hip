@@ -97,6 +97,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
                                                          int W, int Cin, int Cout, int th, int tw, long T, int m_tiles, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TAG_WF_PROF
+    const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
     // ---- workgroup -> (tile block mt, cout block nt)
     int mt, nt;
     {
@@ -241,6 +244,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #endif
     };
 
+#ifdef TAG_WF_PROF
+    const unsigned long long pt1 = __builtin_readcyclecounter();
+#endif
     // ---- prologue of the pipeline: chunk 0 into buffer 0, chunk 1 into the registers.  BOTH chunks are requested before anything
     // waits (the accumulators are not live yet, so chunk 1 has registers to land in): one exposed memory latency per workgroup
     // instead of two -- with one workgroup per CU nothing else covers it, and a 64-channel layer has only 8 chunks to amortise it over
@@ -276,6 +282,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     // order (fillers between groups, behind every MFMA, the two waves of a SIMD in complementary phases) -- so the loop is built
     // for the fewest instructions, not for overlap: bare MFMA loop 1.95 ms, staging +0.85 ms (round-6 first form) for the
     // 512 -> 512 layer.
+#ifdef TAG_WF_PROF
+    const unsigned long long pt2 = __builtin_readcyclecounter();
+#endif
     f32x4 afP, bfP, afQ, bfQ;
 #define WF_M4(J, A_, B_)                                                                                     \
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
@@ -306,6 +315,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #undef WF_FRAG
 #undef WF_SB
 
+#ifdef TAG_WF_PROF
+    const unsigned long long pt3 = __builtin_readcyclecounter();
+#endif
 #if TAG_WF_ABL & 32
     if (acc[0][0] != 12345.678f) return;               // ablation: no epilogue at all (prologue + K loop only)
 #endif
@@ -322,6 +334,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     }
     __syncthreads();
 
+#ifdef TAG_WF_PROF
+    const unsigned long long pt4 = __builtin_readcyclecounter();
+#endif
     // ---- thread = (pixel, cout quad): add the halves, store, epilogue sums
     const int cq = tid & 15, slot = tid >> 4;
     const float* pk = smem + 4 * cq;
@@ -493,6 +508,13 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
             stats[(size_t)P * 3 * Cout + mt] = a;
         }
     }
+#ifdef TAG_WF_PROF
+    if (tid == 0 && (blockIdx.x == 1000 || blockIdx.x == 1001)) {
+        const unsigned long long pt5 = __builtin_readcyclecounter();
+        printf("wf prof block %d nch %d: setup %llu  prologue %llu  loop %llu (%llu per chunk)  park %llu  phase3+fold %llu  total %llu clocks\n", (int)blockIdx.x, nch,
+               pt1 - pt0, pt2 - pt1, pt3 - pt2, (pt3 - pt2) / nch, pt4 - pt3, pt5 - pt4, pt5 - pt0);
+    }
+#endif
 }
 
 template <int PRO, int EPI>

@@ -151,3 +151,50 @@ def test_pass_size_limit_is_reported_before_any_launch():
     ops.check_pass_size(300, 1001)
     with pytest.raises(RuntimeError, match="at most 33520 clips"):
         ops.check_pass_size(33521, 1001)
+
+
+def test_winograd_host_queries_and_dispatch_rule(monkeypatch):
+    """Host side of the fused Winograd path (no GPU): which shapes the C side serves, its row / workspace queries, and the dispatch
+    rule of ops.py (models/panns.py:29-38,49-50 run through it at the benched size)."""
+    from texttoaudiogrounding_amd import ops
+    q = ops.query
+    # channel counts that are multiples of 64: fused form (forward, dgrad and weight gradient) -- no planes, one row per 64-tile block
+    for (B, H, W, Ci, Co) in [(64, 250, 8, 512, 512), (64, 1001, 64, 64, 64), (3, 9, 7, 128, 192), (1, 1, 2, 64, 64)]:
+        assert q("tag_conv3x3_wino_ok", B, H, W, Ci, Co) == 1
+        T = B * ((H + 1) // 2) * ((W + 1) // 2)
+        assert q("tag_conv3x3_wino_stats_rows", B, H, W, Co) == (T + 63) // 64
+        assert q("tag_conv3x3_wino_ws_bytes", B, H, W, Ci, Co) <= 64
+        assert q("tag_conv3x3_wino_wgrad_can_reuse_v", B, H, W, Ci, Co) == 0
+        ws = q("tag_conv3x3_wino_wgrad_ws_bytes", B, H, W, Ci, Co)
+        shares, rem = divmod(ws, Ci * Co * 9 * 4)
+        assert rem == 0 and shares % 2 == 0 and 2 <= shares and (shares // 2) * (Ci // 64) * (Co // 64) <= 256   # S slices: <= one workgroup per CU
+    # the plane form keeps the other channel counts it always took; neither form takes these
+    assert q("tag_conv3x3_wino_ok", 2, 10, 8, 32, 32) == 1 and q("tag_conv3x3_wino_ws_bytes", 2, 10, 8, 32, 32) > 64
+    assert q("tag_conv3x3_wino_ok", 2, 10, 8, 48, 64) == 0 and q("tag_conv3x3_wino_ok", 2, 10, 8, 64, 2048) == 0
+    # a tensor of 2^31 bytes or more is refused (buffer descriptors): the caller cuts the batch
+    assert q("tag_conv3x3_wino_ok", 256, 750, 16, 256, 256) == 0 and q("tag_conv3x3_wino_ok", 32, 750, 16, 256, 256) == 1
+    cuts = ops._batch_chunks(256, 750 * 16 * 256 * 4)
+    assert cuts == [(0, 174), (174, 256)] and all(q("tag_conv3x3_wino_ok", b1 - b0, 750, 16, 256, 256) == 1 for b0, b1 in cuts)
+    # dispatch rule: fp32, widths 8 .. 64, both channel counts >= 64
+    assert ops._wino_shape(8, 512, 512) and ops._wino_shape(64, 64, 64) and ops._wino_shape(32, 64, 128)
+    assert not ops._wino_shape(4, 128, 128) and not ops._wino_shape(16, 32, 64) and not ops._wino_shape(128, 64, 64)
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16")
+    assert not ops._wino_shape(8, 512, 512)
+    monkeypatch.setattr(ops, "CONV_MATH", "fp32")
+    monkeypatch.setattr(ops, "CONV_WINOGRAD", False)
+    assert not ops._wino_shape(8, 512, 512)
+
+
+def test_developer_options_are_set_through_the_abi_not_the_environment():
+    """tag_set_option: known names are accepted, unknown ones refused with a message; no kernel source reads the environment."""
+    from texttoaudiogrounding_amd import lib
+    h = lib.load()
+    assert h.tag_set_option(b"gemm_big_min", 2048) == 0
+    assert h.tag_set_option(b"no_such_switch", 1) != 0 and b"no_such_switch" in h.tag_last_error()
+    csrc = os.path.join(ROOT, "texttoaudiogrounding_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    assert set(v[0] for v in lib._ENV_OPTIONS.values()) <= {"conv_impl", "halo_lds_pad", "halo_bn256", "wgrad_wgs", "conv_rows",
+                                                             "wgrad_dma", "x3_products", "gemm_big_min", "gru_tile4", "gru_xcd",
+                                                             "gru_coop", "mha_mfma"}

@@ -57,6 +57,9 @@ SHAPES = [(2, 10, 8, 64, 128, 1),      # whole tiles, 40-tile launch: ragged GEM
           (8, 64, 8, 512, 256, 1),     # 1024 tiles = whole 128-row GEMM tiles (the loader without tail handling)
           (2, 33, 32, 64, 128, 1),     # block 2's first conv (32-wide image, odd height), fused kernels (round 6)
           (1, 21, 64, 64, 64, 0),      # block 1's second conv (64-wide image, one 64-cout block)
+          (2, 1, 8, 64, 64, 1),        # one-pixel-high images: every tile hangs over the bottom edge (th = 1)
+          (1, 2, 16, 64, 1024, 0),     # the widest cout count the kernels take (16 cout blocks)
+          (1, 6, 8, 1024, 64, 1),      # the deepest K loop (128 chunks) and the full scale / shift staging area
           (3, 10, 16, 128, 192, 1)]    # 192 couts = three 64-cout blocks; 120 tiles: a ragged last tile block
 
 

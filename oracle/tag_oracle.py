@@ -983,8 +983,9 @@ def _wino_tiles(x):
 
 
 def winograd_conv3x3(x, w):
-    """y = conv2d(x, w, padding=1) as  A^T [ (G g G^T) (.) (B^T d B) ] A  per 2 x 2 output tile (csrc/conv_wino.hip:
-    wino_pack_kernel, wino_input_kernel, the 16 products, wino_output_kernel).  x (B,Cin,H,W), w (Cout,Cin,3,3)."""
+    """y = conv2d(x, w, padding=1) as  A^T [ (G g G^T) (.) (B^T d B) ] A  per 2 x 2 output tile (csrc/conv_wino_fused.hip:
+    wino_fused_kernel forms the same four stages inside one launch; csrc/conv_wino.hip: wino_pack_kernel, wino_input_kernel, the 16
+    products, wino_output_kernel).  x (B,Cin,H,W), w (Cout,Cin,3,3)."""
     Bt, G, At = _wino_mats(x)
     B, _, H, W = x.shape
     U = torch.einsum("ri,ocij,sj->ocrs", G, w, G)                     # (Cout,Cin,4,4)
@@ -997,7 +998,8 @@ def winograd_conv3x3(x, w):
 
 def winograd_conv3x3_wgrad(x, dy):
     """dL/dw of y = conv2d(x, w, padding=1) given dL/dy:  G^T [ sum over tiles (A dY A^T) (.) (B^T d B) ] G  -- the adjoint of
-    winograd_conv3x3 in w (csrc/conv_wino.hip: wino_dy_kernel, the K-sliced products, wino_wgrad_finish_kernel)."""
+    winograd_conv3x3 in w (csrc/conv_wino_fused.hip: wino_fused_wgrad_kernel; csrc/conv_wino.hip: wino_dy_kernel, the K-sliced products,
+    wino_wgrad_finish_kernel)."""
     Bt, G, At = _wino_mats(x)
     B, Co, H, W = dy.shape
     th, tw = (H + 1) // 2, (W + 1) // 2

@@ -32,6 +32,9 @@
 // (slice, xi half) are folded in a fixed order by wino_fused_wgrad_finish_kernel.
 #include "conv_wino.h"
 
+#ifndef TAG_WG_ABL
+#define TAG_WG_ABL 0        // weight-gradient ablations: bit 0 no tile advance, bit 1 no gradient transform, bit 2 no input transform
+#endif
 #ifndef TAG_WF_ABL
 #define TAG_WF_ABL 0        // ablation builds (tools/wino_fused_abl.sh; results wrong by construction): bit 0 no x loads in the K loop,
 #endif                      // bit 1 no U loads, bit 2 no transform VALU (raw rows stored), bit 3 no LDS stores (values kept alive), bit 4 no barrier, bit 5 no epilogue, bit 6 no epilogue sums, bit 7 no output stores, bits 8 / 9 x / U loads always of chunk 0
@@ -162,16 +165,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     const int aoff = FBUF + 8 * hh * FPL + (wm * 32 + ml) * 8 + fsw;          // U fragment (A operand)
     const int boff = 8 * hh * FPL + (wn * 32 + ml) * 8 + fsw;                 // V fragment (B operand)
 
-    if (PRO != 0) {
-        for (int i = tid; i < Cin; i += 512) { smem[FSS + i] = in_scale[i]; smem[FSS + Cin + i] = in_shift[i]; }
-    }
-
     f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
     f32x4 xr[4], ur[4];
     auto load_x = [&](int c, int r) {
         xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[r], c * 32, 0));
@@ -260,6 +254,14 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
             x1[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[r], c1 * 32, 0));
             u1[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uo0 + r * (4 * 64 * 8 * 4), (ublk + c1) * (16 * 64 * 8 * 4), 0));
         }
+        // (behind the requests, not in front of them: the scale / shift round trip and the zero fill run under the chunks' latency)
+        if (PRO != 0) {
+            for (int i = tid; i < Cin; i += 512) { smem[FSS + i] = in_scale[i]; smem[FSS + Cin + i] = in_shift[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         __syncthreads();                               // (the producer scale / shift are in LDS)
         ld_ss(0);
 #pragma unroll
@@ -602,6 +604,9 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         tb = __builtin_amdgcn_readfirstlane(tb); ti = __builtin_amdgcn_readfirstlane(ti); tj = __builtin_amdgcn_readfirstlane(tj);
     }
     auto advance = [&]() {                            // + 8 tiles
+#if TAG_WG_ABL & 1
+        return;                                        // ablation: the same tile every chunk (no scalar geometry update)
+#endif
         tj += 8;
         while (tj >= tw) { tj -= tw; ++ti; }
         while (ti >= th) { ti -= th; ++tb; }
@@ -662,8 +667,12 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         tt[3] = d[1] - d[3];
     };
     auto v_write = [&](float* Vb, int r) {
+#if TAG_WG_ABL & 4
+        vv = xr[r];                                    // ablation: no input transform
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+#endif
         *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
     };
     auto g_rows = [&]() {                              // R = A g (the thread's gradient column)
@@ -673,8 +682,12 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         R[3] = -gr[1];
     };
     auto d_write = [&](float* Db, int r) {
+#if TAG_WG_ABL & 2
+        vv = gr[r & 1];                                // ablation: no gradient transform
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) vv[k] = fmaf(cb, dpp_quad_0033(R[r][k]), R[r][k]);
+#endif
         *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
     };
     auto rotate_ok = [&]() {

@@ -520,7 +520,7 @@ def main():
     # (they overlap the dgrad/BatchNorm chain), which stretches every overlapped kernel's own start-to-end time;
     # a second, untimed pass of the same K steps with that overlap switched off gives the isolated kernel rate.
     fam = families(prof)
-    overlap = ops.side_stream_enabled()         # auto: off for the fp32-accurate arithmetics, on in the bf16 mode (ops.py)
+    overlap = ops.side_stream_enabled()         # auto: off for the fp32-accurate arithmetics, on in the bf16 mode (settings.py)
     side_setting = ops.WGRAD_SIDE_STREAM
     fam_iso = fam
     if overlap:

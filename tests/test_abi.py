@@ -155,7 +155,7 @@ def test_pass_size_limit_is_reported_before_any_launch():
 
 def test_winograd_host_queries_and_dispatch_rule(monkeypatch):
     """Host side of the fused Winograd path (no GPU): which shapes the C side serves, its row / workspace queries, and the dispatch
-    rule of ops.py (models/panns.py:29-38,49-50 run through it at the benched size)."""
+    rule of dispatch.py (models/panns.py:29-38,49-50 run through it at the benched size)."""
     from texttoaudiogrounding_amd import ops
     q = ops.query
     # channel counts that are multiples of 64: fused form (forward, dgrad and weight gradient) -- no planes, one row per 64-tile block

@@ -67,7 +67,7 @@ def _one_rank_group():
 
 
 def test_rccl_buckets_in_flight_beside_cooperative_gru_backward(dev):
-    """The ordering DESIGN.md section 5 relies on (ops.py: the fc1 / GRU bucket is announced right after the persistent
+    """The ordering DESIGN.md section 5 relies on (functions.py: the fc1 / GRU bucket is announced right after the persistent
     cooperative GRU backward is ENQUEUED): with a real RCCL communicator the bucket collectives are issued from inside
     backward on the communication stream while the spinning GRU workgroups and the side-stream wgrad kernels are in flight.
     Asserted over 3 steps at a size whose GRU runs the cooperative kernels (B = 16, 10 s clips): no exchange timeout / hang,

@@ -1,7 +1,7 @@
 """Winograd F(2x2,3x3) form of the deep-layer convolutions (csrc/conv_wino.hip; models/panns.py:29-38,49-50) against an fp64
 convolution: forward with every producer prologue and the fused BatchNorm batch statistics, dgrad with the fused
 BatchNorm+ReLU-backward sums, odd heights / widths (tiles that hang over the image), tile counts that do and do not fill the
-GEMM tiles, and the dispatch rule of ops.py (which launches take this path).  Tolerances: 5e-6 of the output range -- the
+GEMM tiles, and the dispatch rule of dispatch.py (which launches take this path).  Tolerances: 5e-6 of the output range -- the
 direct fp32 kernel's own bound in tests/test_gpu_kernels.py (measured: 1e-6, against 2e-6 ... 4e-6 of the direct kernel at 512
 input channels: 16 chains of Cin products round less than one chain of 9 Cin)."""
 import math

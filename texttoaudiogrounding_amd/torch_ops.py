@@ -24,7 +24,7 @@ import torch
 from torch import Tensor
 from torch.library import custom_op, register_autograd
 
-from . import ops
+from . import engine, ops
 
 __all__ = ["OP_NAMES"]
 
@@ -458,11 +458,11 @@ def run_encoder(op, mod, waveform, params):
     """Front door of the two encoder modules: calls ``op`` with the caller's grad mode made visible to the engine (inside an
     operator grad mode is always off) and the module's token."""
     need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    prev, ops._RECORDING = ops._RECORDING, torch.is_grad_enabled()
+    prev, engine._RECORDING = engine._RECORDING, torch.is_grad_enabled()
     try:
         return op(waveform, list(params), encoder_token(mod), need)
     finally:
-        ops._RECORDING = prev
+        engine._RECORDING = prev
         # setup_context has taken the saved state by now; if it was skipped (the dispatcher decided that no input needs a
         # gradient) the slot must not keep GBs of activations alive until the next forward
         _ENC_HANDOVER[0] = None

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import tag_oracle as O
 from tests.test_gpu_path import build_hip_model
-from texttoaudiogrounding_amd import ops
+from texttoaudiogrounding_amd import functions, ops
 from texttoaudiogrounding_amd.lib import query
 from texttoaudiogrounding_amd.runner import StrongRunner
 dev = torch.device("cuda:0")
@@ -19,7 +19,7 @@ for on in (0, 1):
     st = O.init_state(seed=5, logit_gain=120.0)
     batch = O.synthetic_batch(64, 320000, seed=99, ragged=True)
     seeds = iter(int(v) for v in gold["dropout_seeds"])
-    ops.new_seed = lambda: next(seeds)
+    functions.new_seed = lambda: next(seeds)
     model = build_hip_model(st, "dot", dev).train()
     runner = StrongRunner(model, device=str(dev))
     loss = runner.forward_backward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})

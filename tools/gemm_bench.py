@@ -31,9 +31,10 @@ def rec(A, Bm, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     return orig(A, Bm, M, N, K, transA, transB, lda, ldb, out, ldc, bias, act, accumulate)
 
 
-ops.gemm = rec
+from texttoaudiogrounding_amd import dispatch, functions  # noqa: E402
+dispatch.gemm = functions.gemm = rec           # (patched where the launches look it up)
 runner.train_step(batch)
-ops.gemm = orig
+dispatch.gemm = functions.gemm = orig
 torch.cuda.synchronize()
 
 

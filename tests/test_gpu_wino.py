@@ -322,3 +322,34 @@ def test_wino_dispatch_rule(ops, dev, monkeypatch):
     assert not hasattr(wf4, "wino_u")
     wfs, _ = ops.pack_conv_weight(w[:32, :32].contiguous(), W=W)         # 32 channels: direct
     assert not hasattr(wfs, "wino_u")
+
+
+def test_inference_batch_cuts_give_the_same_rows(ops, dev, monkeypatch):
+    """The inference launches are cut into batch slices that keep every tensor inside the fused kernels' 32-bit descriptor range
+    (ops.WINO_MAX_BYTES; at 30 s x 256 clips the 64-channel tensors are 4 x that range).  Any cut gives the same rows bit for bit
+    -- every tile is computed independently of the others -- for the plain forward and for the forward with the BatchNorm / ReLU /
+    pool epilogue; a limit that forces ragged slices (5 clips as 2 + 2 + 1) is compared with the uncut launch."""
+    B, H, W, Cin, Cout = 5, 21, 16, 64, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+    s, t = (torch.rand(Cin, generator=g) + 0.5).to(dev), (0.3 * torch.randn(Cin, generator=g)).to(dev)
+    st = ops.BNStat()
+    st.scale, st.shift, st.train = (torch.rand(Cout, generator=g) + 0.5).to(dev), (0.3 * torch.randn(Cout, generator=g)).to(dev), False
+    wf, _ = ops.pack_conv_weight(w, want_dgrad=False, W=W)
+    assert hasattr(wf, "wino_u")
+    n0 = ops.WINO_LAUNCHES
+    y1, _ = ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=False, inference=True)
+    p1 = ops.conv3x3_bnrelu_pool_eval(x, wf, Cout, st, 2, 2, 1, s, t)
+    assert ops.WINO_LAUNCHES == n0 + 2
+    per_clip = H * W * max(Cin, Cout) * 4
+    monkeypatch.setattr(ops, "WINO_MAX_BYTES", 2 * per_clip + 17)
+    assert ops._batch_chunks(B, per_clip) == [(0, 2), (2, 4), (4, 5)]
+    y2, _ = ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=False, inference=True)
+    p2 = ops.conv3x3_bnrelu_pool_eval(x, wf, Cout, st, 2, 2, 1, s, t)
+    assert torch.equal(y1, y2) and torch.equal(p1, p2)
+    monkeypatch.setattr(ops, "WINO_MAX_BYTES", 1)            # below one clip: one clip per launch, never zero
+    y3, _ = ops.conv3x3_stats(x, wf, Cout, 1, s, t, want_stats=False, inference=True)
+    assert torch.equal(y1, y3)
+    ref = F.conv2d(prologue64(nchw(x.cpu()).double(), 1, s.cpu().double(), t.cpu().double()), w.cpu().double(), padding=1)
+    assert relerr(nchw(y1), ref) < 5e-6

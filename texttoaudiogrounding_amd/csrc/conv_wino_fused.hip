@@ -548,7 +548,7 @@ void launch_fused(const float* x, const float* U, const float* s, const float* t
 // instead of one ds_read_b128 -- reads cost the MFMA stream ~1 clock each, a transposing store would be 32-bit LDS writes, the
 // one form that waits for gaps in the matrix pipe).  Column 3 of both V and D is stored negated (their product is unchanged).
 // Each wave folds its 8 sets to its share of the 3 x 3 filter and writes it to part[slice][half][co][ci][9];
-// wino_fused_wgrad_finish_kernel adds the 2 S shares in a fixed order.
+// wino_fused_wgrad_finish_kernel<Q> adds the 2 S shares in a fixed order.
 struct WgGeom { int th, tw; long T; int nci, nco, S, cps; };
 inline WgGeom wg_geom(int B, int H, int W, int Cin, int Cout) {
     WgGeom g;
@@ -779,12 +779,34 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     }
 }
 
-// dw (Cout,Cin,3,3) = the 2 S shares added in a fixed order; one thread per 4 consecutive floats
+// dw (Cout,Cin,3,3) = the 2 S shares added in a fixed order; 4 consecutive floats per thread group.  The small filters have the
+// MOST shares (64 x 64: 512 shares of 9216 float4): there Q = 4 or 16 threads split the share axis of one float4 into contiguous
+// runs (each run added in order, the Q run sums added in order through LDS) so that the launch still fills the chip -- a single
+// thread per float4 left 36 workgroups walking 512 dependent loads each.
+template <int Q>
 __global__ __launch_bounds__(256) void wino_fused_wgrad_finish_kernel(const float* __restrict__ part, int nshare, long n4, float* __restrict__ dw) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    constexpr int E = 256 / Q;
+    __shared__ f32x4 run[Q > 1 ? 256 : 1];
+    const int el = threadIdx.x % E, q = threadIdx.x / E;
+    const int per = (nshare + Q - 1) / Q;
+    const int p0 = q * per, p1 = (p0 + per < nshare) ? p0 + per : nshare;
+    for (long e0 = (long)blockIdx.x * E; e0 < n4; e0 += (long)gridDim.x * E) {
+        const long e = e0 + el;
         f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int p = 0; p < nshare; ++p) a += *reinterpret_cast<const f32x4*>(part + ((size_t)p * n4 + e) * 4);
-        *reinterpret_cast<f32x4*>(dw + e * 4) = a;
+        if (e < n4)
+            for (int p = p0; p < p1; ++p) a += *reinterpret_cast<const f32x4*>(part + ((size_t)p * n4 + e) * 4);
+        if (Q == 1) {
+            if (e < n4) *reinterpret_cast<f32x4*>(dw + e * 4) = a;
+        } else {
+            run[threadIdx.x] = a;
+            __syncthreads();
+            if (q == 0 && e < n4) {
+#pragma unroll
+                for (int k = 1; k < Q; ++k) a += run[k * E + el];
+                *reinterpret_cast<f32x4*>(dw + e * 4) = a;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -846,6 +868,9 @@ int wino_fused_wgrad_run(const float* x, int pro, const float* s, const float* t
     }
 #undef WG_CASE
     const long n4 = (long)Cin * Cout * 9 / 4;
-    hipLaunchKernelGGL(wino_fused_wgrad_finish_kernel, dim3(cdiv(n4, 256) > 2048 ? 2048 : cdiv(n4, 256)), dim3(256), 0, st, ws, 2 * g.S, n4, dw);
+    const auto blocks = [&](int e) { const long b = cdiv(n4, (long)e); return dim3((unsigned)(b > 4096 ? 4096 : b)); };
+    if (n4 >= 131072 || g.S < 8) hipLaunchKernelGGL(wino_fused_wgrad_finish_kernel<1>, blocks(256), dim3(256), 0, st, ws, 2 * g.S, n4, dw);
+    else if (n4 >= 32768 || g.S < 32) hipLaunchKernelGGL(wino_fused_wgrad_finish_kernel<4>, blocks(64), dim3(256), 0, st, ws, 2 * g.S, n4, dw);
+    else hipLaunchKernelGGL(wino_fused_wgrad_finish_kernel<16>, blocks(16), dim3(256), 0, st, ws, 2 * g.S, n4, dw);
     return 0;
 }

@@ -103,3 +103,33 @@ def test_partial_checkpoint_reinitialises_missing_modules_only(tmp_path):
     a, b = model.state_dict(), back.state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a if "audio_proj" not in k)
     assert torch.isfinite(back.model.audio_proj.weight).all() and back.model.audio_proj.weight.abs().max() < 1.0
+
+
+def test_single_missing_key_does_not_reset_the_rest_of_its_module(tmp_path):
+    """A checkpoint that lacks ONE tensor of a module (a BatchNorm bias, a Linear bias): only that tensor is re-initialised; the
+    module's other tensors -- the BatchNorm running statistics among them -- are the checkpoint's, bit for bit."""
+    import safetensors.torch as st
+    from texttoaudiogrounding_amd.models.hf_modeling_grounding import (Cnn8RnnLaionClapGroundingConfig,
+                                                                      Cnn8RnnLaionClapGroundingModel)
+    torch.manual_seed(1)
+    model = Cnn8RnnLaionClapGroundingModel(Cnn8RnnLaionClapGroundingConfig(text_config=TINY))
+    with torch.no_grad():
+        bn = model.model.audio_encoder.conv_block2.bn1
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-1, 1)
+        model.model.audio_proj.bias.uniform_(-1, 1)
+    model.save_pretrained(tmp_path)
+    f = os.path.join(tmp_path, "model.safetensors")
+    gone = {"model.audio_encoder.conv_block2.bn1.bias", "model.audio_proj.bias"}
+    full = st.load_file(f)
+    assert gone <= set(full)
+    st.save_file({k: v for k, v in full.items() if k not in gone}, f, metadata={"format": "pt"})
+    back = Cnn8RnnLaionClapGroundingModel.from_pretrained(tmp_path)
+    a, b = model.state_dict(), back.state_dict()
+    diff = [k for k in a if not torch.equal(a[k], b[k])]
+    assert set(diff) <= gone, diff
+    assert torch.equal(b["model.audio_encoder.conv_block2.bn1.bias"], torch.zeros(128))        # PyTorch's default for the missing one
+    assert torch.isfinite(b["model.audio_proj.bias"]).all()
+

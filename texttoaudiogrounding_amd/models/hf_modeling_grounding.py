@@ -225,7 +225,14 @@ class Cnn8RnnLaionClapGroundingModel(_ModelBase):
         if getattr(self, "_tag_constructing", False):
             return                              # fresh construction: the constructors' initialisation stands, as in the reference
         if isinstance(module, (nn.Linear, nn.Embedding, nn.LayerNorm, nn.BatchNorm2d, nn.GRU, nn.Conv2d)):
+            # a module with ONE missing key (a LayerNorm bias, a BatchNorm counter) is handed over whole: what the checkpoint did
+            # deliver (transformers marks loaded tensors ``_is_hf_initialized``) survives the reset
+            own = list(module.parameters(recurse=False)) + [b for b in module.buffers(recurse=False) if b is not None]
+            loaded = [(t, t.detach().clone()) for t in own if getattr(t, "_is_hf_initialized", False)]
             module.reset_parameters()
+            with torch.no_grad():
+                for t, v in loaded:
+                    t.copy_(v)
 
     if not _HAVE_TRANSFORMERS:
         @property

@@ -30,6 +30,7 @@
 // wino_fused_wgrad_kernel: dw = G^T [ sum_t (A dY A^T) (.) (B^T d B) ] G with BOTH transforms formed at staging: 64 ci x 64 co x
 // 16 xi accumulators per workgroup, K = tiles in chunks of 8, split over S slices of the tile axis; partial 3 x 3 filters per
 // (slice, xi half) are folded in a fixed order by wino_fused_wgrad_finish_kernel.
+#include <type_traits>
 #include "conv_wino.h"
 
 #ifndef TAG_WG_ABL
@@ -65,15 +66,27 @@ __device__ __forceinline__ f32x4 fused_prologue(f32x4 v, f32x4 s, f32x4 t) {    
     return v;
 }
 
-// v + c * (the value v has in lane {2, 2, 1, 1}[s] / {0, 0, 3, 3}[s] of the quad).  (A hand-written v_fmac_f32_dpp -- one instruction
-// per value instead of hipcc's v_mov_b32_dpp + v_fma_f32 -- was tried: the scalar asm operands cost three register copies per value
-// on the way from the transform to the 16-byte LDS store, 96 v_mov per chunk in the weight-gradient kernel.)
-__device__ __forceinline__ float dpp_quad_2211(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_quad_0033(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF0, 0xF, 0xF, true));
-}
+// v[k] += f * (the value v[k] has in lane {2, 2, 1, 1}[s] / {0, 0, 3, 3}[s] of the quad), in place, as ONE v_fmac_f32_dpp per value:
+// for the same expression the compiler selects v_mov_b32_dpp + v_fma_f32 / v_pk_fma_f32 (it has no DPP form of the three-address
+// fma), and beside the fp32 MFMA every VALU instruction is matrix time.  All four values of a 16-byte LDS store go through ONE asm
+// statement (an earlier per-value form cost three register copies per value on the way to the store: 96 v_mov per chunk in the
+// weight-gradient kernel; this one 3-4 per chunk).  s_nop 1: a DPP read needs two wait states after the VALU write of its source,
+// and the hazard recogniser does not look inside inline assembly.
+#define TAG_QUAD_FMAC(NAME, PERM)                                                                                             \
+    __device__ __forceinline__ void NAME(f32x4& v, float f) {                                                                \
+        float a = v[0], b = v[1], c = v[2], d = v[3];                                                                        \
+        asm("s_nop 1\n\t"                                                                                                    \
+            "v_fmac_f32_dpp %0, %0, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
+            "v_fmac_f32_dpp %1, %1, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
+            "v_fmac_f32_dpp %2, %2, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
+            "v_fmac_f32_dpp %3, %3, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1"                            \
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d)                                                                             \
+            : "v"(f));                                                                                                       \
+        v = (f32x4){a, b, c, d};                                                                                             \
+    }
+TAG_QUAD_FMAC(quad_fmac_2211, "[2,2,1,1]")
+TAG_QUAD_FMAC(quad_fmac_0033, "[0,0,3,3]")
+#undef TAG_QUAD_FMAC
 
 // the wave's share of the 2 x 2 outputs from its 8 accumulator sets (xi = 4 r + s, r = 2 HH + {0, 1}), register quad rq
 template <int HH>
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     const int hh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int kl = lane >> 5, ml = lane & 31;
     const int fsw = (kl ^ ((ml >> 3) & 1)) << 2;
-    const int aoff = FBUF + 8 * hh * FPL + (wm * 32 + ml) * 8 + fsw;          // U fragment (A operand)
+    const int aoff = 2 * FBUF + 8 * hh * FPL + (wm * 32 + ml) * 8 + fsw;      // U fragment (A operand); LDS = [V0 | V1 | U0 | U1]
     const int boff = 8 * hh * FPL + (wn * 32 + ml) * 8 + fsw;                 // V fragment (B operand)
 
     f32x16 acc[8];
@@ -203,8 +216,8 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     };
     auto v_row = [&](int r) {                          // row transform (. B): one quad-permute exchange per value
         if (TAG_WF_ABL & 4) return;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+        vv = tt[r];
+        quad_fmac_2211(vv, fb);
     };
     auto v_write = [&](float* Vb, int r) {
 #if TAG_WF_ABL & 4
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) x_col(r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v_row(r); v_write(smem, r); u_write(smem + FBUF, r); }
+        for (int r = 0; r < 4; ++r) { v_row(r); v_write(smem, r); u_write(smem + 2 * FBUF, r); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { xr[r] = x1[r]; ur[r] = u1[r]; }
         ld_ss(c1);
@@ -287,6 +300,9 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
 #ifdef TAG_WF_PROF
     const unsigned long long pt2 = __builtin_readcyclecounter();
 #endif
+    // The loop body exists twice, once per pipeline stage: the stage offsets are then immediates of the LDS instructions (the four
+    // operand buffers are laid out [V0 | V1 | U0 | U1] so that every toggle, 33,280 B, fits the 16-bit offset field) and a chunk
+    // costs no address arithmetic -- it was 5 vector adds per wave and chunk, each ~3 clocks of matrix time.
     f32x4 afP, bfP, afQ, bfQ;
 #define WF_M4(J, A_, B_)                                                                                     \
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
@@ -295,9 +311,10 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     A_ = *reinterpret_cast<const f32x4*>(cur + aoff + (J) * FPL);                                            \
     B_ = *reinterpret_cast<const f32x4*>(cur + boff + (J) * FPL)
 #define WF_SB __builtin_amdgcn_sched_barrier(0)
-    for (int c = 0; c < nch; ++c) {
-        const float* cur = smem + (c & 1) * 2 * FBUF;
-        float* nxt = smem + ((c + 1) & 1) * 2 * FBUF;
+    auto chunk = [&](int c, auto stage) {
+        constexpr int ST = decltype(stage)::value;
+        const float* cur = smem + ST * FBUF;           // V of this chunk; its U is 2 FBUF further (aoff)
+        float* nxt = smem + (1 - ST) * FBUF;
         const int c2 = c + 2 < nch ? c + 2 : nch - 1;
         WF_SB;
         WF_FRAG(afP, bfP, 0); WF_SB;
@@ -305,13 +322,21 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
         WF_FRAG(afP, bfP, 2); WF_M4(1, afQ, bfQ); WF_SB; x_row(2); x_row(3); x_col(0); x_col(1); x_col(2); x_col(3); WF_SB;
         WF_FRAG(afQ, bfQ, 3); WF_M4(2, afP, bfP); WF_SB; v_row(0); v_write(nxt, 0); v_row(1); v_write(nxt, 1); lx(c2, 0); lx(c2, 1); WF_SB;
         WF_FRAG(afP, bfP, 4); WF_M4(3, afQ, bfQ); WF_SB; v_row(2); v_write(nxt, 2); v_row(3); v_write(nxt, 3); lx(c2, 2); lx(c2, 3); WF_SB;
-        WF_FRAG(afQ, bfQ, 5); WF_M4(4, afP, bfP); WF_SB; u_write(nxt + FBUF, 0); u_write(nxt + FBUF, 1); lu(c2, 0); lu(c2, 1); WF_SB;
-        WF_FRAG(afP, bfP, 6); WF_M4(5, afQ, bfQ); WF_SB; u_write(nxt + FBUF, 2); u_write(nxt + FBUF, 3); lu(c2, 2); lu(c2, 3); WF_SB;
+        WF_FRAG(afQ, bfQ, 5); WF_M4(4, afP, bfP); WF_SB; u_write(nxt + 2 * FBUF, 0); u_write(nxt + 2 * FBUF, 1); lu(c2, 0); lu(c2, 1); WF_SB;
+        WF_FRAG(afP, bfP, 6); WF_M4(5, afQ, bfQ); WF_SB; u_write(nxt + 2 * FBUF, 2); u_write(nxt + 2 * FBUF, 3); lu(c2, 2); lu(c2, 3); WF_SB;
         WF_FRAG(afQ, bfQ, 7); WF_M4(6, afP, bfP); WF_SB; ld_ss(c2); WF_SB;
         WF_M4(7, afQ, bfQ); WF_SB;
 #if !(TAG_WF_ABL & 16)
         __syncthreads();
 #endif
+    };
+    {
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < nch) chunk(c, std::integral_constant<int, 0>{});      // odd chunk count: the last chunk is in stage 0
     }
 #undef WF_M4
 #undef WF_FRAG
@@ -546,7 +571,8 @@ void launch_fused(const float* x, const float* U, const float* s, const float* t
 // by 8 tiles per chunk without a division; only the column validity needs a vector compare.  LDS images are k-major,
 // [xi][tile 8][channel 64] (16-byte stores from the channel-quad threads; fragments are four ds_read_b32 per operand and group
 // instead of one ds_read_b128 -- reads cost the MFMA stream ~1 clock each, a transposing store would be 32-bit LDS writes, the
-// one form that waits for gaps in the matrix pipe).  Column 3 of both V and D is stored negated (their product is unchanged).
+// one form that waits for gaps in the matrix pipe).  Column 3 of both V and D is stored negated (their product is unchanged);
+// row 3 of D too (-g1 would be an instruction per value; the products of row 3 come out negated and the fold subtracts them).
 // Each wave folds its 8 sets to its share of the 3 x 3 filter and writes it to part[slice][half][co][ci][9];
 // wino_fused_wgrad_finish_kernel<Q> adds the 2 S shares in a fixed order.
 struct WgGeom { int th, tw; long T; int nci, nco, S, cps; };
@@ -587,12 +613,12 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     const int s = tid & 3, quad = (tid >> 2) & 15;
     const float fb = s == 1 ? 1.0f : -1.0f;                       // V[r][s] = tt[r][s] + fb tt[r][{2,2,1,1}[s]]  (column 3 negated)
     const float cb = s == 1 ? 1.0f : (s == 2 ? -1.0f : 0.0f);     // D[r][s] = R[r][s & 1] + cb R[r][{0,0,3,3}[s] & 1] (column 3 negated)
-    // descriptors: x one pixel early, so that the window column 2 j - 1 of a tile is a non-negative offset from (row, 2 j)
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - Cin, 0, (int)(((size_t)B * H * W + 1) * Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)((size_t)B * H * W * Cout * 4), 0x00020000);
+    // descriptors: x one pixel early, so that the window column 2 j - 1 of a tile is a non-negative offset from (row, 2 j); a row
+    // outside the image gets the same descriptor with ZERO records (a scalar select: every load of the row comes back as zeros)
+    const int xbytes = (int)(((size_t)B * H * W + 1) * Cin * 4), dbytes = (int)((size_t)B * H * W * Cout * 4);
     const unsigned xvo = (unsigned)((s * Cin + cib * 64 + 4 * quad) * 4);
     const unsigned dvo = (unsigned)(((s & 1) * Cout + cob * 64 + 4 * quad) * 4);
-    const int vw0 = s * FPL + wave * 64 + 4 * quad;               // + 4 r FPL  (V image; the D image is FBUF further)
+    const int vw0 = s * FPL + wave * 64 + 4 * quad;               // + 4 r FPL  (V image; the D image is 2 FBUF further)
     // tile of this wave in the chunk being LOADED (uniform): image b, tile row i, tile column j
     int tb, ti, tj;
     {
@@ -621,7 +647,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     const int hh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int kl = lane >> 5, ml = lane & 31;
     const int aoff = 8 * hh * FPL + kl * 64 + wm * 32 + ml;             // V fragment (A operand: rows = ci); + xi FPL + 128 e
-    const int boff = FBUF + 8 * hh * FPL + kl * 64 + wn * 32 + ml;      // D fragment (B operand: columns = co)
+    const int boff = 2 * FBUF + 8 * hh * FPL + kl * 64 + wn * 32 + ml;  // D fragment (B operand: columns = co); LDS = [V0 | V1 | D0 | D1]
 
     f32x16 acc[8];
 #pragma unroll
@@ -631,22 +657,31 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
 
     f32x4 xr[4], gr[2];
     float okn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, okc[4];   // PRO != 0: upper clamp (+inf | 0) of the rows in flight / being transformed
+    unsigned xcol = 0x80000000u, gcol = 0x80000000u;   // vector offsets of the chunk being loaded (out of range = column outside the image)
+    float xclamp = 0.0f;
+    auto col_offsets = [&]() {                         // once per chunk, before its loads
+        const bool cx = (unsigned)(2 * tj - 1 + s) < (unsigned)W;
+        xcol = cx ? xvo : 0x80000000u;
+        gcol = (2 * tj + (s & 1)) < W ? dvo : 0x80000000u;
+        if (PRO != 0) xclamp = cx ? INFINITY : 0.0f;
+    };
     auto load_x = [&](int r) {                         // window row r of the tile (tb, ti, tj)
         const int h = 2 * ti - 1 + r;
         const bool rv = tb < B && (unsigned)h < (unsigned)H;
-        const bool ok = rv && (unsigned)(2 * tj - 1 + s) < (unsigned)W;
-        // (32-bit scalar arithmetic: the tensor is < 2^31 bytes; for rows outside the image the offset is never used -- every lane
-        // of the wave then carries the out-of-range vector offset)
-        const int so = (int)(((unsigned)(tb * H + h) * (unsigned)W + 2u * (unsigned)tj) * (unsigned)(Cin * 4));
-        xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xvo : 0x80000000u, so, 0));
-        if (PRO != 0) okn[r] = ok ? INFINITY : 0.0f;
+        // (32-bit scalar arithmetic: the tensor is < 2^31 bytes.)  A row outside the image is a WAVE-uniform condition: it selects an
+        // EMPTY descriptor on the scalar unit (every load comes back as zeros); only the column test is a vector select, once per
+        // chunk (xcol), not once per row
+        const int so = (int)(((unsigned)(tb * H + h) * (unsigned)W + 2u * (unsigned)tj) * (unsigned)(Cin * 4));     // (unused when !rv)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - Cin, 0, rv ? xbytes : 0, 0x00020000);
+        xr[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xcol, so, 0));
+        if (PRO != 0) okn[r] = rv ? xclamp : 0.0f;
     };
     auto load_g = [&](int a) {                         // gradient row 2 ti + a, column 2 tj + (s & 1)
         const int h = 2 * ti + a;
         const bool rv = tb < B && h < H;
-        const bool ok = rv && (2 * tj + (s & 1)) < W;
         const int so = (int)(((unsigned)(tb * H + h) * (unsigned)W + 2u * (unsigned)tj) * (unsigned)(Cout * 4));
-        gr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok ? dvo : 0x80000000u, so, 0));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, rv ? dbytes : 0, 0x00020000);
+        gr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, gcol, so, 0));
     };
     f32x4 d[4], tt[4], R[4], vv;
     auto x_row = [&](int r) {
@@ -670,8 +705,8 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
 #if TAG_WG_ABL & 4
         vv = xr[r];                                    // ablation: no input transform
 #else
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(fb, dpp_quad_2211(tt[r][k]), tt[r][k]);
+        vv = tt[r];
+        quad_fmac_2211(vv, fb);
 #endif
         *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
     };
@@ -679,14 +714,14 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         R[0] = gr[0];
         R[1] = gr[0] + gr[1];
         R[2] = gr[0] - gr[1];
-        R[3] = -gr[1];
+        R[3] = gr[1];                                  // (row 3 of D is stored NEGATED: no instruction here, a sign in the fold below)
     };
     auto d_write = [&](float* Db, int r) {
 #if TAG_WG_ABL & 2
         vv = gr[r & 1];                                // ablation: no gradient transform
 #else
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = fmaf(cb, dpp_quad_0033(R[r][k]), R[r][k]);
+        vv = R[r];
+        quad_fmac_0033(vv, cb);
 #endif
         *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
     };
@@ -701,6 +736,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     {
         f32x4 x0[4], g0[2];
         float ok0[4];
+        col_offsets();
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_x(r);
         load_g(0); load_g(1);
@@ -708,6 +744,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) { x0[r] = xr[r]; ok0[r] = okn[r]; }
         g0[0] = gr[0]; g0[1] = gr[1];
+        col_offsets();
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_x(r);         // chunk 1 (stays in xr / gr / okn for the first iteration)
         load_g(0); load_g(1);
@@ -722,7 +759,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         x_col();
         g_rows();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v_write(smem, r); d_write(smem + FBUF, r); }
+        for (int r = 0; r < 4; ++r) { v_write(smem, r); d_write(smem + 2 * FBUF, r); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { xr[r] = x1[r]; okn[r] = ok1[r]; }
         gr[0] = g1[0]; gr[1] = g1[1];
@@ -733,19 +770,29 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[aoff + (J) * FPL + 128 * e], cur[boff + (J) * FPL + 128 * e], acc[J], 0, 0, 0)
 #define WG_SB __builtin_amdgcn_sched_barrier(0)
-    for (int c = 0; c < cps; ++c) {
-        const float* cur = smem + (c & 1) * 2 * FBUF;
-        float* nxt = smem + ((c + 1) & 1) * 2 * FBUF;
+    // (two copies of the chunk body, one per pipeline stage: stage offsets as LDS-instruction immediates, as in the forward kernel)
+    auto chunk = [&](auto stage) {
+        constexpr int ST = decltype(stage)::value;
+        const float* cur = smem + ST * FBUF;
+        float* nxt = smem + (1 - ST) * FBUF;
         WG_SB;
         WG_M4(0); WG_SB; rotate_ok(); x_row(0); x_row(1); WG_SB;
         WG_M4(1); WG_SB; x_row(2); x_row(3); x_col(); WG_SB;
-        WG_M4(2); WG_SB; v_write(nxt, 0); v_write(nxt, 1); load_x(0); load_x(1); WG_SB;
+        WG_M4(2); WG_SB; v_write(nxt, 0); v_write(nxt, 1); col_offsets(); load_x(0); load_x(1); WG_SB;
         WG_M4(3); WG_SB; v_write(nxt, 2); v_write(nxt, 3); load_x(2); load_x(3); WG_SB;
-        WG_M4(4); WG_SB; g_rows(); d_write(nxt + FBUF, 0); d_write(nxt + FBUF, 1); WG_SB;
-        WG_M4(5); WG_SB; d_write(nxt + FBUF, 2); d_write(nxt + FBUF, 3); load_g(0); load_g(1); advance(); WG_SB;
+        WG_M4(4); WG_SB; g_rows(); d_write(nxt + 2 * FBUF, 0); d_write(nxt + 2 * FBUF, 1); WG_SB;
+        WG_M4(5); WG_SB; d_write(nxt + 2 * FBUF, 2); d_write(nxt + 2 * FBUF, 3); load_g(0); load_g(1); advance(); WG_SB;
         WG_M4(6); WG_SB;
         WG_M4(7); WG_SB;
         __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 1 < cps; c += 2) {
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+        }
+        if (c < cps) chunk(std::integral_constant<int, 0>{});
     }
 #undef WG_M4
 #undef WG_SB
@@ -762,7 +809,7 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
             for (int sx = 0; sx < 4; ++sx) {
                 const float m0 = acc[sx][4 * rq + k], m1 = acc[4 + sx][4 * rq + k];
                 if (hh == 0) { P[0][sx] = m0 + 0.5f * m1; P[1][sx] = 0.5f * m1; P[2][sx] = 0.5f * m1; }      // transform rows r = 0, 1
-                else { P[0][sx] = 0.5f * m0; P[1][sx] = -0.5f * m0; P[2][sx] = 0.5f * m0 + m1; }              // rows r = 2, 3
+                else { P[0][sx] = 0.5f * m0; P[1][sx] = -0.5f * m0; P[2][sx] = 0.5f * m0 - m1; }              // rows r = 2, 3 (m1 = -dU of row 3)
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {

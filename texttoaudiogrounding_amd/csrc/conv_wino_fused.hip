@@ -73,8 +73,8 @@ __device__ __forceinline__ f32x4 fused_prologue(f32x4 v, f32x4 s, f32x4 t) {    
 // weight-gradient kernel; this one 3-4 per chunk).  s_nop 1: a DPP read needs two wait states after the VALU write of its source,
 // and the hazard recogniser does not look inside inline assembly.
 #define TAG_QUAD_FMAC(NAME, PERM)                                                                                             \
-    __device__ __forceinline__ void NAME(f32x4& v, float f) {                                                                \
-        float a = v[0], b = v[1], c = v[2], d = v[3];                                                                        \
+    __device__ __forceinline__ void NAME(const float (&t)[4], float f, f32x4& v) {                                           \
+        float a = t[0], b = t[1], c = t[2], d = t[3];                                                                        \
         asm("s_nop 1\n\t"                                                                                                    \
             "v_fmac_f32_dpp %0, %0, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
             "v_fmac_f32_dpp %1, %1, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     auto load_u = [&](int c, int i) {
         ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uo0 + i * (4 * 64 * 8 * 4), (ublk + c) * (16 * 64 * 8 * 4), 0));
     };
-    f32x4 d[4], tt[4], vv;
+    f32x4 d[4], vv;
+    float tt[4][4];
     f32x4 psc = {1.0f, 1.0f, 1.0f, 1.0f}, psh = {0.0f, 0.0f, 0.0f, 0.0f};
     auto ld_ss = [&](int c) {
         if (PRO != 0) {
@@ -209,15 +210,17 @@ __global__ __launch_bounds__(512) void wino_fused_kernel(const float* __restrict
     };
     auto x_col = [&](int r) {                          // column transform (B^T d) of the thread's window column
         if (TAG_WF_ABL & 4) return;
-        if (r == 0) tt[0] = d[0] - d[2];
-        if (r == 1) tt[1] = d[1] + d[2];
-        if (r == 2) tt[2] = d[2] - d[1];
-        if (r == 3) tt[3] = d[1] - d[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                  // (element by element: a packed add would put two values into a register PAIR,
+            if (r == 0) tt[0][k] = d[0][k] - d[2][k];  //  and the row transform's in-place DPP instruction then needs copies out of it)
+            if (r == 1) tt[1][k] = d[1][k] + d[2][k];
+            if (r == 2) tt[2][k] = d[2][k] - d[1][k];
+            if (r == 3) tt[3][k] = d[1][k] - d[3][k];
+        }
     };
     auto v_row = [&](int r) {                          // row transform (. B): one quad-permute exchange per value
         if (TAG_WF_ABL & 4) return;
-        vv = tt[r];
-        quad_fmac_2211(vv, fb);
+        quad_fmac_2211(tt[r], fb, vv);
     };
     auto v_write = [&](float* Vb, int r) {
 #if TAG_WF_ABL & 4
@@ -683,7 +686,8 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, rv ? dbytes : 0, 0x00020000);
         gr[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, gcol, so, 0));
     };
-    f32x4 d[4], tt[4], R[4], vv;
+    f32x4 d[4], vv;
+    float tt[4][4], R[4][4];
     auto x_row = [&](int r) {
         if (PRO == 0) {
             d[r] = xr[r];
@@ -696,32 +700,36 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
         }
     };
     auto x_col = [&]() {
-        tt[0] = d[0] - d[2];
-        tt[1] = d[1] + d[2];
-        tt[2] = d[2] - d[1];
-        tt[3] = d[1] - d[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tt[0][k] = d[0][k] - d[2][k];
+            tt[1][k] = d[1][k] + d[2][k];
+            tt[2][k] = d[2][k] - d[1][k];
+            tt[3][k] = d[1][k] - d[3][k];
+        }
     };
     auto v_write = [&](float* Vb, int r) {
 #if TAG_WG_ABL & 4
         vv = xr[r];                                    // ablation: no input transform
 #else
-        vv = tt[r];
-        quad_fmac_2211(vv, fb);
+        quad_fmac_2211(tt[r], fb, vv);
 #endif
         *reinterpret_cast<f32x4*>(Vb + vw0 + 4 * r * FPL) = vv;
     };
     auto g_rows = [&]() {                              // R = A g (the thread's gradient column)
-        R[0] = gr[0];
-        R[1] = gr[0] + gr[1];
-        R[2] = gr[0] - gr[1];
-        R[3] = gr[1];                                  // (row 3 of D is stored NEGATED: no instruction here, a sign in the fold below)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R[0][k] = gr[0][k];
+            R[1][k] = gr[0][k] + gr[1][k];
+            R[2][k] = gr[0][k] - gr[1][k];
+            R[3][k] = gr[1][k];                        // (row 3 of D is stored NEGATED: no instruction here, a sign in the fold below)
+        }
     };
     auto d_write = [&](float* Db, int r) {
 #if TAG_WG_ABL & 2
         vv = gr[r & 1];                                // ablation: no gradient transform
 #else
-        vv = R[r];
-        quad_fmac_0033(vv, cb);
+        quad_fmac_0033(R[r], cb, vv);
 #endif
         *reinterpret_cast<f32x4*>(Db + vw0 + 4 * r * FPL) = vv;
     };

@@ -259,13 +259,13 @@ def query(name, *args):
 
 
 def csrc_sha256() -> str:
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, file names included, sorted): stored in the _meta of the PMC
-    traffic profiles (tools/pmc_traffic.py) so that bench.py can tell a profile collected on OTHER kernels from a current one."""
+    """sha256 over the kernel sources and their build flags (csrc/*.hip, csrc/*.h, csrc/Makefile; file names included, byte-sorted):
+    stored in the _meta of the PMC traffic profiles (tools/pmc_traffic.py) so that bench.py can tell a profile collected on OTHER kernels from a current one."""
     import glob
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + [os.path.join(src, "Makefile")]):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

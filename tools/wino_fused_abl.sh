@@ -4,7 +4,7 @@
 #   bash tools/wino_fused_abl.sh run "1 2 12 3 4" [bench args]   (GPU box) -> one line per variant
 set -e
 cd "$(dirname "$0")/../texttoaudiogrounding_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -fno-slp-vectorize"   # = csrc/Makefile for this file
 if [ "$1" = build ]; then
   OBJS=$(ls *.o | grep -v conv_wino_fused.o)
   for a in $2; do

@@ -17,9 +17,14 @@
 //     -- and ONE 4 x 4 (k x n) block of U per xi: 4 global loads, the transpose is register naming, 4 ds_write_b128.
 //   * LDS image of both operands: [xi][row 64][k 8] with the 16-byte slot XOR-ed by (row >> 3) & 1 and planes 2080 B apart: the
 //     fragment of four k-steps is ONE conflict-free ds_read_b128 per operand, and the 8 lanes of a ds_write_b128 group (same row,
-//     different xi / slot) cover 128 contiguous bytes.  Two buffers of (V + U) = 133 KB; one barrier per chunk.
+//     different xi / slot) cover 128 contiguous bytes.  Two stages of (V + U) = 133 KB; one barrier per chunk.
 //   * pipeline: global loads of chunk c+2 | transform + LDS writes of chunk c+1 | MFMAs of chunk c, the staging work cut into
-//     slices between the 8 MFMA groups of a chunk (sched_barrier keeps the slices where they are).
+//     slices between the 8 MFMA groups of a chunk (sched_barrier keeps the slices where they are).  Beside the fp32 MFMA every
+//     VALU instruction is matrix time (tools/coissue2_probe.hip), so the loop carries the MINIMUM of them: 16 + 16 for the two
+//     transforms of a thread's 16 values (the row transform is one in-place v_fmac_f32_dpp per value), nothing for addresses (the
+//     loop body exists once per pipeline stage, the four operand buffers lie [V0 | V1 | U0 | U1] and every stage offset is an
+//     immediate of the LDS instruction), no register copies (transforms written element by element, file built without the SLP
+//     vectoriser: csrc/Makefile).
 //   * epilogue: each wave reduces its 8 sets to its share of the 2 x 2 outputs (A^T . A is linear, the two xi halves add), parks
 //     it in LDS [half][pixel of the tile][tile][cout]; then thread = (pixel, cout quad): the two halves are added, y leaves with
 //     fully coalesced 16-byte stores and the epilogue sums are formed per thread, folded over the workgroup through LDS in a fixed

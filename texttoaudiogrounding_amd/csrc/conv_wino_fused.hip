@@ -779,9 +779,19 @@ __global__ __launch_bounds__(512) void wino_fused_wgrad_kernel(const float* __re
     }
     __syncthreads();
 
+    // Fragment addresses: the planes are 2080 B apart, i.e. 8 x 256 B + 32 B -- the 32 J bytes cannot ride in the offset field of
+    // ds_read2st64_b32 (units of 256 B), and the compiler re-added them to the base for every plane of every chunk (10 vector adds
+    // per wave and chunk).  The 16 plane bases are formed ONCE and made opaque, so that they stay in registers.
+    int aJ[8], bJ[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        aJ[j] = aoff + j * FPL;
+        bJ[j] = boff + j * FPL;
+        asm volatile("" : "+v"(aJ[j]), "+v"(bJ[j]));
+    }
 #define WG_M4(J)                                                                                              \
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[aoff + (J) * FPL + 128 * e], cur[boff + (J) * FPL + 128 * e], acc[J], 0, 0, 0)
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[aJ[J] + 128 * e], cur[bJ[J] + 128 * e], acc[J], 0, 0, 0)
 #define WG_SB __builtin_amdgcn_sched_barrier(0)
     // (two copies of the chunk body, one per pipeline stage: stage offsets as LDS-instruction immediates, as in the forward kernel)
     auto chunk = [&](auto stage) {

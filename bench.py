@@ -358,8 +358,11 @@ def workload_name(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 20 timed steps (0.7 s of the contract workload).  The first timed step starts on an idle queue -- the host has
+    # nothing enqueued ahead, so the GPU waits for launches (+1.5 ... 2.5 ms on that step, `step_ms.first`); a training job runs in
+    # the steady state, where the host is a step ahead.  With 5 steps that one step was 1 % of the mean.
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cross-encoder", action="store_true",

@@ -191,11 +191,12 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
     // split-K: all tiles of ONE K slice are neighbours -- they read the same A and B slices, and xcd_remap gives an XCD a
     // contiguous run of L, i.e. whole K slices whose operands are then fetched once into that XCD's L2 (the tile-major order
     // put the K slices of one tile side by side, which share nothing: 4 x the algorithmic fetch on the weight-gradient GEMMs)
+    L = __builtin_amdgcn_readfirstlane(L);     // (a function of blockIdx: said explicitly, so that tile origins and K ranges live on the scalar unit)
     const int split = L / (n_tiles * m_tiles);
     L -= split * (n_tiles * m_tiles);
-    const int n0 = (L % n_tiles) * T, m0 = (L / n_tiles) * T;
-    const int kbeg = split * kchunk;
-    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int n0 = __builtin_amdgcn_readfirstlane((L % n_tiles) * T), m0 = __builtin_amdgcn_readfirstlane((L / n_tiles) * T);
+    const int kbeg = __builtin_amdgcn_readfirstlane(split * kchunk);
+    const int kend = __builtin_amdgcn_readfirstlane((kbeg + kchunk < K) ? kbeg + kchunk : K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm0 = (wid >> 1) * (T / 2), wn0 = (wid & 1) * (T / 2);
     const int kl = lane >> 5, ml = lane & 31;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int kiters = (kend - kbeg + KCH - 1) / KCH;
+    const int kiters = __builtin_amdgcn_readfirstlane((kend - kbeg + KCH - 1) / KCH);
     auto ld = [&](auto& ra, auto& rb, int chunk) {
         // FAST loads carry no bounds tests: past the last chunk the last one is requested again (and never used)
         const int c = FAST ? (chunk < kiters ? chunk : kiters - 1) : chunk;
@@ -233,6 +234,105 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
             rb.store(Bs + buf * BSZ);
         }
     };
+    if constexpr (FAST && !BF && PD == 1) {
+        // Whole tiles on the exact-fp32 MFMA: beside it every VALU instruction and every load with a 64-bit vector address is matrix
+        // time (tools/coissue2_probe.hip: ~3 and ~24 clocks; a scalar-base buffer load ~7).  The operands therefore come through
+        // buffer descriptors at the TILE origin with one loop-invariant 32-bit vector offset per load and the K advance on the scalar
+        // unit, and the loop body exists once per LDS stage so that every stage offset is an immediate of the LDS instruction: a chunk
+        // carries no address arithmetic (it was 13-16 vector instructions, four of them 64-bit multiply-adds, beside 16 MFMAs).
+        constexpr int NLA = Stage<AKC, T, GKT>::NL, NLB = Stage<BKC, T, GKT>::NL;
+        constexpr int RQ = GKT / 4;
+        auto uniform = [](const float* ptr) {          // (the tile origin IS wave-uniform; said explicitly, or the descriptor is built in a waterfall loop)
+            const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+        };
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(uniform(AKC ? A + (size_t)m0 * lda : A + m0), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(uniform(BKC ? B + (size_t)n0 * ldb : B + n0), 0, 0x7FFFFFFF, 0x00020000);
+        unsigned voa[NLA], vob[NLB];
+        int wsa[NLA], wsb[NLB];                        // LDS offsets (floats) of the thread's pieces inside a stage
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (AKC) { const int r = idx / RQ, k = (idx % RQ) * 4; voa[i] = (unsigned)((r * lda + k) * 4); wsa[i] = r * LDSA + k; }
+            else { const int k = idx / (T / 4), r = (idx % (T / 4)) * 4; voa[i] = (unsigned)((k * lda + r) * 4); wsa[i] = k * LDSA + r; }
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (BKC) { const int r = idx / RQ, k = (idx % RQ) * 4; vob[i] = (unsigned)((r * ldb + k) * 4); wsb[i] = r * LDSB + k; }
+            else { const int k = idx / (T / 4), r = (idx % (T / 4)) * 4; vob[i] = (unsigned)((k * ldb + r) * 4); wsb[i] = k * LDSB + r; }
+        }
+        f32x4 ra[NLA], rb[NLB];
+        auto ldf = [&](int chunk) {                    // (past the last chunk the last one is requested again and never used)
+            const int k0 = kbeg + (chunk < kiters ? chunk : kiters - 1) * KCH;
+            const int soa = AKC ? k0 * 4 : k0 * lda * 4, sob = BKC ? k0 * 4 : k0 * ldb * 4;
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, voa[i], soa, 0));
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, vob[i], sob, 0));
+        };
+        auto stf = [&](float* as, float* bs) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) *reinterpret_cast<f32x4*>(as + wsa[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) *reinterpret_cast<f32x4*>(bs + wsb[i]) = rb[i];
+        };
+        const int afr = AKC ? (wm0 + ml) * LDSA + kl * 4 : (kl * 4) * LDSA + wm0 + ml;
+        const int bfr = BKC ? (wn0 + ml) * LDSB + kl * 4 : (kl * 4) * LDSB + wn0 + ml;
+        auto step = [&](int it, auto stage) {
+            constexpr int ST = decltype(stage)::value;
+            const float* a = As + ST * ASZ + afr;
+            const float* b = Bs + ST * BSZ + bfr;
+            ldf(it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto frag_a = [&](int g, f32x4 (&v)[TT]) {
+#pragma unroll
+                for (int i = 0; i < TT; ++i) {
+                    if (AKC) v[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSA + 8 * g);
+                    else v[i] = (f32x4){a[(8 * g) * LDSA + i * 32], a[(8 * g + 1) * LDSA + i * 32], a[(8 * g + 2) * LDSA + i * 32],
+                                        a[(8 * g + 3) * LDSA + i * 32]};
+                }
+            };
+            auto frag_b = [&](int g, f32x4 (&v)[TT]) {
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    if (BKC) v[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSB + 8 * g);
+                    else v[j] = (f32x4){b[(8 * g) * LDSB + j * 32], b[(8 * g + 1) * LDSB + j * 32], b[(8 * g + 2) * LDSB + j * 32],
+                                        b[(8 * g + 3) * LDSB + j * 32]};
+                }
+            };
+            f32x4 af[2][TT], bf[2][TT];
+            frag_a(0, af[0]);
+            frag_b(0, bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < GKT / 8; ++g) {
+                if (g + 1 < GKT / 8) { frag_a(g + 1, af[(g + 1) & 1]); frag_b(g + 1, bf[(g + 1) & 1]); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TT; ++i)
+#pragma unroll
+                        for (int j = 0; j < TT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it + 1 < kiters) stf(As + (1 - ST) * ASZ, Bs + (1 - ST) * BSZ);
+            __syncthreads();
+        };
+        ldf(0);
+        stf(As, Bs);
+        __syncthreads();
+        {
+            int it = 0;
+            for (; it + 1 < kiters; it += 2) {
+                step(it, std::integral_constant<int, 0>{});
+                step(it + 1, std::integral_constant<int, 1>{});
+            }
+            if (it < kiters) step(it, std::integral_constant<int, 0>{});
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < PD; ++d) ld(sa[d], sb[d], d);
     st(sa[0], sb[0], 0);
@@ -310,6 +410,7 @@ __global__ __launch_bounds__(256, GKT == 16 ? 3 : 1) void gemm_kernel(const floa
         __syncthreads();
 #endif
         }
+    }
     }
     if constexpr (FAST && GKT == 16 && !BF) {
         // The batched Winograd-domain products (whole tiles, no bias / activation / split-K): 16-byte stores after a 4 x 4 transpose
@@ -417,7 +518,11 @@ void launch_gemm_t(const float* A, int lda, const float* B, int ldb, float* C, i
     int kchunk = (K + splits - 1) / splits;
     kchunk = (kchunk + KCH - 1) / KCH * KCH;
     // whole tiles, whole K chunks, no empty K slice, 16-byte aligned rows: the loader without tail handling
-    const bool fast = a_al && b_al && M % T == 0 && N % T == 0 && K % KCH == 0 && (long)(splits - 1) * kchunk < K;
+    // (... and, for the buffer-load form of the fp32 kernel, 32-bit byte offsets from a tile's origin)
+    const size_t lim = 0x7FFFFFFFull;
+    const bool off32 = (AKC ? ((size_t)T * lda + K) * 4 < lim : (size_t)K * lda * 4 < lim) &&
+                       (BKC ? ((size_t)T * ldb + K) * 4 < lim : (size_t)K * ldb * 4 < lim);
+    const bool fast = a_al && b_al && M % T == 0 && N % T == 0 && K % KCH == 0 && (long)(splits - 1) * kchunk < K && off32;
     if (fast) {
         static bool fast_attr_set = false;
         if (!fast_attr_set) {
